@@ -1,0 +1,99 @@
+// Minimal stand-in for dmlc-core's src/data/row_block.h (absent submodule):
+// an owning CSR builder.  Written from scratch; semantics taken from how the
+// reference uses it (BatchReader/Localizer): a fresh container has
+// offset == {0}; Push(Row)/Push(RowBlock) append; GetBlock() returns a view
+// whose optional arrays are nullptr when empty.
+#ifndef SHIM_DATA_ROW_BLOCK_H_
+#define SHIM_DATA_ROW_BLOCK_H_
+#include <algorithm>
+#include <vector>
+#include "dmlc/data.h"
+
+namespace dmlc {
+namespace data {
+
+template <typename IndexType>
+struct RowBlockContainer {
+  std::vector<size_t> offset;
+  std::vector<real_t> label;
+  std::vector<real_t> weight;
+  std::vector<IndexType> index;
+  std::vector<real_t> value;
+  IndexType max_index;
+
+  RowBlockContainer() { Clear(); }
+
+  inline void Clear() {
+    offset.assign(1, 0);
+    label.clear();
+    weight.clear();
+    index.clear();
+    value.clear();
+    max_index = 0;
+  }
+  inline size_t Size() const { return offset.size() - 1; }
+  inline size_t MemCostBytes() const {
+    return offset.size() * sizeof(size_t) + (label.size() + weight.size() + value.size()) * sizeof(real_t) +
+           index.size() * sizeof(IndexType);
+  }
+
+  /*! \brief append one example */
+  template <typename I>
+  inline void Push(Row<I> row) {
+    label.push_back(row.label);
+    if (!weight.empty() || row.weight != 1.0f) {
+      // keep weights dense once any non-unit weight shows up
+      weight.resize(label.size() - 1, 1.0f);
+      weight.push_back(row.weight);
+    }
+    for (size_t i = 0; i < row.length; ++i) {
+      IndexType id = static_cast<IndexType>(row.index[i]);
+      index.push_back(id);
+      max_index = std::max(max_index, id);
+    }
+    if (row.value != nullptr) {
+      value.insert(value.end(), row.value, row.value + row.length);
+    }
+    offset.push_back(index.size());
+  }
+
+  /*! \brief append a whole block (block.index/value point at its first nnz) */
+  template <typename I>
+  inline void Push(RowBlock<I> blk) {
+    if (blk.size == 0) return;
+    size_t nnz = blk.offset[blk.size] - blk.offset[0];
+    if (blk.label != nullptr) label.insert(label.end(), blk.label, blk.label + blk.size);
+    if (blk.weight != nullptr) weight.insert(weight.end(), blk.weight, blk.weight + blk.size);
+    size_t base = index.size();
+    index.resize(base + nnz);
+    for (size_t i = 0; i < nnz; ++i) {
+      IndexType id = static_cast<IndexType>(blk.index[i]);
+      index[base + i] = id;
+      max_index = std::max(max_index, id);
+    }
+    if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
+    size_t shift = offset.back();
+    for (size_t i = 0; i < blk.size; ++i) {
+      offset.push_back(shift + blk.offset[i + 1] - blk.offset[0]);
+    }
+  }
+
+  /*! \brief view of the stored rows */
+  inline RowBlock<IndexType> GetBlock() const {
+    if (!label.empty()) CHECK_EQ(label.size() + 1, offset.size());
+    CHECK_EQ(offset.back(), index.size());
+    CHECK(value.empty() || value.size() == offset.back());
+    RowBlock<IndexType> b;
+    b.size = offset.size() - 1;
+    b.offset = offset.data();
+    b.label = label.empty() ? nullptr : label.data();
+    b.weight = weight.empty() ? nullptr : weight.data();
+    b.index = index.empty() ? nullptr : index.data();
+    b.value = value.empty() ? nullptr : value.data();
+    return b;
+  }
+};
+
+}  // namespace data
+}  // namespace dmlc
+#endif  // SHIM_DATA_ROW_BLOCK_H_
