@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py — examples/sec of the FM/SGD worker step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torchrun)
+
+A "step" is one pass of the hot path over one Criteo-shaped synthetic minibatch
+(B rows x 39 slots, ids over 33 M features, V_dim=64, binary values) whose raw
+CSR (u64 feature ids) is already resident in HBM:
+    device Localizer::Compact -> Pull (table gather) -> FMLoss::Predict ->
+    Evaluate -> FMLoss::CalcGrad (segmented sum) -> Push -> FTRL/AdaGrad in place.
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10000, help="minibatch rows per GPU per step (criteo_sgd.conf:10)")
+    ap.add_argument("--ids", type=int, default=33_000_000, help="feature id space")
+    ap.add_argument("--vdim", type=int, default=64)
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic batches cycled through")
+    ap.add_argument("--no-prefill", action="store_true", help="start from an empty model instead of a warm one")
+    ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
+    ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
+    return ap.parse_args()
+
+
+HYPER = dict(l1=0.0, l2=0.0, V_l2=0.01, lr=0.01, lr_beta=1.0, V_lr=0.01, V_lr_beta=1.0, V_init_scale=0.01,
+             V_threshold=0, seed=0)
+
+
+def cpu_baseline(batches, V_dim, nbatches):
+    """the reference CPU path (oracle/_ref: the reference's own Localizer/SGDUpdater/FMLoss
+    compiled here) or the C port, timed on this box's host cores over `nbatches` batches"""
+    from oracle import bindings as ob
+    kind = "reference" if ob.have_ref() else "port"
+    t_total = 0.0
+    rows = 0
+    if kind == "reference":
+        R = ob.Ref()
+        st = R.store_create(V_dim=V_dim, **HYPER)
+        for b in batches[:nbatches]:
+            t0 = time.perf_counter()
+            loc = R.localize(b["offset"], b["index"], nthreads=2)
+            st.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
+            vals, lens = st.pull(loc["feaids"])
+            # GetPos (sgd_learner.cc:113-127), vectorised
+            ends = np.cumsum(lens)
+            w_pos = (ends - lens).astype(np.int32)
+            V_pos = np.where(lens > 1, w_pos + 1, -1).astype(np.int32)
+            pred, grad = R.fm_predict_calcgrad(V_dim, loc["offset"], loc["index"], None, b["label"], vals, w_pos, V_pos)
+            R.loss_evaluate(b["label"], pred)
+            st.push(loc["feaids"], ob.GRADIENT, grad, lens)
+            t_total += time.perf_counter() - t0
+            rows += len(b["label"])
+        cores = 2  # blk_nthreads_ = DEFAULT_NTHREADS (sgd_learner.h:90); the updater is single-threaded
+    else:
+        O = ob.Oracle()
+        st = O.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **HYPER)
+        for b in batches[:nbatches]:
+            t0 = time.perf_counter()
+            loc = O.localize(b["offset"], b["index"])
+            st.sgd_step(loc["offset"], loc["index"], None, b["label"], loc["feaids"], feacnt=loc["feacnt"], is_train=True)
+            t_total += time.perf_counter() - t0
+            rows += len(b["label"])
+        cores = 1
+    return dict(value=rows / t_total, unit="examples/sec", cores=cores, kind=kind,
+                sample="%d batches x %d rows of the same synthetic stream, model starting empty, "
+                       "localize+pull+predict+calcgrad+push, no file I/O" % (nbatches, len(batches[0]["label"])))
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from difacto_amd import sharded
+        return sharded.bench_main(args, rank, world, local_rank, HYPER)
+
+    import torch  # device plumbing only: barrier-equivalent sync + sanity that a GPU exists
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    from difacto_amd import capi, synth
+    from difacto_amd.build import build_hip
+    build_hip()
+
+    B, k = args.rows, args.vdim
+    S = synth.NUM_SLOTS
+    ctx = capi.Context(local_rank)
+    gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
+    table = capi.Table(ctx, int(args.ids * 1.02) + 4 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **HYPER)
+
+    t0 = time.time()
+    if not args.no_prefill:
+        # warm model: every feature id present with an allocated V row, so every
+        # gathered row moves its full (1+k)*4 bytes (worst-case traffic)
+        for g in range(S):
+            keys = synth.reverse_bytes_np(gen.all_ids(g))
+            chunk = 1 << 22
+            for o in range(0, len(keys), chunk):
+                part = np.ascontiguousarray(keys[o:o + chunk])
+                db = capi.DeviceBuffer.from_numpy(ctx, part)
+                table.warm_start(db.ptr, len(part), w0=0.01, cnt0=100.0)
+                ctx.sync()
+                db.close()
+    nkeys = table.size()
+    t_prefill = time.time() - t0
+
+    nd = max(1, min(args.distinct, args.steps + args.warmup))
+    host_batches = [gen.batch(B) for _ in range(nd)]
+    dev = []
+    for hb in host_batches:
+        off32 = hb["offset"].astype(np.uint32)
+        dev.append((capi.DeviceBuffer.from_numpy(ctx, off32), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
+                    capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
+    bt = capi.Batch(ctx, B, B * S)
+
+    def step(i):
+        o, x, l = dev[i % nd]
+        bt.load_device(B, B * S, o.ptr, x.ptr, None, l.ptr)
+        bt.localize()
+        bt.sgd_step(table, is_train=True, push_cnt=True)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    bt.progress(reset=True)
+    if not args.no_timing:
+        ctx.set_timing(True)
+        ctx.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prog = bt.progress(reset=True)
+    timing = {} if args.no_timing else ctx.get_timing(reset=True)
+    ctx.set_timing(False)
+    _, _, U_last = bt.shape()
+
+    ex_per_s = args.steps * B / dt
+    r_g = S * (1 + k) * 4  # algorithmic gather bytes per example
+    roofline = None
+    if timing and timing["forward"][1] > 0:
+        fwd_ms = timing["forward"][0] / timing["forward"][1]
+        achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="k_forward", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBPS, traffic=None,
+                        algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms)
+    nb = args.cpu_batches
+    cpu = None
+    if nb != 0:
+        if nb < 0:
+            nb = max(2, min(nd, int(200000 / B)))  # ~20 batches of 10k rows: tens of seconds of CPU work
+        cpu = cpu_baseline(host_batches, k, nb)
+
+    out = {
+        "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
+        "value": ex_per_s, "unit": "examples/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, FTRL(w)+AdaGrad(V), 1 MI355X"
+                               % (args.ids, k),
+                   "rows_per_step": B, "nnz_per_row": S, "unique_keys_last_batch": int(U_last),
+                   "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
+                   "model_keys": int(nkeys), "prefilled": not args.no_prefill, "hyper": HYPER,
+                   "distinct_batches": nd},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "kernel_ms_per_step": {n: (v[0] / max(args.steps, 1)) for n, v in timing.items() if v[1] > 0},
+        "train_logloss_per_example": prog.loss / max(prog.nrows, 1),
+        "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
+        "prefill_seconds": t_prefill,
+    }
+    print(json.dumps(out))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main() or 0)

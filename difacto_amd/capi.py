@@ -1,0 +1,411 @@
+"""ctypes binding of include/difacto_hip.h (the reference-side stub for a Python
+host; the C++ host in difacto_amd/host/ binds the same symbols)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdifacto_hip.so")
+
+FEA_COUNT, WEIGHT, GRADIENT = 1, 2, 3
+INIT_REFRAND, INIT_HASH = 0, 1
+U64MAX = 2 ** 64 - 1
+
+# every symbol include/difacto_hip.h declares (tests check the .so exports them all)
+SYMBOLS = [
+    "dfh_last_error", "dfh_updater_param_default", "dfh_ctx_create", "dfh_ctx_destroy", "dfh_ctx_sync",
+    "dfh_ctx_stream", "dfh_ctx_device", "dfh_reverse_bytes", "dfh_encode_fea_grp_id", "dfh_table_create",
+    "dfh_table_destroy", "dfh_table_size", "dfh_table_param", "dfh_table_bytes", "dfh_pull", "dfh_push",
+    "dfh_table_export", "dfh_table_import", "dfh_fm_predict", "dfh_fm_calcgrad", "dfh_loss_evaluate",
+    "dfh_auc_times_n", "dfh_batch_create", "dfh_batch_destroy", "dfh_batch_load_host", "dfh_batch_load_device",
+    "dfh_localize", "dfh_batch_load_localized_host", "dfh_batch_get_localized", "dfh_batch_shape", "dfh_sgd_step",
+    "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
+    "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
+    "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
+    "dfh_table_warm_start",
+]
+K_COUNT = 7
+
+
+class UpdaterParam(C.Structure):
+    """SGDUpdaterParam (src/sgd/sgd_param.h:66-107)"""
+    _fields_ = [("l1", C.c_float), ("l2", C.c_float), ("V_l2", C.c_float), ("lr", C.c_float),
+                ("lr_beta", C.c_float), ("V_lr", C.c_float), ("V_lr_beta", C.c_float),
+                ("V_init_scale", C.c_float), ("V_dim", C.c_int), ("V_threshold", C.c_int),
+                ("seed", C.c_uint), ("init_mode", C.c_int)]
+
+
+class Progress(C.Structure):
+    """sgd::Progress (src/sgd/sgd_utils.h:40-75)"""
+    _fields_ = [("loss", C.c_float), ("penalty", C.c_float), ("auc", C.c_float),
+                ("nnz_w", C.c_float), ("nrows", C.c_float)]
+
+
+class DfhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("difacto_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """load libdifacto_hip.so; raises (no fallback) if it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -m difacto_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, u64, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_float
+    PP = C.POINTER
+    L.dfh_last_error.restype = C.c_char_p
+    L.dfh_updater_param_default.argtypes = [PP(UpdaterParam), i32]
+    L.dfh_ctx_create.argtypes = [i32, vp, PP(vp)]
+    L.dfh_ctx_destroy.argtypes = [vp]
+    L.dfh_ctx_sync.argtypes = [vp]
+    L.dfh_ctx_stream.restype = vp
+    L.dfh_ctx_stream.argtypes = [vp]
+    L.dfh_ctx_device.argtypes = [vp]
+    L.dfh_reverse_bytes.restype = u64
+    L.dfh_reverse_bytes.argtypes = [u64]
+    L.dfh_encode_fea_grp_id.restype = u64
+    L.dfh_encode_fea_grp_id.argtypes = [u64, i32, i32]
+    L.dfh_table_create.argtypes = [vp, PP(UpdaterParam), u64, PP(vp)]
+    L.dfh_table_destroy.argtypes = [vp]
+    L.dfh_table_size.argtypes = [vp, PP(u64)]
+    L.dfh_table_param.argtypes = [vp, PP(UpdaterParam)]
+    L.dfh_table_bytes.restype = u64
+    L.dfh_table_bytes.argtypes = [vp]
+    L.dfh_pull.argtypes = [vp, vp, sz, vp, PP(sz), vp, PP(sz)]
+    L.dfh_push.argtypes = [vp, vp, sz, i32, vp, sz, vp, sz]
+    L.dfh_table_export.argtypes = [vp, u64, vp, vp, vp, vp, PP(u64)]
+    L.dfh_table_import.argtypes = [vp, u64, vp, vp, vp, vp]
+    L.dfh_fm_predict.argtypes = [vp, i32, sz, vp, vp, vp, vp, sz, vp, vp, sz, vp]
+    L.dfh_fm_calcgrad.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp, sz, vp, vp, sz, vp, vp]
+    L.dfh_loss_evaluate.argtypes = [vp, vp, vp, sz, PP(f32)]
+    L.dfh_auc_times_n.argtypes = [vp, vp, vp, sz, PP(f32)]
+    L.dfh_batch_create.argtypes = [vp, sz, sz, PP(vp)]
+    L.dfh_batch_destroy.argtypes = [vp]
+    L.dfh_batch_load_host.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.dfh_batch_load_device.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.dfh_localize.argtypes = [vp, u64]
+    L.dfh_batch_load_localized_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz]
+    L.dfh_batch_get_localized.argtypes = [vp, PP(sz), vp, vp, vp]
+    L.dfh_batch_shape.argtypes = [vp, PP(sz), PP(sz), PP(sz)]
+    L.dfh_sgd_step.argtypes = [vp, vp, i32, i32]
+    L.dfh_batch_progress.argtypes = [vp, PP(Progress), i32]
+    L.dfh_batch_get_pred.argtypes = [vp, vp]
+    L.dfh_row_stride.restype = sz
+    L.dfh_row_stride.argtypes = [i32]
+    L.dfh_shard_pull.argtypes = [vp, vp, sz, vp]
+    L.dfh_shard_push_count.argtypes = [vp, vp, sz, vp]
+    L.dfh_shard_push_grad.argtypes = [vp, vp, sz, vp]
+    L.dfh_batch_forward.argtypes = [vp, i32, vp]
+    L.dfh_batch_backward.argtypes = [vp, i32, vp, vp]
+    L.dfh_batch_device_keys.argtypes = [vp, PP(vp), PP(vp), PP(sz)]
+    L.dfh_malloc.argtypes = [vp, sz, PP(vp)]
+    L.dfh_free.argtypes = [vp, vp]
+    L.dfh_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.dfh_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.dfh_table_warm_start.argtypes = [vp, vp, sz, f32, f32]
+    L.dfh_ctx_set_timing.argtypes = [vp, i32]
+    L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
+    L.dfh_kernel_name.restype = C.c_char_p
+    L.dfh_kernel_name.argtypes = [i32]
+    _lib = L
+    return L
+
+
+def _ck(rc):
+    if rc != 0:
+        raise DfhError(rc, lib().dfh_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(x):
+    """device pointer: int, c_void_p or a torch tensor"""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return x if isinstance(x, C.c_void_p) else C.c_void_p(int(x))
+
+
+def make_param(V_dim=0, init_mode=INIT_HASH, **kw):
+    p = UpdaterParam()
+    lib().dfh_updater_param_default(C.byref(p), V_dim)
+    p.init_mode = init_mode
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def reverse_bytes(x):
+    return int(lib().dfh_reverse_bytes(int(x)))
+
+
+class Context:
+    """a HIP device + stream (dfh_ctx)"""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _ck(lib().dfh_ctx_create(device, _dp(stream), C.byref(self.h)))
+
+    def sync(self):
+        _ck(lib().dfh_ctx_sync(self.h))
+
+    def set_timing(self, on=True):
+        _ck(lib().dfh_ctx_set_timing(self.h, 1 if on else 0))
+
+    def get_timing(self, reset=True):
+        """{kernel name: (total_ms, calls)} from HIP events on this context's stream"""
+        ms = np.zeros(K_COUNT, np.float64)
+        calls = np.zeros(K_COUNT, np.uint64)
+        _ck(lib().dfh_ctx_get_timing(self.h, 1 if reset else 0, _p(ms), _p(calls)))
+        return {lib().dfh_kernel_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(K_COUNT)}
+
+    @property
+    def stream(self):
+        return lib().dfh_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().dfh_ctx_destroy(self.h)
+            self.h = None
+
+    # literal Loss API ------------------------------------------------------
+    def fm_predict(self, V_dim, offset, index, value, weights, w_pos=None, V_pos=None, pred0=None):
+        """FMLoss::Predict (src/loss/fm_loss.h:67-119)"""
+        offset = np.ascontiguousarray(offset, np.uint64)
+        index = np.ascontiguousarray(index, np.uint32)
+        value = None if value is None else np.ascontiguousarray(value, np.float32)
+        weights = np.ascontiguousarray(weights, np.float32)
+        n = len(offset) - 1
+        pred = np.zeros(n, np.float32) if pred0 is None else np.array(pred0, np.float32)
+        npos = 0 if w_pos is None else len(w_pos)
+        w_pos = None if w_pos is None else np.ascontiguousarray(w_pos, np.int32)
+        V_pos = None if V_pos is None else np.ascontiguousarray(V_pos, np.int32)
+        _ck(lib().dfh_fm_predict(self.h, V_dim, n, _p(offset), _p(index), _p(value), _p(weights), len(weights),
+                                 _p(w_pos), _p(V_pos), npos, _p(pred)))
+        return pred
+
+    def fm_calcgrad(self, V_dim, offset, index, value, label, weights, pred, w_pos=None, V_pos=None):
+        """FMLoss::CalcGrad (src/loss/fm_loss.h:148-199)"""
+        offset = np.ascontiguousarray(offset, np.uint64)
+        index = np.ascontiguousarray(index, np.uint32)
+        value = None if value is None else np.ascontiguousarray(value, np.float32)
+        weights = np.ascontiguousarray(weights, np.float32)
+        label = np.ascontiguousarray(label, np.float32)
+        pred = np.ascontiguousarray(pred, np.float32)
+        n = len(offset) - 1
+        grad = np.zeros(len(weights), np.float32)
+        npos = 0 if w_pos is None else len(w_pos)
+        w_pos = None if w_pos is None else np.ascontiguousarray(w_pos, np.int32)
+        V_pos = None if V_pos is None else np.ascontiguousarray(V_pos, np.int32)
+        _ck(lib().dfh_fm_calcgrad(self.h, V_dim, n, _p(offset), _p(index), _p(value), _p(label), _p(weights),
+                                  len(weights), _p(w_pos), _p(V_pos), npos, _p(pred), _p(grad)))
+        return grad
+
+    def loss_evaluate(self, label, pred):
+        label = np.ascontiguousarray(label, np.float32)
+        pred = np.ascontiguousarray(pred, np.float32)
+        o = C.c_float(0)
+        _ck(lib().dfh_loss_evaluate(self.h, _p(label), _p(pred), len(pred), C.byref(o)))
+        return o.value
+
+
+class Table:
+    """one shard of the model in HBM (dfh_table): replaces Store + SGDUpdater state"""
+
+    def __init__(self, ctx, capacity, V_dim=0, init_mode=INIT_HASH, **kw):
+        self.ctx = ctx
+        self.param = make_param(V_dim, init_mode, **kw)
+        self.V_dim = V_dim
+        self.h = C.c_void_p()
+        _ck(lib().dfh_table_create(ctx.h, C.byref(self.param), capacity, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dfh_table_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        n = C.c_uint64(0)
+        _ck(lib().dfh_table_size(self.h, C.byref(n)))
+        return n.value
+
+    def bytes(self):
+        return int(lib().dfh_table_bytes(self.h))
+
+    def pull(self, keys):
+        """Store::Pull(kWeight) -> (vals ragged, lens)"""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        n = len(keys)
+        vals = np.zeros(max(n * (1 + self.V_dim), 1), np.float32)
+        lens = np.zeros(max(n, 1), np.int32)
+        nv, nl = C.c_size_t(0), C.c_size_t(0)
+        _ck(lib().dfh_pull(self.h, _p(keys), n, _p(vals), C.byref(nv), _p(lens), C.byref(nl)))
+        return vals[:nv.value].copy(), lens[:nl.value].copy()
+
+    def push(self, keys, val_type, vals, lens=None):
+        """Store::Push(kFeaCount | kGradient)"""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        vals = np.ascontiguousarray(vals, np.float32)
+        lens = np.zeros(0, np.int32) if lens is None else np.ascontiguousarray(lens, np.int32)
+        _ck(lib().dfh_push(self.h, _p(keys), len(keys), val_type, _p(vals), len(vals), _p(lens), len(lens)))
+
+    def export(self):
+        n = self.size()
+        k = self.V_dim
+        keys = np.zeros(max(n, 1), np.uint64)
+        scal = np.zeros(max(n, 1) * 4, np.float32)
+        has = np.zeros(max(n, 1), np.int32)
+        V = np.zeros(max(n * 2 * k, 1), np.float32)
+        m = C.c_uint64(0)
+        _ck(lib().dfh_table_export(self.h, max(n, 1), _p(keys), _p(scal), _p(has), _p(V), C.byref(m)))
+        n = m.value
+        return dict(keys=keys[:n], scal=scal[:4 * n].reshape(n, 4), has_V=has[:n], V=V[:n * 2 * k].reshape(n, 2 * k) if k else None)
+
+    def import_(self, keys, scal, has_V, V=None):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        scal = np.ascontiguousarray(scal, np.float32)
+        has_V = np.ascontiguousarray(has_V, np.int32)
+        V = None if V is None else np.ascontiguousarray(V, np.float32)
+        _ck(lib().dfh_table_import(self.h, len(keys), _p(keys), _p(scal), _p(has_V), _p(V)))
+
+    def warm_start(self, d_keys, n, w0=0.01, cnt0=100.0):
+        _ck(lib().dfh_table_warm_start(self.h, _dp(d_keys), n, w0, cnt0))
+
+    # device-pointer (sharded) calls
+    def shard_pull(self, d_keys, n, d_rows):
+        _ck(lib().dfh_shard_pull(self.h, _dp(d_keys), n, _dp(d_rows)))
+
+    def shard_push_count(self, d_keys, n, d_cnt):
+        _ck(lib().dfh_shard_push_count(self.h, _dp(d_keys), n, _dp(d_cnt)))
+
+    def shard_push_grad(self, d_keys, n, d_grads):
+        _ck(lib().dfh_shard_push_grad(self.h, _dp(d_keys), n, _dp(d_grads)))
+
+
+class Batch:
+    """a device-resident minibatch + workspace (dfh_batch)"""
+
+    def __init__(self, ctx, max_rows, max_nnz):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _ck(lib().dfh_batch_create(ctx.h, max_rows, max_nnz, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dfh_batch_destroy(self.h)
+            self.h = None
+
+    def load_host(self, offset, index, value, label):
+        """raw CSR with u64 feature ids (what Reader::Value() yields)"""
+        offset = np.ascontiguousarray(offset, np.uint64)
+        index = np.ascontiguousarray(index, np.uint64)
+        value = None if value is None else np.ascontiguousarray(value, np.float32)
+        label = np.ascontiguousarray(label, np.float32)
+        _ck(lib().dfh_batch_load_host(self.h, len(offset) - 1, _p(offset), _p(index), _p(value), _p(label)))
+
+    def load_device(self, nrows, nnz, d_offset, d_index, d_value, d_label):
+        _ck(lib().dfh_batch_load_device(self.h, nrows, nnz, _dp(d_offset), _dp(d_index), _dp(d_value), _dp(d_label)))
+
+    def localize(self, max_index=U64MAX):
+        """Localizer::Compact on device"""
+        _ck(lib().dfh_localize(self.h, max_index))
+
+    def load_localized_host(self, offset, index, value, label, feaids, feacnt=None):
+        offset = np.ascontiguousarray(offset, np.uint64)
+        index = np.ascontiguousarray(index, np.uint32)
+        value = None if value is None else np.ascontiguousarray(value, np.float32)
+        label = np.ascontiguousarray(label, np.float32)
+        feaids = np.ascontiguousarray(feaids, np.uint64)
+        feacnt = None if feacnt is None else np.ascontiguousarray(feacnt, np.float32)
+        _ck(lib().dfh_batch_load_localized_host(self.h, len(offset) - 1, _p(offset), _p(index), _p(value), _p(label),
+                                                _p(feaids), _p(feacnt), len(feaids)))
+
+    def shape(self, want_U=True):
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        _ck(lib().dfh_batch_shape(self.h, C.byref(a), C.byref(b), C.byref(c) if want_U else None))
+        return a.value, b.value, c.value
+
+    def get_localized(self):
+        nrows, nnz, U = self.shape()
+        feaids = np.zeros(max(U, 1), np.uint64)
+        cnt = np.zeros(max(U, 1), np.float32)
+        index = np.zeros(max(nnz, 1), np.uint32)
+        u = C.c_size_t(0)
+        _ck(lib().dfh_batch_get_localized(self.h, C.byref(u), _p(feaids), _p(cnt), _p(index)))
+        return dict(U=U, feaids=feaids[:U], feacnt=cnt[:U], index=index[:nnz])
+
+    def sgd_step(self, table, is_train=True, push_cnt=False):
+        """the batch executor of SGDLearner::IterateData, on device (async)"""
+        _ck(lib().dfh_sgd_step(table.h, self.h, 1 if is_train else 0, 1 if push_cnt else 0))
+
+    def progress(self, reset=True):
+        p = Progress()
+        _ck(lib().dfh_batch_progress(self.h, C.byref(p), 1 if reset else 0))
+        return p
+
+    def pred(self):
+        nrows, _, _ = self.shape(want_U=False)
+        out = np.zeros(nrows, np.float32)
+        _ck(lib().dfh_batch_get_pred(self.h, _p(out)))
+        return out
+
+    def forward(self, V_dim, d_rows):
+        _ck(lib().dfh_batch_forward(self.h, V_dim, _dp(d_rows)))
+
+    def backward(self, V_dim, d_rows, d_grads):
+        _ck(lib().dfh_batch_backward(self.h, V_dim, _dp(d_rows), _dp(d_grads)))
+
+    def device_keys(self):
+        a, b, u = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        _ck(lib().dfh_batch_device_keys(self.h, C.byref(a), C.byref(b), C.byref(u)))
+        return a.value, b.value, u.value
+
+
+class DeviceBuffer:
+    """raw device memory owned through the C ABI (dfh_malloc)"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = C.c_void_p()
+        _ck(lib().dfh_malloc(ctx.h, nbytes, C.byref(self.ptr)))
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(ctx, max(arr.nbytes, 16))
+        if arr.nbytes:
+            _ck(lib().dfh_memcpy_h2d(ctx.h, b.ptr, _p(arr), arr.nbytes))
+        return b
+
+    def to_numpy(self, dtype, count):
+        out = np.zeros(count, dtype)
+        if out.nbytes:
+            _ck(lib().dfh_memcpy_d2h(self.ctx.h, _p(out), self.ptr, out.nbytes))
+        return out
+
+    def at(self, byte_offset):
+        return C.c_void_p(self.ptr.value + byte_offset)
+
+    def close(self):
+        if self.ptr:
+            lib().dfh_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+def row_stride(V_dim):
+    return int(lib().dfh_row_stride(V_dim))

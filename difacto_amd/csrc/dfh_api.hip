@@ -1,0 +1,1279 @@
+// C ABI of libdifacto_hip (include/difacto_hip.h): handle management, host<->device
+// staging for the literal Store/Loss calls, and kernel orchestration.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include <rocprim/rocprim.hpp>
+
+#include "dfh_kernels.hip"
+
+using namespace dfh;
+
+namespace dfh {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace dfh
+
+// --------------------------------------------------------------------- handles
+struct dfh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // monotonic scratch for the literal (host-pointer) calls
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  int num_cu = 256;
+  // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
+  bool timing = false;
+  struct Span { int id; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+  double t_ms[DFH_K_COUNT] = {0};
+  uint64_t t_calls[DFH_K_COUNT] = {0};
+};
+
+namespace {
+// brackets the launches of one logical kernel with HIP events on the ctx stream
+struct TimeScope {
+  dfh_ctx* c;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  static hipEvent_t get(dfh_ctx* c) {
+    if (!c->pool.empty()) {
+      hipEvent_t e = c->pool.back();
+      c->pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  TimeScope(dfh_ctx* ctx, int kid) : c(ctx), id(kid) {
+    if (!c->timing) return;
+    a = get(c);
+    b = get(c);
+    if (a && b) (void)hipEventRecord(a, c->stream);
+  }
+  ~TimeScope() {
+    if (!c->timing || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->spans.push_back({id, a, b});
+  }
+};
+}  // namespace
+
+struct dfh_table {
+  dfh_ctx* ctx = nullptr;
+  TableView v{};
+  uint64_t hslots = 0;
+  uint64_t bytes = 0;
+  // REFRAND scratch (need/rank/urow per pushed key) for the literal + shard calls
+  uint32_t* d_need = nullptr;
+  uint32_t* d_rank = nullptr;
+  uint32_t* d_urow = nullptr;
+  uint32_t* d_total = nullptr;
+  size_t aux_cap = 0;
+};
+
+struct dfh_batch {
+  dfh_ctx* ctx = nullptr;
+  size_t max_rows = 0, max_nnz = 0;
+  size_t nrows = 0, nnz = 0;
+  bool has_value = false;
+  bool has_cnt = false;
+  bool localized = false;
+  // raw input
+  uint64_t* d_raw = nullptr;
+  uint32_t* d_offset = nullptr;
+  float* d_value = nullptr;
+  float* d_label = nullptr;
+  // localizer workspace
+  uint64_t *d_keys = nullptr, *d_skeys = nullptr;
+  uint32_t *d_pos = nullptr, *d_spos = nullptr, *d_head = nullptr, *d_uid = nullptr;
+  void* d_temp = nullptr;
+  size_t temp_bytes = 0;
+  // localized view
+  uint64_t* d_feaids = nullptr;
+  float* d_feacnt = nullptr;
+  uint32_t *d_col_ptr = nullptr, *d_index = nullptr, *d_s_row = nullptr;
+  float* d_s_val = nullptr;
+  uint32_t* d_U = nullptr;
+  // step workspace
+  uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
+  float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
+  size_t xv_floats = 0;
+  double* d_prog = nullptr;
+  float nrows_seen = 0;
+};
+
+namespace {
+
+inline int grid_for_threads(size_t n, const dfh_ctx* c) {
+  size_t b = (n + 255) / 256;
+  size_t cap = (size_t)c->num_cu * 8;
+  return (int)std::max<size_t>(1, std::min(b, cap));
+}
+inline int grid_for_waves(size_t nwaves, const dfh_ctx* c) {
+  size_t b = (nwaves + 3) / 4;
+  size_t cap = (size_t)c->num_cu * 8;
+  return (int)std::max<size_t>(1, std::min(b, cap));
+}
+
+int ensure_scratch(dfh_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return DFH_OK;
+  if (c->scratch) {
+    DFH_HIP(hipStreamSynchronize(c->stream));
+    DFH_HIP(hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+  }
+  size_t want = std::max(bytes, (size_t)1 << 20);
+  want = (want + 255) & ~(size_t)255;
+  DFH_HIP(hipMalloc(&c->scratch, want));
+  c->scratch_bytes = want;
+  return DFH_OK;
+}
+
+// carve aligned pieces out of the scratch block
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+template <typename T>
+size_t padded(size_t n) { return ((n * sizeof(T)) + 255 + 256) & ~(size_t)255; }
+
+int check_table_err(dfh_table* t) {
+  uint32_t e = 0;
+  DFH_HIP(hipMemcpyAsync(&e, t->v.err, sizeof(e), hipMemcpyDeviceToHost, t->ctx->stream));
+  DFH_HIP(hipStreamSynchronize(t->ctx->stream));
+  if (e & 1u) {
+    set_error("model table is full (capacity_rows exceeded)");
+    return DFH_ERR_CAPACITY;
+  }
+  if (e & 2u) {
+    set_error("duplicate key inside one push/pull");
+    return DFH_ERR_ARG;
+  }
+  if (e & 4u) {
+    set_error("gradient carries V for a key whose V is not allocated (reference CHECK(e.V != nullptr))");
+    return DFH_ERR_ARG;
+  }
+  return DFH_OK;
+}
+
+int ensure_table_aux(dfh_table* t, size_t n) {
+  if (n <= t->aux_cap) return DFH_OK;
+  if (t->d_need) {
+    DFH_HIP(hipStreamSynchronize(t->ctx->stream));
+    DFH_HIP(hipFree(t->d_need));
+    DFH_HIP(hipFree(t->d_rank));
+    DFH_HIP(hipFree(t->d_urow));
+  }
+  size_t cap = std::max<size_t>(n, 1024);
+  DFH_HIP(hipMalloc(&t->d_need, cap * sizeof(uint32_t)));
+  DFH_HIP(hipMalloc(&t->d_rank, cap * sizeof(uint32_t)));
+  DFH_HIP(hipMalloc(&t->d_urow, cap * sizeof(uint32_t)));
+  t->aux_cap = cap;
+  return DFH_OK;
+}
+
+// REFRAND: initialise the rows flagged in need[0..n) in key order, advance the chain
+int refrand_flush(dfh_table* t, const uint64_t* d_keys, const uint32_t* d_n, uint32_t n_static, const uint32_t* d_urow,
+                  const uint32_t* d_need, uint32_t* d_rank, uint32_t* d_total) {
+  hipStream_t s = t->ctx->stream;
+  TimeScope ts(t->ctx, DFH_K_MISC);
+  hipLaunchKernelGGL(k_refrand_scan, dim3(1), dim3(1024), 0, s, d_need, d_n, n_static, d_rank, d_total);
+  hipLaunchKernelGGL(k_refrand_init, dim3(grid_for_threads(n_static, t->ctx)), dim3(256), 0, s, t->v, d_keys, d_n,
+                     n_static, d_urow, d_need, d_rank);
+  hipLaunchKernelGGL(k_refrand_advance, dim3(1), dim3(64), 0, s, t->v, d_total);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+inline int lanes_for(int kp) {
+  int nvec = kp / 4;
+  int L = 1;
+  while (L < nvec) L <<= 1;
+  return L;
+}
+
+RowSrc table_src(const dfh_table* t, const uint32_t* urow) {
+  RowSrc s;
+  s.wbase = reinterpret_cast<const float*>(t->v.hdr);
+  s.wstride = sizeof(RowHdr) / sizeof(float);
+  s.vbase = t->v.va;
+  s.vstride = (size_t)2 * t->v.kp;
+  s.urow = urow;
+  s.flag_is_float = 0;
+  return s;
+}
+
+RowSrc packed_src(const float* rows, int V_dim) {
+  RowSrc s;
+  size_t stride = dfh_row_stride(V_dim);
+  s.wbase = rows;
+  s.wstride = stride;
+  s.vbase = rows + 4;
+  s.vstride = stride;
+  s.urow = nullptr;
+  s.flag_is_float = 1;
+  return s;
+}
+
+BatchView batch_view(const dfh_batch* b) {
+  BatchView v;
+  v.nrows = (uint32_t)b->nrows;
+  v.nnz = (uint32_t)b->nnz;
+  v.d_U = b->d_U;
+  v.offset = b->d_offset;
+  v.index = b->d_index;
+  v.value = b->has_value ? b->d_value : nullptr;
+  v.label = b->d_label;
+  v.feaids = b->d_feaids;
+  v.col_ptr = b->d_col_ptr;
+  v.s_row = b->d_s_row;
+  v.s_val = b->has_value ? b->d_s_val : nullptr;
+  v.urow = b->d_urow;
+  v.pred = b->d_pred;
+  v.slope = b->d_slope;
+  v.xv = b->d_xv;
+  v.prog = b->d_prog;
+  return v;
+}
+
+int ensure_xv(dfh_batch* b, int kp) {
+  size_t need = b->max_rows * (size_t)std::max(kp, 4);
+  if (need <= b->xv_floats) return DFH_OK;
+  if (b->d_xv) {
+    DFH_HIP(hipStreamSynchronize(b->ctx->stream));
+    DFH_HIP(hipFree(b->d_xv));
+  }
+  DFH_HIP(hipMalloc(&b->d_xv, need * sizeof(float)));
+  b->xv_floats = need;
+  return DFH_OK;
+}
+
+template <typename F>
+int dispatch_L(int kp, F&& f) {
+  switch (lanes_for(kp)) {
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 8: f(std::integral_constant<int, 8>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 32: f(std::integral_constant<int, 32>()); break;
+    case 64: f(std::integral_constant<int, 64>()); break;
+    default:
+      set_error("V_dim > 256 is not supported by the wave-per-row kernels");
+      return DFH_ERR_ARG;
+  }
+  return DFH_OK;
+}
+
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp) {
+  BatchView bv = batch_view(b);
+  int grid = grid_for_waves(b->nrows, b->ctx);
+  hipStream_t s = b->ctx->stream;
+  TimeScope ts(b->ctx, DFH_K_FORWARD);
+  int rc = dispatch_L(kp, [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    hipLaunchKernelGGL((k_forward<L>), dim3(grid), dim3(256), 0, s, bv, src, k, kp);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+template <bool FUSED>
+int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
+                    uint32_t* need) {
+  BatchView bv = batch_view(b);
+  // U lives on the device; nnz bounds it
+  int grid = grid_for_waves(b->nnz, b->ctx);
+  hipStream_t s = b->ctx->stream;
+  TimeScope ts(b->ctx, DFH_K_BACKWARD);
+  int rc = dispatch_L(kp, [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    hipLaunchKernelGGL((k_backward<L, FUSED>), dim3(grid), dim3(256), 0, s, bv, src, tv, grads, gstride, k, kp, need);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" {
+
+const char* dfh_last_error(void) { return g_err.c_str(); }
+
+void dfh_updater_param_default(dfh_updater_param* p, int V_dim) {
+  // src/sgd/sgd_param.h:95-105
+  p->l1 = 1.0f;
+  p->l2 = 0.0f;
+  p->V_l2 = 0.01f;
+  p->lr = 0.01f;
+  p->lr_beta = 1.0f;
+  p->V_lr = 0.01f;
+  p->V_lr_beta = 1.0f;
+  p->V_init_scale = 0.01f;
+  p->V_threshold = 10;
+  p->V_dim = V_dim;
+  p->seed = 0;
+  p->init_mode = DFH_INIT_HASH;
+}
+
+uint64_t dfh_reverse_bytes(uint64_t x) { return reverse_bytes(x); }
+uint64_t dfh_encode_fea_grp_id(uint64_t x, int gid, int nbits) { return (x << nbits) | (uint64_t)gid; }
+size_t dfh_row_stride(int V_dim) { return 4 + (size_t)((V_dim + 3) / 4) * 4; }
+
+// ------------------------------------------------------------------ context
+int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
+  DFH_ARG(out != nullptr, "dfh_ctx_create: out is NULL");
+  int ndev = 0;
+  DFH_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0 || device < 0 || device >= ndev) {
+    set_error("dfh_ctx_create: no such HIP device (this library has no CPU fallback)");
+    return DFH_ERR_HIP;
+  }
+  DFH_HIP(hipSetDevice(device));
+  dfh_ctx* c = new (std::nothrow) dfh_ctx();
+  DFH_ARG(c != nullptr, "out of host memory");
+  c->device = device;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+      return DFH_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  *out = c;
+  return DFH_OK;
+}
+
+int dfh_ctx_destroy(dfh_ctx* c) {
+  if (!c) return DFH_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->scratch) hipFree(c->scratch);
+  for (auto& sp : c->spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  for (auto e : c->pool) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return DFH_OK;
+}
+
+int dfh_ctx_sync(dfh_ctx* c) {
+  DFH_ARG(c, "ctx is NULL");
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  return DFH_OK;
+}
+void* dfh_ctx_stream(dfh_ctx* c) { return c ? c->stream : nullptr; }
+int dfh_ctx_device(dfh_ctx* c) { return c ? c->device : -1; }
+
+int dfh_ctx_set_timing(dfh_ctx* c, int enable) {
+  DFH_ARG(c, "ctx is NULL");
+  c->timing = enable != 0;
+  return DFH_OK;
+}
+
+int dfh_ctx_get_timing(dfh_ctx* c, int reset, double* total_ms, uint64_t* calls) {
+  DFH_ARG(c, "ctx is NULL");
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  for (auto& sp : c->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      c->t_ms[sp.id] += ms;
+      c->t_calls[sp.id] += 1;
+    }
+    c->pool.push_back(sp.a);
+    c->pool.push_back(sp.b);
+  }
+  c->spans.clear();
+  for (int i = 0; i < DFH_K_COUNT; ++i) {
+    if (total_ms) total_ms[i] = c->t_ms[i];
+    if (calls) calls[i] = c->t_calls[i];
+    if (reset) {
+      c->t_ms[i] = 0;
+      c->t_calls[i] = 0;
+    }
+  }
+  return DFH_OK;
+}
+
+const char* dfh_kernel_name(int id) {
+  static const char* names[DFH_K_COUNT] = {"localize", "lookup", "forward", "backward", "pull_rows", "push_grad", "misc"};
+  return (id >= 0 && id < DFH_K_COUNT) ? names[id] : "?";
+}
+
+int dfh_malloc(dfh_ctx* c, size_t bytes, void** dptr) {
+  DFH_ARG(c && dptr, "dfh_malloc: NULL argument");
+  DFH_HIP(hipSetDevice(c->device));
+  DFH_HIP(hipMalloc(dptr, std::max<size_t>(bytes, 16)));
+  return DFH_OK;
+}
+int dfh_free(dfh_ctx* c, void* dptr) {
+  DFH_ARG(c, "ctx is NULL");
+  if (dptr) DFH_HIP(hipFree(dptr));
+  return DFH_OK;
+}
+int dfh_memcpy_h2d(dfh_ctx* c, void* dst, const void* src, size_t bytes) {
+  DFH_ARG(c, "ctx is NULL");
+  DFH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  return DFH_OK;
+}
+int dfh_memcpy_d2h(dfh_ctx* c, void* dst, const void* src, size_t bytes) {
+  DFH_ARG(c, "ctx is NULL");
+  DFH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  return DFH_OK;
+}
+
+// -------------------------------------------------------------------- table
+int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out) {
+  DFH_ARG(c && p && out, "dfh_table_create: NULL argument");
+  DFH_ARG(p->V_dim >= 0 && p->V_dim <= 10000, "V_dim out of range [0, 10000] (FMLossParam, fm_loss.h:25)");
+  DFH_ARG(capacity_rows >= 1 && capacity_rows < 0xFFFFFFF0ULL, "capacity_rows must be in [1, 2^32-16)");
+  DFH_ARG(p->lr > 0, "lr must be > 0");
+  DFH_ARG(p->init_mode == DFH_INIT_HASH || p->init_mode == DFH_INIT_REFRAND, "bad init_mode");
+  DFH_HIP(hipSetDevice(c->device));
+  dfh_table* t = new (std::nothrow) dfh_table();
+  DFH_ARG(t != nullptr, "out of host memory");
+  t->ctx = c;
+  TableView& v = t->v;
+  v.p = *p;
+  v.k = p->V_dim;
+  v.kp = (p->V_dim + 3) / 4 * 4;
+  v.capacity = (uint32_t)capacity_rows;
+  uint64_t H = 1024;
+  while (H < 2 * capacity_rows) H <<= 1;
+  t->hslots = H;
+  v.hmask = H - 1;
+  size_t ht_b = H * sizeof(HEntry);
+  size_t hdr_b = capacity_rows * sizeof(RowHdr);
+  size_t va_b = std::max<size_t>(capacity_rows * (size_t)(2 * v.kp) * sizeof(float), 256);
+  hipError_t e;
+  if ((e = hipMalloc(&v.ht, ht_b)) != hipSuccess || (e = hipMalloc(&v.hdr, hdr_b)) != hipSuccess ||
+      (e = hipMalloc(&v.va, va_b)) != hipSuccess || (e = hipMalloc(&v.nrows, 256)) != hipSuccess) {
+    set_error(std::string("dfh_table_create: hipMalloc: ") + hipGetErrorString(e));
+    if (v.ht) hipFree(v.ht);
+    if (v.hdr) hipFree(v.hdr);
+    if (v.va) hipFree(v.va);
+    delete t;
+    return DFH_ERR_HIP;
+  }
+  v.err = v.nrows + 1;
+  v.rng_state = v.nrows + 2;
+  t->d_total = v.nrows + 3;
+  t->bytes = ht_b + hdr_b + va_b;
+  DFH_HIP(hipMemsetAsync(v.ht, 0xFF, ht_b, c->stream));  // key = ~0 (empty), row = ~0
+  DFH_HIP(hipMemsetAsync(v.hdr, 0, hdr_b, c->stream));
+  DFH_HIP(hipMemsetAsync(v.va, 0, va_b, c->stream));
+  DFH_HIP(hipMemsetAsync(v.nrows, 0, 256, c->stream));
+  uint32_t seed = p->seed;
+  DFH_HIP(hipMemcpyAsync(v.rng_state, &seed, sizeof(seed), hipMemcpyHostToDevice, c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  *out = t;
+  return DFH_OK;
+}
+
+int dfh_table_destroy(dfh_table* t) {
+  if (!t) return DFH_OK;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  hipFree(t->v.ht);
+  hipFree(t->v.hdr);
+  hipFree(t->v.va);
+  hipFree(t->v.nrows);
+  if (t->d_need) {
+    hipFree(t->d_need);
+    hipFree(t->d_rank);
+    hipFree(t->d_urow);
+  }
+  delete t;
+  return DFH_OK;
+}
+
+int dfh_table_size(dfh_table* t, uint64_t* nkeys) {
+  DFH_ARG(t && nkeys, "NULL argument");
+  uint32_t n = 0;
+  DFH_HIP(hipMemcpyAsync(&n, t->v.nrows, sizeof(n), hipMemcpyDeviceToHost, t->ctx->stream));
+  DFH_HIP(hipStreamSynchronize(t->ctx->stream));
+  *nkeys = std::min<uint64_t>(n, t->v.capacity);
+  return check_table_err(t);
+}
+
+int dfh_table_param(dfh_table* t, dfh_updater_param* out) {
+  DFH_ARG(t && out, "NULL argument");
+  *out = t->v.p;
+  return DFH_OK;
+}
+uint64_t dfh_table_bytes(dfh_table* t) { return t ? t->bytes : 0; }
+
+int dfh_table_warm_start(dfh_table* t, const uint64_t* d_keys, size_t n, float w0, float cnt0) {
+  DFH_ARG(t && (n == 0 || d_keys), "dfh_table_warm_start: NULL argument");
+  if (n == 0) return DFH_OK;
+  hipLaunchKernelGGL(k_warm_start, dim3(grid_for_waves(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
+                     (uint64_t)n, w0, cnt0);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+// ---- device-pointer (sharded) store calls
+int dfh_shard_pull(dfh_table* t, const uint64_t* d_keys, size_t n, float* d_rows) {
+  DFH_ARG(t && (n == 0 || (d_keys && d_rows)), "dfh_shard_pull: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PULL);
+  hipLaunchKernelGGL(k_pull_rows, dim3(grid_for_waves(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
+                     (uint32_t)n, d_rows, dfh_row_stride(t->v.k));
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_cnt) {
+  DFH_ARG(t && (n == 0 || (d_keys && d_cnt)), "dfh_shard_push_count: NULL argument");
+  if (n == 0) return DFH_OK;
+  bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && t->v.k > 0;
+  if (refrand) {
+    int rc = ensure_table_aux(t, n);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
+                     (const uint32_t*)nullptr, (uint32_t)n, refrand ? t->d_urow : (uint32_t*)nullptr, d_cnt,
+                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr);
+  DFH_HIP(hipGetLastError());
+  if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
+  return DFH_OK;
+}
+
+int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_grads) {
+  DFH_ARG(t && (n == 0 || (d_keys && d_grads)), "dfh_shard_push_grad: NULL argument");
+  if (n == 0) return DFH_OK;
+  bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && t->v.k > 0;
+  if (refrand) {
+    int rc = ensure_table_aux(t, n);
+    if (rc) return rc;
+  }
+  TimeScope* ts = new TimeScope(t->ctx, DFH_K_PUSH);
+  hipLaunchKernelGGL(k_push_grad, dim3(grid_for_waves(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
+                     (uint32_t)n, d_grads, dfh_row_stride(t->v.k), refrand ? t->d_need : (uint32_t*)nullptr,
+                     refrand ? t->d_urow : (uint32_t*)nullptr);
+  delete ts;
+  DFH_HIP(hipGetLastError());
+  if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
+  return DFH_OK;
+}
+
+// ---- literal Store API (host pointers)
+int dfh_pull(dfh_table* t, const uint64_t* keys, size_t n, float* vals, size_t* nvals, int* lens, size_t* nlens) {
+  DFH_ARG(t && nvals && nlens && (n == 0 || (keys && vals && lens)), "dfh_pull: NULL argument");
+  const int k = t->v.k;
+  *nvals = 0;
+  *nlens = k == 0 ? 0 : n;  // sgd_updater.cc:40
+  if (n == 0) return DFH_OK;
+  for (size_t i = 0; i < n; ++i) DFH_ARG(keys[i] != kEmptyKey, "key ~0 is reserved");
+  dfh_ctx* c = t->ctx;
+  DFH_HIP(hipSetDevice(c->device));
+  const size_t stride = dfh_row_stride(k);
+  int rc = ensure_scratch(c, padded<uint64_t>(n) + padded<float>(n * stride));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint64_t* d_keys = cv.take<uint64_t>(n);
+  float* d_rows = cv.take<float>(n * stride);
+  DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  rc = dfh_shard_pull(t, d_keys, n, d_rows);
+  if (rc) return rc;
+  std::vector<float> rows(n * stride);
+  DFH_HIP(hipMemcpyAsync(rows.data(), d_rows, rows.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  rc = check_table_err(t);
+  if (rc) return rc;
+  size_t p = 0;
+  for (size_t i = 0; i < n; ++i) {  // ragged layout of SGDUpdater::Get (sgd_updater.cc:46-53)
+    const float* r = rows.data() + i * stride;
+    vals[p++] = r[0];
+    if (r[1] != 0.0f) {
+      memcpy(vals + p, r + 4, sizeof(float) * (size_t)k);
+      p += (size_t)k;
+      lens[i] = k + 1;
+    } else if (k != 0) {
+      lens[i] = 1;
+    }
+  }
+  *nvals = p;
+  return DFH_OK;
+}
+
+int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const float* vals, size_t nvals,
+             const int* lens, size_t nlens) {
+  DFH_ARG(t && (n == 0 || keys), "dfh_push: NULL argument");
+  DFH_ARG(val_type == DFH_FEA_COUNT || val_type == DFH_GRADIENT, "dfh_push: unknown val_type (sgd_updater.cc:99)");
+  dfh_ctx* c = t->ctx;
+  DFH_HIP(hipSetDevice(c->device));
+  const int k = t->v.k;
+  for (size_t i = 0; i < n; ++i) DFH_ARG(keys[i] != kEmptyKey, "key ~0 is reserved");
+  if (val_type == DFH_FEA_COUNT) {
+    DFH_ARG(nvals == n, "kFeaCount: CHECK_EQ(fea_ids.size(), values.size()) (sgd_updater.cc:63)");
+    if (n == 0) return DFH_OK;
+    int rc = ensure_scratch(c, padded<uint64_t>(n) + padded<float>(n));
+    if (rc) return rc;
+    Carver cv(c->scratch);
+    uint64_t* d_keys = cv.take<uint64_t>(n);
+    float* d_cnt = cv.take<float>(n);
+    DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    DFH_HIP(hipMemcpyAsync(d_cnt, vals, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = dfh_shard_push_count(t, d_keys, n, d_cnt);
+    if (rc) return rc;
+    return check_table_err(t);
+  }
+  // kGradient (sgd_updater.cc:74-97)
+  const bool w_only = nlens == 0;
+  if (w_only) {
+    DFH_ARG(nvals == n, "kGradient: CHECK_EQ(values.size(), size) (sgd_updater.cc:79)");
+  } else {
+    DFH_ARG(nlens == n && lens, "kGradient: CHECK_EQ(lens.size(), size) (sgd_updater.cc:81)");
+  }
+  if (n == 0) return DFH_OK;
+  const size_t stride = dfh_row_stride(k);
+  std::vector<float> rows(n * stride, 0.0f);
+  size_t p = 0;
+  for (size_t i = 0; i < n; ++i) {
+    float* r = rows.data() + i * stride;
+    DFH_ARG(p < nvals, "kGradient: values shorter than lens imply (sgd_updater.cc:96)");
+    r[0] = vals[p++];
+    if (!w_only && lens[i] > 1) {
+      DFH_ARG(lens[i] == k + 1, "kGradient: CHECK_EQ(lens[i], V_dim+1) (sgd_updater.cc:91)");
+      DFH_ARG(p + (size_t)k <= nvals, "kGradient: values shorter than lens imply (sgd_updater.cc:96)");
+      r[1] = 1.0f;
+      memcpy(r + 4, vals + p, sizeof(float) * (size_t)k);
+      p += (size_t)k;
+    }
+  }
+  DFH_ARG(p == nvals, "kGradient: CHECK_EQ(p, values.size()) (sgd_updater.cc:96)");
+  int rc = ensure_scratch(c, padded<uint64_t>(n) + padded<float>(n * stride));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint64_t* d_keys = cv.take<uint64_t>(n);
+  float* d_rows = cv.take<float>(n * stride);
+  DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  DFH_HIP(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = dfh_shard_push_grad(t, d_keys, n, d_rows);
+  if (rc) return rc;
+  return check_table_err(t);
+}
+
+int dfh_table_export(dfh_table* t, uint64_t cap, uint64_t* keys, float* scal, int* has_V, float* V, uint64_t* n) {
+  DFH_ARG(t && n, "NULL argument");
+  dfh_ctx* c = t->ctx;
+  DFH_HIP(hipSetDevice(c->device));
+  uint64_t cnt = 0;
+  int rc = dfh_table_size(t, &cnt);
+  if (rc) return rc;
+  *n = cnt;
+  if (cap == 0 || cnt == 0) return DFH_OK;
+  DFH_ARG(cap >= cnt && keys && scal && has_V, "dfh_table_export: buffers too small");
+  const int k = t->v.k;
+  size_t vfl = (size_t)cnt * 2 * (size_t)std::max(k, 1);
+  rc = ensure_scratch(c, padded<uint64_t>(cnt) + padded<float>(cnt * 4) + padded<int>(cnt) + padded<float>(vfl) + 512);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint64_t* d_keys = cv.take<uint64_t>(cnt);
+  float* d_scal = cv.take<float>(cnt * 4);
+  int* d_has = cv.take<int>(cnt);
+  float* d_V = cv.take<float>(vfl);
+  unsigned long long* d_counter = cv.take<unsigned long long>(1);
+  DFH_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_export, dim3(grid_for_threads(t->hslots, c)), dim3(256), 0, c->stream, t->v, t->hslots, cnt,
+                     d_keys, d_scal, d_has, d_V, d_counter);
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipMemcpyAsync(keys, d_keys, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  DFH_HIP(hipMemcpyAsync(scal, d_scal, cnt * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  DFH_HIP(hipMemcpyAsync(has_V, d_has, cnt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (k > 0 && V) DFH_HIP(hipMemcpyAsync(V, d_V, (size_t)cnt * 2 * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  return DFH_OK;
+}
+
+int dfh_table_import(dfh_table* t, uint64_t n, const uint64_t* keys, const float* scal, const int* has_V, const float* V) {
+  DFH_ARG(t && (n == 0 || (keys && scal && has_V)), "NULL argument");
+  if (n == 0) return DFH_OK;
+  dfh_ctx* c = t->ctx;
+  DFH_HIP(hipSetDevice(c->device));
+  const int k = t->v.k;
+  DFH_ARG(k == 0 || V, "V is NULL");
+  size_t vfl = (size_t)n * 2 * (size_t)std::max(k, 1);
+  int rc = ensure_scratch(c, padded<uint64_t>(n) + padded<float>(n * 4) + padded<int>(n) + padded<float>(vfl));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint64_t* d_keys = cv.take<uint64_t>(n);
+  float* d_scal = cv.take<float>(n * 4);
+  int* d_has = cv.take<int>(n);
+  float* d_V = cv.take<float>(vfl);
+  DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  DFH_HIP(hipMemcpyAsync(d_scal, scal, n * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  DFH_HIP(hipMemcpyAsync(d_has, has_V, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (k > 0) DFH_HIP(hipMemcpyAsync(d_V, V, (size_t)n * 2 * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_import, dim3(grid_for_threads(n, c)), dim3(256), 0, c->stream, t->v, n, d_keys, d_scal, d_has, d_V);
+  DFH_HIP(hipGetLastError());
+  return check_table_err(t);
+}
+
+// --------------------------------------------------------- literal Loss API
+namespace {
+int to_u32_offsets(const size_t* offset, size_t nrows, std::vector<uint32_t>* out) {
+  out->resize(nrows + 1);
+  const size_t base = offset[0];
+  for (size_t i = 0; i <= nrows; ++i) {
+    size_t o = offset[i] - base;
+    DFH_ARG(o < 0xFFFFFFFFULL, "batch has >= 2^32 nonzeros (localizer.cc:19 CHECK_LT)");
+    (*out)[i] = (uint32_t)o;
+  }
+  return DFH_OK;
+}
+}  // namespace
+
+int dfh_fm_predict(dfh_ctx* c, int V_dim, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,
+                   const float* weights, size_t nweights, const int* w_pos, const int* V_pos, size_t npos, float* pred) {
+  DFH_ARG(c && V_dim >= 0, "dfh_fm_predict: bad argument");
+  if (nrows == 0) return DFH_OK;
+  DFH_ARG(offset && pred && weights, "dfh_fm_predict: NULL argument");
+  DFH_ARG(V_dim == 0 || (w_pos && V_pos), "dfh_fm_predict: V_dim > 0 needs w_pos and V_pos");
+  DFH_HIP(hipSetDevice(c->device));
+  std::vector<uint32_t> off32;
+  int rc = to_u32_offsets(offset, nrows, &off32);
+  if (rc) return rc;
+  const size_t base = offset[0];
+  const size_t nnz = off32[nrows];
+  DFH_ARG(nnz == 0 || index, "dfh_fm_predict: index is NULL");
+  const size_t ncols = w_pos ? npos : nweights;
+  for (size_t j = 0; j < nnz; ++j) DFH_ARG(index[base + j] < ncols, "dfh_fm_predict: index out of range");
+  if (w_pos) {  // SpMV/SpMM::CheckPos (spmv.h:194-202, spmm.h:172-180)
+    for (size_t u = 0; u < npos; ++u) {
+      DFH_ARG(w_pos[u] == -1 || (w_pos[u] >= 0 && (size_t)w_pos[u] < nweights), "w_pos out of range");
+      if (V_dim > 0) DFH_ARG(V_pos[u] == -1 || (V_pos[u] >= 0 && (size_t)V_pos[u] + V_dim <= nweights), "V_pos out of range");
+    }
+  }
+  rc = ensure_scratch(c, padded<uint32_t>(nrows + 1) + padded<uint32_t>(nnz) + padded<float>(nnz) + padded<float>(nweights) +
+                             2 * padded<int>(npos) + padded<float>(nrows));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint32_t* d_off = cv.take<uint32_t>(nrows + 1);
+  uint32_t* d_idx = cv.take<uint32_t>(std::max<size_t>(nnz, 1));
+  float* d_val = cv.take<float>(std::max<size_t>(nnz, 1));
+  float* d_w = cv.take<float>(std::max<size_t>(nweights, 1));
+  int* d_wp = cv.take<int>(std::max<size_t>(npos, 1));
+  int* d_vp = cv.take<int>(std::max<size_t>(npos, 1));
+  float* d_pred = cv.take<float>(nrows);
+  hipStream_t s = c->stream;
+  DFH_HIP(hipMemcpyAsync(d_off, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  if (nnz) DFH_HIP(hipMemcpyAsync(d_idx, index + base, nnz * 4, hipMemcpyHostToDevice, s));
+  if (nnz && value) DFH_HIP(hipMemcpyAsync(d_val, value + base, nnz * 4, hipMemcpyHostToDevice, s));
+  if (nweights) DFH_HIP(hipMemcpyAsync(d_w, weights, nweights * 4, hipMemcpyHostToDevice, s));
+  if (w_pos) {
+    DFH_HIP(hipMemcpyAsync(d_wp, w_pos, npos * 4, hipMemcpyHostToDevice, s));
+    if (V_pos) DFH_HIP(hipMemcpyAsync(d_vp, V_pos, npos * 4, hipMemcpyHostToDevice, s));
+  }
+  DFH_HIP(hipMemcpyAsync(d_pred, pred, nrows * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_predict_generic, dim3(grid_for_waves(nrows, c)), dim3(256), 0, s, (uint32_t)nrows, d_off, d_idx,
+                     value ? d_val : (const float*)nullptr, d_w, w_pos ? d_wp : (const int*)nullptr,
+                     (w_pos && V_pos) ? d_vp : (const int*)nullptr, V_dim, d_pred, (float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipMemcpyAsync(pred, d_pred, nrows * 4, hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  return DFH_OK;
+}
+
+int dfh_fm_calcgrad(dfh_ctx* c, int V_dim, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,
+                    const float* label, const float* weights, size_t nweights, const int* w_pos, const int* V_pos,
+                    size_t npos, const float* pred, float* grad) {
+  DFH_ARG(c && V_dim >= 0, "dfh_fm_calcgrad: bad argument");
+  if (nrows == 0) return DFH_OK;
+  DFH_ARG(offset && pred && weights && grad && label, "dfh_fm_calcgrad: NULL argument");
+  DFH_ARG(V_dim == 0 || (w_pos && V_pos), "dfh_fm_calcgrad: V_dim > 0 needs w_pos and V_pos");
+  DFH_HIP(hipSetDevice(c->device));
+  std::vector<uint32_t> off32;
+  int rc = to_u32_offsets(offset, nrows, &off32);
+  if (rc) return rc;
+  const size_t base = offset[0];
+  const size_t nnz = off32[nrows];
+  const size_t ncols = w_pos ? npos : nweights;
+  // column-major view (stable counting sort by column => ascending rows per column,
+  // the order SpMV/SpMM::TransTimes accumulate in: spmv.h:152-168, spmm.h:137-156)
+  std::vector<uint32_t> col_ptr(ncols + 1, 0), s_row(std::max<size_t>(nnz, 1));
+  std::vector<float> s_val(value ? std::max<size_t>(nnz, 1) : 0);
+  for (size_t j = 0; j < nnz; ++j) {
+    DFH_ARG(index[base + j] < ncols, "dfh_fm_calcgrad: index out of range");
+    ++col_ptr[index[base + j] + 1];
+  }
+  for (size_t u = 0; u < ncols; ++u) col_ptr[u + 1] += col_ptr[u];
+  {
+    std::vector<uint32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+    for (size_t i = 0; i < nrows; ++i) {
+      for (uint32_t j = off32[i]; j < off32[i + 1]; ++j) {
+        uint32_t q = fill[index[base + j]]++;
+        s_row[q] = (uint32_t)i;
+        if (value) s_val[q] = value[base + j];
+      }
+    }
+  }
+  if (w_pos) {
+    for (size_t u = 0; u < npos; ++u) {
+      DFH_ARG(w_pos[u] == -1 || (w_pos[u] >= 0 && (size_t)w_pos[u] < nweights), "w_pos out of range");
+      if (V_dim > 0) DFH_ARG(V_pos[u] == -1 || (V_pos[u] >= 0 && (size_t)V_pos[u] + V_dim <= nweights), "V_pos out of range");
+    }
+  }
+  const size_t xvn = nrows * (size_t)std::max(V_dim, 1);
+  rc = ensure_scratch(c, padded<uint32_t>(nrows + 1) + 2 * padded<uint32_t>(nnz) + 2 * padded<float>(nnz) +
+                             2 * padded<float>(nweights) + 2 * padded<int>(npos) + 3 * padded<float>(nrows) +
+                             padded<float>(xvn) + padded<uint32_t>(ncols + 1));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint32_t* d_off = cv.take<uint32_t>(nrows + 1);
+  uint32_t* d_idx = cv.take<uint32_t>(std::max<size_t>(nnz, 1));
+  float* d_val = cv.take<float>(std::max<size_t>(nnz, 1));
+  uint32_t* d_srow = cv.take<uint32_t>(std::max<size_t>(nnz, 1));
+  float* d_sval = cv.take<float>(std::max<size_t>(nnz, 1));
+  uint32_t* d_colptr = cv.take<uint32_t>(ncols + 1);
+  float* d_w = cv.take<float>(std::max<size_t>(nweights, 1));
+  float* d_grad = cv.take<float>(std::max<size_t>(nweights, 1));
+  int* d_wp = cv.take<int>(std::max<size_t>(npos, 1));
+  int* d_vp = cv.take<int>(std::max<size_t>(npos, 1));
+  float* d_pred = cv.take<float>(nrows);
+  float* d_label = cv.take<float>(nrows);
+  float* d_slope = cv.take<float>(nrows);
+  float* d_xv = cv.take<float>(xvn);
+  hipStream_t s = c->stream;
+  DFH_HIP(hipMemcpyAsync(d_off, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  if (nnz) {
+    DFH_HIP(hipMemcpyAsync(d_idx, index + base, nnz * 4, hipMemcpyHostToDevice, s));
+    DFH_HIP(hipMemcpyAsync(d_srow, s_row.data(), nnz * 4, hipMemcpyHostToDevice, s));
+    if (value) {
+      DFH_HIP(hipMemcpyAsync(d_val, value + base, nnz * 4, hipMemcpyHostToDevice, s));
+      DFH_HIP(hipMemcpyAsync(d_sval, s_val.data(), nnz * 4, hipMemcpyHostToDevice, s));
+    }
+  }
+  DFH_HIP(hipMemcpyAsync(d_colptr, col_ptr.data(), (ncols + 1) * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_w, weights, nweights * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_grad, grad, nweights * 4, hipMemcpyHostToDevice, s));
+  if (w_pos) {
+    DFH_HIP(hipMemcpyAsync(d_wp, w_pos, npos * 4, hipMemcpyHostToDevice, s));
+    if (V_pos) DFH_HIP(hipMemcpyAsync(d_vp, V_pos, npos * 4, hipMemcpyHostToDevice, s));
+  }
+  DFH_HIP(hipMemcpyAsync(d_pred, pred, nrows * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_label, label, nrows * 4, hipMemcpyHostToDevice, s));
+  const float* dv = value ? d_val : nullptr;
+  const int* dwp = w_pos ? d_wp : nullptr;
+  const int* dvp = (w_pos && V_pos) ? d_vp : nullptr;
+  // pass A: XV = X*V (what Predict left in XV_, fm_loss.h:81-83) and the slope p (fm_loss.h:157-161)
+  hipLaunchKernelGGL(k_predict_generic, dim3(grid_for_waves(nrows, c)), dim3(256), 0, s, (uint32_t)nrows, d_off, d_idx, dv,
+                     d_w, dwp, dvp, V_dim, (float*)nullptr, V_dim > 0 ? d_xv : (float*)nullptr, d_label, d_pred, d_slope);
+  // pass B: per-column accumulation
+  hipLaunchKernelGGL(k_calcgrad_generic, dim3(grid_for_waves(ncols, c)), dim3(256), 0, s, (uint32_t)ncols, d_colptr,
+                     d_srow, value ? d_sval : (const float*)nullptr, d_w, dwp, dvp, V_dim, d_slope, d_xv, d_grad);
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipMemcpyAsync(grad, d_grad, nweights * 4, hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  return DFH_OK;
+}
+
+int dfh_loss_evaluate(dfh_ctx* c, const float* label, const float* pred, size_t n, float* objv) {
+  DFH_ARG(c && objv, "NULL argument");
+  *objv = 0;
+  if (n == 0) return DFH_OK;
+  DFH_ARG(label && pred, "NULL argument");
+  DFH_HIP(hipSetDevice(c->device));
+  int rc = ensure_scratch(c, 2 * padded<float>(n) + 512);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  float* d_l = cv.take<float>(n);
+  float* d_p = cv.take<float>(n);
+  double* d_o = cv.take<double>(1);
+  hipStream_t s = c->stream;
+  DFH_HIP(hipMemcpyAsync(d_l, label, n * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_p, pred, n * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemsetAsync(d_o, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_logloss, dim3(grid_for_threads(n, c)), dim3(256), 0, s, d_l, d_p, (uint32_t)n, d_o);
+  DFH_HIP(hipGetLastError());
+  double o = 0;
+  DFH_HIP(hipMemcpyAsync(&o, d_o, sizeof(double), hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  *objv = (float)o;
+  return DFH_OK;
+}
+
+// ------------------------------------------------------------------ batches
+int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** out) {
+  DFH_ARG(c && out && max_rows >= 1 && max_nnz >= 1, "dfh_batch_create: bad argument");
+  DFH_ARG(max_nnz < 0xFFFFFFF0ULL && max_rows < 0xFFFFFFF0ULL, "batch too large for 32-bit positions");
+  DFH_HIP(hipSetDevice(c->device));
+  dfh_batch* b = new (std::nothrow) dfh_batch();
+  DFH_ARG(b != nullptr, "out of host memory");
+  b->ctx = c;
+  b->max_rows = max_rows;
+  b->max_nnz = max_nnz;
+  const size_t N = max_nnz, B = max_rows;
+  size_t sort_bytes = 0, scan_bytes = 0;
+  rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                            (uint32_t*)nullptr, N, 0, 64, c->stream);
+  rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N, rocprim::plus<uint32_t>(), c->stream);
+  b->temp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+#define DFH_ALLOC(ptr, count, type)                                                        \
+  do {                                                                                     \
+    hipError_t e__ = hipMalloc(reinterpret_cast<void**>(&(ptr)), (count) * sizeof(type));  \
+    if (e__ != hipSuccess) {                                                               \
+      set_error(std::string("dfh_batch_create: hipMalloc: ") + hipGetErrorString(e__));    \
+      dfh_batch_destroy(b);                                                                \
+      return DFH_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+  DFH_ALLOC(b->d_raw, N, uint64_t);
+  DFH_ALLOC(b->d_offset, B + 1, uint32_t);
+  DFH_ALLOC(b->d_value, N, float);
+  DFH_ALLOC(b->d_label, B, float);
+  DFH_ALLOC(b->d_keys, N, uint64_t);
+  DFH_ALLOC(b->d_skeys, N, uint64_t);
+  DFH_ALLOC(b->d_pos, N, uint32_t);
+  DFH_ALLOC(b->d_spos, N, uint32_t);
+  DFH_ALLOC(b->d_head, N, uint32_t);
+  DFH_ALLOC(b->d_uid, N, uint32_t);
+  DFH_ALLOC(b->d_temp, b->temp_bytes, char);
+  DFH_ALLOC(b->d_feaids, N, uint64_t);
+  DFH_ALLOC(b->d_feacnt, N, float);
+  DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
+  DFH_ALLOC(b->d_index, N, uint32_t);
+  DFH_ALLOC(b->d_s_row, N, uint32_t);
+  DFH_ALLOC(b->d_s_val, N, float);
+  DFH_ALLOC(b->d_U, 64, uint32_t);
+  DFH_ALLOC(b->d_urow, N, uint32_t);
+  DFH_ALLOC(b->d_need, N, uint32_t);
+  DFH_ALLOC(b->d_rank, N, uint32_t);
+  DFH_ALLOC(b->d_pred, B, float);
+  DFH_ALLOC(b->d_slope, B, float);
+  DFH_ALLOC(b->d_prog, 8, double);
+#undef DFH_ALLOC
+  b->d_total = b->d_U + 1;
+  DFH_HIP(hipMemsetAsync(b->d_prog, 0, 8 * sizeof(double), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  *out = b;
+  return DFH_OK;
+}
+
+int dfh_batch_destroy(dfh_batch* b) {
+  if (!b) return DFH_OK;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  void* ptrs[] = {b->d_raw,   b->d_offset, b->d_value,   b->d_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
+                  b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
+                  b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_pred,  b->d_slope, b->d_xv,
+                  b->d_prog};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete b;
+  return DFH_OK;
+}
+
+int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint64_t* index, const float* value,
+                        const float* label) {
+  DFH_ARG(b && offset && label, "dfh_batch_load_host: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows, "dfh_batch_load_host: nrows out of range");
+  std::vector<uint32_t> off32;
+  int rc = to_u32_offsets(offset, nrows, &off32);
+  if (rc) return rc;
+  const size_t base = offset[0], nnz = off32[nrows];
+  DFH_ARG(nnz <= b->max_nnz, "dfh_batch_load_host: nnz exceeds max_nnz");
+  DFH_ARG(nnz == 0 || index, "index is NULL");
+  hipStream_t s = b->ctx->stream;
+  DFH_HIP(hipSetDevice(b->ctx->device));
+  DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, index + base, nnz * 8, hipMemcpyHostToDevice, s));
+  if (nnz && value) DFH_HIP(hipMemcpyAsync(b->d_value, value + base, nnz * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_label, label, nrows * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipStreamSynchronize(s));  // off32 is a temporary
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = value != nullptr;
+  b->has_cnt = false;
+  b->localized = false;
+  return DFH_OK;
+}
+
+int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t* d_offset, const uint64_t* d_index,
+                          const float* d_value, const float* d_label) {
+  DFH_ARG(b && d_offset && d_label && (nnz == 0 || d_index), "dfh_batch_load_device: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows && nnz <= b->max_nnz, "dfh_batch_load_device: shape out of range");
+  hipStream_t s = b->ctx->stream;
+  DFH_HIP(hipMemcpyAsync(b->d_offset, d_offset, (nrows + 1) * 4, hipMemcpyDeviceToDevice, s));
+  if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, d_index, nnz * 8, hipMemcpyDeviceToDevice, s));
+  if (nnz && d_value) DFH_HIP(hipMemcpyAsync(b->d_value, d_value, nnz * 4, hipMemcpyDeviceToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_label, d_label, nrows * 4, hipMemcpyDeviceToDevice, s));
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = d_value != nullptr;
+  b->has_cnt = false;
+  b->localized = false;
+  return DFH_OK;
+}
+
+int dfh_localize(dfh_batch* b, uint64_t max_index) {
+  DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
+  DFH_ARG(max_index != 0, "max_index must be nonzero");
+  dfh_ctx* c = b->ctx;
+  hipStream_t s = c->stream;
+  const uint32_t N = (uint32_t)b->nnz;
+  if (N == 0) {
+    // reference would index an empty vector (localizer.cc:35); define: no keys
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, b->d_U, 0u);
+    DFH_HIP(hipMemsetAsync(b->d_col_ptr, 0, 4, s));
+    b->localized = true;
+    return DFH_OK;
+  }
+  const int g = grid_for_threads(N, c);
+  TimeScope ts(c, DFH_K_LOCALIZE);
+  hipLaunchKernelGGL(k_loc_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
+  size_t tb = b->temp_bytes;
+  DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_keys, b->d_skeys, b->d_pos, b->d_spos, (size_t)N, 0, 64, s));
+  hipLaunchKernelGGL(k_loc_heads, dim3(g), dim3(256), 0, s, b->d_skeys, N, b->d_head);
+  tb = b->temp_bytes;
+  DFH_HIP(rocprim::inclusive_scan(b->d_temp, tb, b->d_head, b->d_uid, (size_t)N, rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(k_loc_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
+                     b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
+                     b->d_s_row, b->d_s_val, b->d_U);
+  DFH_HIP(hipGetLastError());
+  b->localized = true;
+  b->has_cnt = false;
+  return DFH_OK;
+}
+
+int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,
+                                  const float* label, const uint64_t* feaids, const float* feacnt, size_t U) {
+  DFH_ARG(b && offset && label && feaids, "dfh_batch_load_localized_host: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows, "nrows out of range");
+  std::vector<uint32_t> off32;
+  int rc = to_u32_offsets(offset, nrows, &off32);
+  if (rc) return rc;
+  const size_t base = offset[0], nnz = off32[nrows];
+  DFH_ARG(nnz <= b->max_nnz && U <= b->max_nnz, "batch exceeds max_nnz");
+  DFH_ARG(nnz == 0 || index, "index is NULL");
+  for (size_t u = 0; u < U; ++u) {
+    DFH_ARG(feaids[u] != kEmptyKey, "key ~0 is reserved");
+    DFH_ARG(u == 0 || feaids[u] > feaids[u - 1], "feaids must be strictly ascending (Localizer output)");
+  }
+  // key-ordered occurrence view: stable counting sort of the nnz by compact index
+  std::vector<uint32_t> col_ptr(U + 1, 0), s_row(std::max<size_t>(nnz, 1));
+  std::vector<float> s_val(value ? std::max<size_t>(nnz, 1) : 0);
+  for (size_t j = 0; j < nnz; ++j) {
+    DFH_ARG(index[base + j] < U, "compact index out of range");
+    ++col_ptr[index[base + j] + 1];
+  }
+  for (size_t u = 0; u < U; ++u) col_ptr[u + 1] += col_ptr[u];
+  {
+    std::vector<uint32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+    for (size_t i = 0; i < nrows; ++i)
+      for (uint32_t j = off32[i]; j < off32[i + 1]; ++j) {
+        uint32_t q = fill[index[base + j]]++;
+        s_row[q] = (uint32_t)i;
+        if (value) s_val[q] = value[base + j];
+      }
+  }
+  hipStream_t s = b->ctx->stream;
+  DFH_HIP(hipSetDevice(b->ctx->device));
+  uint32_t U32 = (uint32_t)U;
+  DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  if (nnz) {
+    DFH_HIP(hipMemcpyAsync(b->d_index, index + base, nnz * 4, hipMemcpyHostToDevice, s));
+    DFH_HIP(hipMemcpyAsync(b->d_s_row, s_row.data(), nnz * 4, hipMemcpyHostToDevice, s));
+    if (value) {
+      DFH_HIP(hipMemcpyAsync(b->d_value, value + base, nnz * 4, hipMemcpyHostToDevice, s));
+      DFH_HIP(hipMemcpyAsync(b->d_s_val, s_val.data(), nnz * 4, hipMemcpyHostToDevice, s));
+    }
+  }
+  DFH_HIP(hipMemcpyAsync(b->d_label, label, nrows * 4, hipMemcpyHostToDevice, s));
+  if (U) DFH_HIP(hipMemcpyAsync(b->d_feaids, feaids, U * 8, hipMemcpyHostToDevice, s));
+  if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = value != nullptr;
+  b->has_cnt = feacnt != nullptr;
+  b->localized = true;
+  return DFH_OK;
+}
+
+int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
+  DFH_ARG(b, "NULL batch");
+  if (nrows) *nrows = b->nrows;
+  if (nnz) *nnz = b->nnz;
+  if (U) {
+    DFH_ARG(b->localized, "batch is not localized");
+    uint32_t u = 0;
+    DFH_HIP(hipMemcpyAsync(&u, b->d_U, 4, hipMemcpyDeviceToHost, b->ctx->stream));
+    DFH_HIP(hipStreamSynchronize(b->ctx->stream));
+    *U = u;
+  }
+  return DFH_OK;
+}
+
+int dfh_batch_get_localized(dfh_batch* b, size_t* U, uint64_t* feaids, float* feacnt, uint32_t* index) {
+  DFH_ARG(b && b->localized, "batch is not localized");
+  size_t u = 0;
+  int rc = dfh_batch_shape(b, nullptr, nullptr, &u);
+  if (rc) return rc;
+  if (U) *U = u;
+  hipStream_t s = b->ctx->stream;
+  if (feaids && u) DFH_HIP(hipMemcpyAsync(feaids, b->d_feaids, u * 8, hipMemcpyDeviceToHost, s));
+  if (feacnt && u) {
+    if (!b->has_cnt) {
+      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(u, b->ctx)), dim3(256), 0, s, b->d_col_ptr, b->d_U, b->d_feacnt);
+      DFH_HIP(hipGetLastError());
+    }
+    DFH_HIP(hipMemcpyAsync(feacnt, b->d_feacnt, u * 4, hipMemcpyDeviceToHost, s));
+  }
+  if (index && b->nnz) DFH_HIP(hipMemcpyAsync(index, b->d_index, b->nnz * 4, hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  return DFH_OK;
+}
+
+int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float** d_feacnt, size_t* U) {
+  DFH_ARG(b && b->localized, "batch is not localized");
+  if (d_feaids) *d_feaids = b->d_feaids;
+  if (d_feacnt) {
+    if (!b->has_cnt) {
+      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, b->ctx)), dim3(256), 0, b->ctx->stream, b->d_col_ptr,
+                         b->d_U, b->d_feacnt);
+      DFH_HIP(hipGetLastError());
+      b->has_cnt = true;
+    }
+    *d_feacnt = b->d_feacnt;
+  }
+  if (U) return dfh_batch_shape(b, nullptr, nullptr, U);
+  return DFH_OK;
+}
+
+// ------------------------------------------------------------ the fused step
+int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
+  DFH_ARG(t && b, "dfh_sgd_step: NULL argument");
+  DFH_ARG(t->ctx == b->ctx, "table and batch must share a context");
+  if (!b->localized) {
+    set_error("dfh_sgd_step: batch is not localized (call dfh_localize first)");
+    return DFH_ERR_STATE;
+  }
+  dfh_ctx* c = t->ctx;
+  hipStream_t s = c->stream;
+  const int k = t->v.k, kp = t->v.kp;
+  DFH_ARG(kp <= 256, "V_dim > 256 is not supported by the fused step");
+  int rc = ensure_xv(b, kp);
+  if (rc) return rc;
+  b->nrows_seen += (float)b->nrows;
+  if (b->nnz == 0) {
+    // rows without features: pred = 0 for every example; nothing to pull or push
+    RowSrc src = table_src(t, b->d_urow);
+    return launch_forward(b, src, k, kp);
+  }
+  const bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && k > 0;
+  const uint32_t Nb = (uint32_t)b->nnz;  // upper bound of U for grids
+  // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217)
+  {
+    TimeScope ts(c, DFH_K_LOOKUP);
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+                       b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? 1 : 0,
+                       refrand ? b->d_need : (uint32_t*)nullptr);
+  }
+  DFH_HIP(hipGetLastError());
+  if (push_cnt && refrand) {
+    rc = refrand_flush(t, b->d_feaids, b->d_U, Nb, b->d_urow, b->d_need, b->d_rank, b->d_total);
+    if (rc) return rc;
+  }
+  RowSrc src = table_src(t, b->d_urow);
+  rc = launch_forward(b, src, k, kp);
+  if (rc) return rc;
+  if (is_train) {
+    if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
+    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need);
+    if (rc) return rc;
+    if (refrand) {
+      rc = refrand_flush(t, b->d_feaids, b->d_U, Nb, b->d_urow, b->d_need, b->d_rank, b->d_total);
+      if (rc) return rc;
+    }
+  } else {
+    BatchView bv = batch_view(b);
+    hipLaunchKernelGGL((k_penalty<1>), dim3(grid_for_waves(Nb, c)), dim3(256), 0, s, bv, src, t->v, k, kp);
+    DFH_HIP(hipGetLastError());
+  }
+  return DFH_OK;
+}
+
+int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows) {
+  DFH_ARG(b && b->localized && d_rows, "dfh_batch_forward: bad argument");
+  const int kp = (V_dim + 3) / 4 * 4;
+  int rc = ensure_xv(b, kp);
+  if (rc) return rc;
+  b->nrows_seen += (float)b->nrows;
+  return launch_forward(b, packed_src(d_rows, V_dim), V_dim, kp);
+}
+
+int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_grads) {
+  DFH_ARG(b && b->localized && d_rows && d_grads, "dfh_batch_backward: bad argument");
+  const int kp = (V_dim + 3) / 4 * 4;
+  if (b->nnz == 0) return DFH_OK;
+  TableView dummy{};
+  return launch_backward<false>(b, packed_src(d_rows, V_dim), dummy, d_grads, dfh_row_stride(V_dim), V_dim, kp, nullptr);
+}
+
+int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
+  DFH_ARG(b && out, "NULL argument");
+  double p[4] = {0, 0, 0, 0};
+  hipStream_t s = b->ctx->stream;
+  DFH_HIP(hipMemcpyAsync(p, b->d_prog, sizeof(p), hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  out->loss = (float)p[0];
+  out->penalty = (float)p[1];
+  out->auc = (float)p[2];
+  out->nnz_w = 0;
+  out->nrows = b->nrows_seen;
+  if (reset) {
+    DFH_HIP(hipMemsetAsync(b->d_prog, 0, 8 * sizeof(double), s));
+    b->nrows_seen = 0;
+  }
+  return DFH_OK;
+}
+
+int dfh_batch_get_pred(dfh_batch* b, float* pred) {
+  DFH_ARG(b && pred, "NULL argument");
+  hipStream_t s = b->ctx->stream;
+  DFH_HIP(hipMemcpyAsync(pred, b->d_pred, b->nrows * 4, hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  return DFH_OK;
+}
+
+int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n, float* auc_n) {
+  (void)c; (void)label; (void)pred; (void)n; (void)auc_n;
+  set_error("dfh_auc_times_n: not implemented yet");
+  return DFH_ERR_STATE;
+}
+
+}  // extern "C"

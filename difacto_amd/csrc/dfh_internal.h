@@ -1,0 +1,128 @@
+// Internal declarations shared by the HIP translation units of libdifacto_hip.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts are assumed throughout.
+#ifndef DFH_INTERNAL_H_
+#define DFH_INTERNAL_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "difacto_hip.h"
+
+namespace dfh {
+
+constexpr int kWave = 64;
+constexpr uint64_t kEmptyKey = ~0ULL;
+constexpr uint32_t kNoRow = ~0u;
+
+// ---------------------------------------------------------------------------
+// HBM layout of one model shard (DESIGN.md "Data layout")
+//
+//   ht   : HEntry[H]      open-addressing index, H = pow2 >= 2*capacity, 16 B/entry
+//   hdr  : RowHdr[C]      32 B/row: the scalars of SGDEntry (sgd_updater.h:19-29)
+//   va   : float[C][2*kp] per row [V[0..kp) | AdaGrad accumulators[0..kp)],
+//                         kp = V_dim rounded up to 4 floats -> 16 B aligned,
+//                         128 B-line aligned rows when kp*8 % 128 == 0 (k=64: 512 B)
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(16))) HEntry {
+  uint64_t key;
+  uint32_t row;
+  uint32_t pad;
+};
+
+struct __attribute__((aligned(32))) RowHdr {
+  float w;         // FTRL weight
+  uint32_t has_V;  // V allocated (e.V != nullptr)
+  float sqrt_g;    // FTRL sqrt of the squared-gradient sum
+  float z;         // FTRL z (reference sign convention, sgd_updater.cc:111)
+  float fea_cnt;   // feature occurrence count
+  uint32_t pad[3];
+};
+static_assert(sizeof(HEntry) == 16, "HEntry");
+static_assert(sizeof(RowHdr) == 32, "RowHdr");
+
+// device-side view of a table, passed to kernels by value
+struct TableView {
+  HEntry* ht;
+  uint64_t hmask;
+  RowHdr* hdr;
+  float* va;
+  uint32_t* nrows;     // device counter of allocated rows
+  uint32_t* err;       // device error word (bit0: capacity, bit1: duplicate key in a launch)
+  uint32_t* rng_state; // REFRAND: the mutated rand_r seed (sgd_updater.cc:144)
+  uint32_t capacity;
+  int k;   // V_dim
+  int kp;  // padded V_dim (multiple of 4)
+  dfh_updater_param p;
+};
+
+// "row source" seen by the forward / backward kernels: either the table
+// itself (rows addressed through urow[u]) or a packed [U x stride] buffer of
+// pulled rows (multi-GPU exchange layout, dfh_row_stride()).
+struct RowSrc {
+  const float* wbase;   // &row0.w ; has_V flag lives at wbase[1] (as u32 or float!=0)
+  size_t wstride;       // floats between consecutive rows' w
+  const float* vbase;   // &row0.V[0]
+  size_t vstride;       // floats between consecutive rows' V
+  const uint32_t* urow; // optional indirection u -> row (NULL: identity)
+  int flag_is_float;    // packed rows carry has_V as float
+};
+
+// device pointers + sizes of a localized minibatch (all arrays live in dfh_batch)
+struct BatchView {
+  uint32_t nrows;
+  uint32_t nnz;
+  const uint32_t* d_U;      // number of unique keys (device scalar)
+  const uint32_t* offset;   // [nrows+1]
+  const uint32_t* index;    // [nnz] compact key rank per nnz (row order)
+  const float* value;       // [nnz] or NULL
+  const float* label;       // [nrows]
+  const uint64_t* feaids;   // [U] ascending reversed keys
+  const uint32_t* col_ptr;  // [U+1] segment starts in the key-ordered view
+  const uint32_t* s_row;    // [nnz] row of each occurrence, key order (ties: row order)
+  const float* s_val;       // [nnz] value of each occurrence, key order, or NULL
+  uint32_t* urow;           // [U] table row of each unique key (filled by lookup)
+  float* pred;              // [nrows]
+  float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
+  float* xv;                // [nrows x kp]
+  double* prog;             // [4]: loss, penalty, auc, spare
+};
+
+// ------------------------------------------------------------- error plumbing
+void set_error(const std::string& msg);
+#define DFH_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (call);                                                       \
+    if (e__ != hipSuccess) {                                                       \
+      ::dfh::set_error(std::string(#call) + ": " + hipGetErrorString(e__));        \
+      return DFH_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+#define DFH_ARG(cond, msg)                 \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::dfh::set_error(msg);               \
+      return DFH_ERR_ARG;                  \
+    }                                      \
+  } while (0)
+
+// ------------------------------------------------------ host+device id helpers
+__host__ __device__ inline uint64_t reverse_bytes(uint64_t x) {
+  // include/difacto/base.h:39-51 — swaps 32/16/8/4-bit groups: nibble reversal
+  x = x << 32 | x >> 32;
+  x = (x & 0x0000FFFF0000FFFFULL) << 16 | (x & 0xFFFF0000FFFF0000ULL) >> 16;
+  x = (x & 0x00FF00FF00FF00FFULL) << 8 | (x & 0xFF00FF00FF00FF00ULL) >> 8;
+  x = (x & 0x0F0F0F0F0F0F0F0FULL) << 4 | (x & 0xF0F0F0F0F0F0F0F0ULL) >> 4;
+  return x;
+}
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+}  // namespace dfh
+#endif  // DFH_INTERNAL_H_

@@ -1,0 +1,853 @@
+// HIP kernels of the FM/SGD worker path for gfx950 (MI355X, CDNA4).
+//
+// Kernel inventory (DESIGN.md has the roofline of each):
+//   k_lookup          keys -> table rows (insert-on-miss) [+ Push(kFeaCount)]
+//   k_forward<L>      fused gather + FMLoss::Predict + logistic slope + logloss
+//   k_backward<L,F>   wavefront segmented sum over duplicate keys = FMLoss::CalcGrad,
+//                     F=1: fused in-place FTRL/AdaGrad (SGDUpdater::Update)
+//   k_pull_rows / k_push_grad / k_push_count   owner side of the sharded store
+//   k_refrand_*       rand_r-compatible lazy InitV (parity mode)
+//   k_predict_generic / k_xv_slope_generic / k_calcgrad_generic   literal Loss API
+//   k_loc_*           device Localizer::Compact around a radix sort
+//
+// All kernels assume 64-lane wavefronts and are launched with 256-thread
+// blocks (4 waves) unless noted.
+#include "dfh_internal.h"
+
+namespace dfh {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over lanes whose ids differ only in bits >= log2(L) (same "sub" lane of every group)
+template <int L>
+__device__ __forceinline__ float cross_group_sum(float v) {
+#pragma unroll
+  for (int o = L; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the L lanes of one group
+template <int L>
+__device__ __forceinline__ float in_group_sum(float v) {
+#pragma unroll
+  for (int o = L >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// The sharding-independent V init: must match oracle/difacto_oracle.c:orc_hash_init_value
+__device__ __forceinline__ float hash_init_value(uint64_t key, int j, unsigned seed, float scale) {
+  uint64_t a = splitmix64(key ^ (0xD1B54A32D192ED03ULL * ((uint64_t)seed + 1ULL)));
+  uint64_t h = splitmix64(a + (uint64_t)j);
+  uint32_t r = (uint32_t)(h >> 40);
+  float u = (float)r * (1.0f / 16777216.0f);
+  return (u - 0.5f) * scale;
+}
+
+// ---- key index: open addressing, linear probing.  Every launch that calls
+// this is handed UNIQUE keys, so two lanes never race on the same key; racing
+// on the same slot with different keys is resolved by the 64-bit CAS.
+__device__ __forceinline__ uint32_t find_or_insert(const TableView& t, uint64_t key) {
+  uint64_t h = splitmix64(key) & t.hmask;
+  for (;;) {
+    uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return t.ht[h].row;
+    if (k == kEmptyKey) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
+                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == kEmptyKey) {
+        uint32_t r = atomicAdd(t.nrows, 1u);
+        if (r >= t.capacity) {
+          atomicOr(t.err, 1u);
+          r = t.capacity - 1;  // keep memory safe; host reports DFH_ERR_CAPACITY
+        }
+        t.ht[h].row = r;
+        return r;
+      }
+      if (old == key) {  // duplicate key inside one launch: contract violation
+        atomicOr(t.err, 2u);
+        return t.capacity - 1;
+      }
+    }
+    h = (h + 1) & t.hmask;
+  }
+}
+
+// read-only probe (export / tests)
+__device__ __forceinline__ uint32_t find_only(const TableView& t, uint64_t key) {
+  uint64_t h = splitmix64(key) & t.hmask;
+  for (;;) {
+    uint64_t k = t.ht[h].key;
+    if (k == key) return t.ht[h].row;
+    if (k == kEmptyKey) return kNoRow;
+    h = (h + 1) & t.hmask;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The per-key update arithmetic, kept operation-for-operation with
+// src/sgd/sgd_updater.cc (no FMA contraction: the reference is built for
+// generic x86-64 where a*b+c rounds twice).
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+// SGDUpdater::UpdateW — FTRL-proximal, src/sgd/sgd_updater.cc:104-120.
+// returns the new w; hdr fields are updated in registers by the caller.
+__device__ __forceinline__ float ftrl_update_w(float gw, float w, float& sqrt_g, float& z,
+                                               const dfh_updater_param& P) {
+  float sg = sqrt_g;
+  gw += w * P.l2;                       // :108
+  float nsg = sqrtf(sg * sg + gw * gw); // :109
+  sqrt_g = nsg;
+  z -= gw - (nsg - sg) / P.lr * w;      // :111
+  float l1 = P.l1;
+  if (z <= l1 && z >= -l1) return 0.0f; // :115-116
+  float eta = (P.lr_beta + nsg) / P.lr; // :118
+  return (z > 0 ? z - l1 : z + l1) / eta; // :119
+}
+
+// SGDUpdater::UpdateV — AdaGrad, one coordinate, src/sgd/sgd_updater.cc:129-138
+__device__ __forceinline__ void adagrad_update_v(float gv, float& v, float& acc, const dfh_updater_param& P) {
+  float g = gv + P.V_l2 * v;           // :132
+  float cg = acc;                      // :133
+  float ncg = sqrtf(cg * cg + g * g);  // :134
+  acc = ncg;
+  float eta = P.V_lr / (ncg + P.V_lr_beta);  // :135
+  v -= eta * g;                        // :136
+}
+
+// the reference's REFRAND value: (rand_r(&seed) / (real_t)RAND_MAX - 0.5) * scale  (:144)
+__device__ __forceinline__ uint32_t lcg_step(uint32_t x) { return x * 1103515245u + 12345u; }
+__device__ __forceinline__ float refrand_value(uint32_t& state, float scale) {
+  // glibc rand_r: 3 LCG steps, 11+10+10 bits
+  uint32_t next = lcg_step(state);
+  int result = (int)((next / 65536u) % 2048u);
+  next = lcg_step(next);
+  result = (result << 10) ^ (int)((next / 65536u) % 1024u);
+  next = lcg_step(next);
+  result = (result << 10) ^ (int)((next / 65536u) % 1024u);
+  state = next;
+  float q = (float)result / 2147483648.0f;  // (real_t)RAND_MAX == 2^31 in float
+  return (float)(((double)q - 0.5) * (double)scale);
+}
+
+#pragma clang fp contract(fast)
+
+// LCG jump-ahead: state after n steps, by squaring the affine map x -> a x + c
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t x, uint64_t n) {
+  uint32_t a = 1103515245u, c = 12345u;  // current power of the map
+  uint32_t ra = 1u, rc = 0u;             // accumulated map (identity)
+  while (n) {
+    if (n & 1) {
+      ra = ra * a;
+      rc = rc * a + c;
+    }
+    c = c * a + c;
+    a = a * a;
+    n >>= 1;
+  }
+  return ra * x + rc;
+}
+
+// write V (hash init) + zero accumulators for row r; one thread does the row
+__device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, uint64_t key) {
+  float* va = t.va + (size_t)r * (2 * t.kp);
+  for (int j = 0; j < t.kp; ++j) {
+    va[j] = j < t.k ? hash_init_value(key, j, t.p.seed, t.p.V_init_scale) : 0.0f;
+    va[t.kp + j] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lookup: one thread per unique key.  urow[u] = row of feaids[u] (inserted as
+// a zero row if unseen: sgd_updater.cc:44).  With cnt != NULL it also applies
+// Push(kFeaCount): fea_cnt += cnt, maybe InitV (sgd_updater.cc:62-73).
+// cnt_from_ptr: counts are the segment lengths of the localized batch.
+// ---------------------------------------------------------------------------
+__global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                         uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
+                         const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init) {
+  uint32_t n = d_n ? *d_n : n_static;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    uint64_t key = keys[u];
+    uint32_t r = find_or_insert(t, key);
+    if (urow) urow[u] = r;
+    if (push_cnt) {
+      float c = cnt ? cnt[u] : (float)(col_ptr[u + 1] - col_ptr[u]);
+      RowHdr& h = t.hdr[r];
+      float fc = h.fea_cnt + c;
+      h.fea_cnt = fc;
+      bool init = t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold;
+      if (t.p.init_mode == DFH_INIT_HASH) {
+        if (init) {
+          init_v_hash_row(t, r, key);
+          h.has_V = 1;
+        }
+      } else if (need_init) {
+        need_init[u] = init ? 1u : 0u;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// REFRAND lazy init (parity mode): rows flagged in need[] are initialised in
+// ascending key order from the mutated rand_r chain, exactly as the serial
+// loop of SGDUpdater::Update would (sgd_updater.cc:62-73, :86-95, :140-147).
+// k_refrand_scan: single block, exclusive scan of need[0..n) -> rank[], total.
+// ---------------------------------------------------------------------------
+__global__ void k_refrand_scan(const uint32_t* __restrict__ need, const uint32_t* __restrict__ d_n, uint32_t n_static,
+                               uint32_t* __restrict__ rank, uint32_t* __restrict__ total) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  uint32_t n = d_n ? *d_n : n_static;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += blockDim.x) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t v = i < n ? need[i] : 0;
+    // inclusive scan inside the wave
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t y = __shfl_up(s, o, 64);
+      if (lane_id() >= o) s += y;
+    }
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = s;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int j = 0; j < w; ++j) woff += wsum[j];
+    uint32_t carry = carry_s;
+    if (i < n) rank[i] = carry + woff + s - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ void k_refrand_init(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                               uint32_t n_static, const uint32_t* __restrict__ urow,
+                               const uint32_t* __restrict__ need, const uint32_t* __restrict__ rank) {
+  uint32_t n = d_n ? *d_n : n_static;
+  uint32_t state0 = *t.rng_state;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    if (!need[u]) continue;
+    uint32_t r = urow ? urow[u] : find_only(t, keys[u]);
+    uint32_t st = lcg_jump(state0, (uint64_t)3 * (uint64_t)t.k * (uint64_t)rank[u]);
+    float* va = t.va + (size_t)r * (2 * t.kp);
+    for (int j = 0; j < t.kp; ++j) {
+      va[j] = j < t.k ? refrand_value(st, t.p.V_init_scale) : 0.0f;
+      va[t.kp + j] = 0.0f;
+    }
+    t.hdr[r].has_V = 1;
+  }
+}
+
+__global__ void k_refrand_advance(TableView t, const uint32_t* __restrict__ total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *t.rng_state = lcg_jump(*t.rng_state, (uint64_t)3 * (uint64_t)t.k * (uint64_t)(*total));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_forward<L>: FMLoss::Predict (src/loss/fm_loss.h:67-119) fused with the
+// gather (Store::Pull, sgd_updater.cc:32-56), the logistic slope
+// (fm_loss.h:157-161) and Loss::Evaluate (include/difacto/loss.h:57-66).
+//
+// One wavefront per example.  A V row is read by L = kp/4 lanes as one float4
+// each (16 B/lane: k=64 -> 16 lanes x 16 B = two full 128 B lines), so a wave
+// has G = 64/L rows in flight per step.  The wave first stages up to 64 nnz of
+// the example (one coalesced index load, one gather of {row, w, has_V}), then
+// the groups walk the staged nnz with cross-lane broadcasts.
+//
+//   pred_i = sum_j x_ij w_j + 1/2 sum_d [ (sum_j x_ij V_jd)^2 - sum_j x_ij^2 V_jd^2 ]
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k, int kp) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const int grp = lane / L;
+  const int sub = lane % L;
+  const bool sub_ok = sub * 4 < kp;  // L may exceed kp/4 when kp/4 is not a power of two
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  double loss_acc = 0.0;
+
+  for (uint32_t i = wave; i < b.nrows; i += nwaves) {
+    const uint32_t beg = b.offset[i], end = b.offset[i + 1];
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xxvv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wsum = 0.f;
+    for (uint32_t base = beg; base < end; base += 64) {
+      const uint32_t j = base + lane;
+      const bool valid = j < end;
+      uint32_t r = 0;
+      float x = 0.f;
+      uint32_t hv = 0;
+      if (valid) {
+        uint32_t u = b.index[j];
+        x = b.value ? b.value[j] : 1.0f;
+        r = src.urow ? src.urow[u] : u;
+        const float* wp = src.wbase + (size_t)r * src.wstride;
+        // {w, has_V} are adjacent: one 8 B load
+        float2 wf = *reinterpret_cast<const float2*>(wp);
+        hv = __float_as_uint(wf.y);
+        wsum += wf.x * x;
+      }
+      const int cnt = min(64u, end - base);
+      if (k > 0) {
+#pragma unroll 4
+        for (int t0 = 0; t0 < cnt; t0 += G) {
+          const int t = t0 + grp;
+          const uint32_t rr = __shfl(r, t, 64);
+          const float xx = __shfl(x, t, 64);
+          const uint32_t hh = __shfl(hv, t, 64);
+          if (t < cnt && hh != 0 && sub_ok) {
+            const float4 v = ld4(src.vbase + (size_t)rr * src.vstride + sub * 4);
+            xv.x += v.x * xx; xv.y += v.y * xx; xv.z += v.z * xx; xv.w += v.w * xx;
+            const float x2 = xx * xx;
+            xxvv.x += (v.x * v.x) * x2; xxvv.y += (v.y * v.y) * x2;
+            xxvv.z += (v.z * v.z) * x2; xxvv.w += (v.w * v.w) * x2;
+          }
+        }
+      }
+    }
+    wsum = wave_sum(wsum);
+    float pred = wsum;
+    if (k > 0) {
+      // combine the G groups' partial rows: every group now holds the full XV / XXVV slice
+      xv.x = cross_group_sum<L>(xv.x); xv.y = cross_group_sum<L>(xv.y);
+      xv.z = cross_group_sum<L>(xv.z); xv.w = cross_group_sum<L>(xv.w);
+      xxvv.x = cross_group_sum<L>(xxvv.x); xxvv.y = cross_group_sum<L>(xxvv.y);
+      xxvv.z = cross_group_sum<L>(xxvv.z); xxvv.w = cross_group_sum<L>(xxvv.w);
+      // s = sum_d (XV_d^2 - XXVV_d), per-dimension difference first as fm_loss.h:113
+      float s = (xv.x * xv.x - xxvv.x) + (xv.y * xv.y - xxvv.y) + (xv.z * xv.z - xxvv.z) + (xv.w * xv.w - xxvv.w);
+      s = in_group_sum<L>(s);
+      pred += 0.5f * s;
+      pred = pred > 20.f ? 20.f : (pred < -20.f ? -20.f : pred);  // fm_loss.h:118 (only when V_dim > 0, :77)
+      if (grp == 0 && sub_ok && b.xv) st4(b.xv + (size_t)i * kp + sub * 4, xv);
+    }
+    if (lane == 0) {
+      const float y = b.label[i] > 0 ? 1.0f : -1.0f;
+      b.pred[i] = pred;
+      b.slope[i] = -y / (1.0f + expf(y * pred));            // fm_loss.h:160
+      loss_acc += log(1.0 + exp((double)(-y * pred)));       // loss.h:63
+    }
+  }
+  // one atomic per block for the batch's logloss
+  __shared__ double blk[4];
+  if (lane == 0) blk[threadIdx.x >> 6] = loss_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = blk[0] + blk[1] + blk[2] + blk[3];
+    if (s != 0.0) atomicAdd(&b.prog[0], s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_backward<L, FUSED>: FMLoss::CalcGrad (src/loss/fm_loss.h:148-199) as a
+// wavefront segmented sum over the key-ordered occurrence list the Localizer's
+// sort leaves behind (runs of equal key, src/data/localizer.cc:28), one
+// wavefront per unique key:
+//   gw_u   = sum_occ x p_i
+//   gV_u,d = sum_occ x (p_i XV_i,d) - V_u,d sum_occ x^2 p_i
+// FUSED: apply SGDUpdater::Update for the key in place (FTRL on w, AdaGrad on
+// V, lazy InitV) — no gradient ever reaches HBM.
+// !FUSED: write [gw, has_V, 0, 0 | gV] rows of `gstride` floats (exchange layout).
+// ---------------------------------------------------------------------------
+template <int L, bool FUSED>
+__global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
+                                                  size_t gstride, int k, int kp, uint32_t* __restrict__ need_init) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const int grp = lane / L;
+  const int sub = lane % L;
+  const bool sub_ok = sub * 4 < kp;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t U = *b.d_U;
+  double pen_acc = 0.0;
+
+  for (uint32_t u = wave; u < U; u += nwaves) {
+    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+    const uint32_t r = src.urow ? src.urow[u] : u;
+    const float* wp = src.wbase + (size_t)r * src.wstride;
+    const float2 wf = *reinterpret_cast<const float2*>(wp);
+    const float w_old = wf.x;
+    const bool has_v = k > 0 && __float_as_uint(wf.y) != 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_v && sub_ok) v = ld4(src.vbase + (size_t)r * src.vstride + sub * 4);
+
+    float gw = 0.f, xxp = 0.f;
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t base = beg; base < end; base += 64) {
+      const uint32_t j = base + lane;
+      const bool valid = j < end;
+      uint32_t row = 0;
+      float x = 0.f, p = 0.f;
+      if (valid) {
+        row = b.s_row[j];
+        x = b.s_val ? b.s_val[j] : 1.0f;
+        p = b.slope[row];
+        gw += p * x;          // spmv.h:160-163: y_j += x_i * value
+        xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
+      }
+      if (has_v) {
+        const int cnt = min(64u, end - base);
+#pragma unroll 4
+        for (int t0 = 0; t0 < cnt; t0 += G) {
+          const int tt = t0 + grp;
+          const uint32_t rowi = __shfl(row, tt, 64);
+          const float xx = __shfl(x, tt, 64);
+          const float pp = __shfl(p, tt, 64);
+          if (tt < cnt && sub_ok) {
+            const float4 a = ld4(b.xv + (size_t)rowi * kp + sub * 4);
+            // (XV_i * p_i) * x as fm_loss.h:192-198
+            gv.x += (a.x * pp) * xx; gv.y += (a.y * pp) * xx;
+            gv.z += (a.z * pp) * xx; gv.w += (a.w * pp) * xx;
+          }
+        }
+      }
+    }
+    gw = wave_sum(gw);
+    if (has_v) {
+      xxp = wave_sum(xxp);
+      gv.x = cross_group_sum<L>(gv.x); gv.y = cross_group_sum<L>(gv.y);
+      gv.z = cross_group_sum<L>(gv.z); gv.w = cross_group_sum<L>(gv.w);
+      // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198)
+      gv.x -= v.x * xxp; gv.y -= v.y * xxp; gv.z -= v.z * xxp; gv.w -= v.w * xxp;
+    }
+
+    if (!FUSED) {
+      float* g = grads + (size_t)u * gstride;
+      if (lane == 0) st4(g, make_float4(gw, has_v ? 1.0f : 0.0f, 0.f, 0.f));
+      if (grp == 0 && sub_ok && k > 0) st4(g + 4 + sub * 4, has_v ? gv : make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {
+      // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
+      float pen = 0.f;
+      if (grp == 0 && has_v && sub_ok) pen = 0.5f * t.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+      pen = wave_sum(pen);
+      if (lane == 0) pen_acc += (double)pen + (double)t.p.l1 * fabs((double)w_old) + 0.5 * (double)t.p.l2 * (double)w_old * (double)w_old;
+
+      // SGDUpdater::Update(kGradient) for this key (sgd_updater.cc:86-95)
+      RowHdr* hp = t.hdr + r;
+      if (lane == 0) {
+        float sqrt_g = hp->sqrt_g, z = hp->z;
+        const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
+        hp->w = w_new;
+        hp->sqrt_g = sqrt_g;
+        hp->z = z;
+        // lazy InitV when w leaves zero (sgd_updater.cc:122-126)
+        if (w_old == 0 && w_new != 0 && k > 0 && !has_v && hp->fea_cnt > (float)t.p.V_threshold) {
+          if (t.p.init_mode == DFH_INIT_HASH) {
+            init_v_hash_row(t, r, b.feaids[u]);
+            hp->has_V = 1;
+          } else {
+            need_init[u] = 1;
+          }
+        }
+      }
+      if (has_v && grp == 0 && sub_ok) {
+        float* va = t.va + (size_t)r * (2 * kp);
+        float4 acc = ld4(va + kp + sub * 4);
+        float4 nv = v;
+        // padded coordinates (>= k) stay exactly zero: g = 0 + V_l2*0
+        adagrad_update_v(gv.x, nv.x, acc.x, t.p);
+        adagrad_update_v(gv.y, nv.y, acc.y, t.p);
+        adagrad_update_v(gv.z, nv.z, acc.z, t.p);
+        adagrad_update_v(gv.w, nv.w, acc.w, t.p);
+        const int d0 = sub * 4;
+        if (d0 + 0 >= k) { nv.x = 0.f; acc.x = 0.f; }
+        if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
+        if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
+        if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
+        st4(va + sub * 4, nv);
+        st4(va + kp + sub * 4, acc);
+      }
+    }
+  }
+  if (FUSED) {
+    __shared__ double blk[4];
+    if (lane == 0) blk[threadIdx.x >> 6] = pen_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = blk[0] + blk[1] + blk[2] + blk[3];
+      if (s != 0.0) atomicAdd(&b.prog[1], s);
+    }
+  }
+}
+
+// penalty only (validation batches: no backward pass)
+template <int L>
+__global__ void __launch_bounds__(256) k_penalty(BatchView b, RowSrc src, TableView t, int k, int kp) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t U = *b.d_U;
+  double pen_acc = 0.0;
+  for (uint32_t u = wave; u < U; u += nwaves) {
+    const uint32_t r = src.urow ? src.urow[u] : u;
+    const float2 wf = *reinterpret_cast<const float2*>(src.wbase + (size_t)r * src.wstride);
+    float pen = 0.f;
+    if (k > 0 && __float_as_uint(wf.y) != 0) {
+      for (int d = lane; d < k; d += 64) {
+        float vv = src.vbase[(size_t)r * src.vstride + d];
+        pen += 0.5f * t.p.V_l2 * vv * vv;
+      }
+    }
+    pen = wave_sum(pen);
+    if (lane == 0) pen_acc += (double)pen + (double)t.p.l1 * fabs((double)wf.x) + 0.5 * (double)t.p.l2 * (double)wf.x * (double)wf.x;
+  }
+  if (lane == 0 && pen_acc != 0.0) atomicAdd(&b.prog[1], pen_acc);
+}
+
+// ---------------------------------------------------------------------------
+// Owner side of the sharded store (device pointers, fixed-stride rows).
+// k_pull_rows: Store::Pull -> SGDUpdater::Get for n unique keys: one wave per
+// key copies [w, has_V, 0, 0 | V] into the exchange buffer.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pull_rows(TableView t, const uint64_t* __restrict__ keys, uint32_t n,
+                                                   float* __restrict__ rows, size_t stride) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t u = wave; u < n; u += nwaves) {
+    uint32_t r = 0;
+    if (lane == 0) r = find_or_insert(t, keys[u]);
+    r = __shfl(r, 0, 64);
+    const RowHdr h = t.hdr[r];
+    float* out = rows + (size_t)u * stride;
+    if (lane == 0) st4(out, make_float4(h.w, h.has_V ? 1.0f : 0.0f, 0.f, 0.f));
+    const float* va = t.va + (size_t)r * (2 * t.kp);
+    for (int d = lane * 4; d < t.kp; d += 256) {
+      st4(out + 4 + d, h.has_V ? ld4(va + d) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
+// Push(kGradient) for n unique keys from fixed-stride gradient rows; one wave per key.
+// The V part is applied iff the gradient row says V was present at pull time
+// (lens[i] > 1 in sgd_updater.cc:90).
+__global__ void __launch_bounds__(256) k_push_grad(TableView t, const uint64_t* __restrict__ keys, uint32_t n,
+                                                   const float* __restrict__ grads, size_t stride,
+                                                   uint32_t* __restrict__ need_init, uint32_t* __restrict__ urow_out) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t u = wave; u < n; u += nwaves) {
+    uint32_t r = 0;
+    if (lane == 0) r = find_or_insert(t, keys[u]);
+    r = __shfl(r, 0, 64);
+    if (urow_out && lane == 0) urow_out[u] = r;
+    const float* g = grads + (size_t)u * stride;
+    const float4 g0 = ld4(g);
+    const bool had_v = g0.y != 0.0f;
+    RowHdr* hp = t.hdr + r;
+    if (need_init && lane == 0) need_init[u] = 0;
+    if (lane == 0) {
+      const float w_old = hp->w;
+      float sqrt_g = hp->sqrt_g, z = hp->z;
+      const float w_new = ftrl_update_w(g0.x, w_old, sqrt_g, z, t.p);
+      hp->w = w_new;
+      hp->sqrt_g = sqrt_g;
+      hp->z = z;
+      if (w_old == 0 && w_new != 0 && t.k > 0 && hp->has_V == 0 && hp->fea_cnt > (float)t.p.V_threshold) {
+        if (t.p.init_mode == DFH_INIT_HASH) {
+          init_v_hash_row(t, r, keys[u]);
+          hp->has_V = 1;
+        } else if (need_init) {
+          need_init[u] = 1;
+        }
+      }
+    }
+    if (had_v && hp->has_V == 0) {  // CHECK(e.V != nullptr), sgd_updater.cc:92
+      if (lane == 0) atomicOr(t.err, 4u);
+    } else if (had_v) {
+      float* va = t.va + (size_t)r * (2 * t.kp);
+      for (int d = lane; d < t.k; d += 64) {
+        float vv = va[d], acc = va[t.kp + d];
+        adagrad_update_v(g[4 + d], vv, acc, t.p);
+        va[d] = vv;
+        va[t.kp + d] = acc;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Literal Loss API kernels: arbitrary V_dim, arbitrary w_pos/V_pos into a
+// ragged weights array (host SArray semantics).  Sums run serially in the
+// reference's order per output element, so these agree with the CPU path to
+// rounding of FMA contraction only.
+// ---------------------------------------------------------------------------
+// one wave per example; lanes stride over the embedding dimension
+__global__ void __launch_bounds__(256) k_predict_generic(uint32_t nrows, const uint32_t* __restrict__ offset,
+                                                         const uint32_t* __restrict__ index, const float* __restrict__ value,
+                                                         const float* __restrict__ weights, const int* __restrict__ w_pos,
+                                                         const int* __restrict__ V_pos, int k, float* __restrict__ pred,
+                                                         float* __restrict__ xv_out, const float* __restrict__ label,
+                                                         const float* __restrict__ pred_in, float* __restrict__ slope_out) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t i = wave; i < nrows; i += nwaves) {
+    const uint32_t beg = offset[i], end = offset[i + 1];
+    float wsum = 0.f;
+    if (pred && lane == 0) {
+      for (uint32_t j = beg; j < end; ++j) {  // SpMV::Times, spmv.h:119-132
+        const uint32_t u = index[j];
+        const int pj = w_pos ? w_pos[u] : (int)u;
+        if (pj < 0) continue;
+        const float xj = weights[pj];
+        wsum += value ? xj * value[j] : xj;
+      }
+    }
+    float s = 0.f;
+    if (k > 0) {
+      for (int d = lane; d < k; d += 64) {
+        float a = 0.f, bb = 0.f;
+        for (uint32_t j = beg; j < end; ++j) {  // SpMM::Times x2, spmm.h:105-118
+          const int pj = V_pos[index[j]];
+          if (pj < 0) continue;
+          const float vv = weights[pj + d];
+          if (value) {
+            const float x = value[j];
+            a += vv * x;
+            bb += (vv * vv) * (x * x);
+          } else {
+            a += vv;
+            bb += vv * vv;
+          }
+        }
+        if (xv_out) xv_out[(size_t)i * k + d] = a;
+        s += a * a - bb;
+      }
+      s = wave_sum(s);
+    }
+    if (lane == 0) {
+      if (pred) {
+        float pr = pred[i] + wsum;  // pred is accumulated into
+        if (k > 0) {
+          pr += 0.5f * s;
+          pr = pr > 20.f ? 20.f : (pr < -20.f ? -20.f : pr);
+        }
+        pred[i] = pr;
+      }
+      if (slope_out) {
+        const float y = label[i] > 0 ? 1.0f : -1.0f;
+        slope_out[i] = -y / (1.0f + expf(y * pred_in[i]));
+      }
+    }
+  }
+}
+
+// one wave per column (unique key): grad[w_pos[u]] += X'p ; grad[V_pos[u]+d] += ...
+__global__ void __launch_bounds__(256) k_calcgrad_generic(uint32_t ncols, const uint32_t* __restrict__ col_ptr,
+                                                          const uint32_t* __restrict__ s_row, const float* __restrict__ s_val,
+                                                          const float* __restrict__ weights, const int* __restrict__ w_pos,
+                                                          const int* __restrict__ V_pos, int k, const float* __restrict__ slope,
+                                                          const float* __restrict__ xv, float* __restrict__ grad) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t u = wave; u < ncols; u += nwaves) {
+    const uint32_t beg = col_ptr[u], end = col_ptr[u + 1];
+    const int pw = w_pos ? w_pos[u] : (int)u;
+    const int pv = (k > 0 && V_pos) ? V_pos[u] : -1;
+    if (lane == 0) {
+      float gw = 0.f;
+      for (uint32_t j = beg; j < end; ++j) {  // SpMV::TransTimes, spmv.h:152-168, ascending rows
+        const float p = slope[s_row[j]];
+        gw += s_val ? p * s_val[j] : p;
+      }
+      if (pw >= 0) grad[pw] += gw;
+    }
+    if (pv >= 0) {
+      float xxp = 0.f;
+      // every lane recomputes XXp serially (identical value, reference order)
+      for (uint32_t j = beg; j < end; ++j) {
+        const float p = slope[s_row[j]];
+        const float x = s_val ? s_val[j] : 1.0f;
+        xxp += p * (x * x);
+      }
+      for (int d = lane; d < k; d += 64) {
+        float g = grad[pv + d] - weights[pv + d] * xxp;  // fm_loss.h:181-188
+        for (uint32_t j = beg; j < end; ++j) {           // spmm.h:137-156, ascending rows
+          const uint32_t row = s_row[j];
+          const float a = xv[(size_t)row * k + d] * slope[row];
+          g += s_val ? a * s_val[j] : a;
+        }
+        grad[pv + d] = g;
+      }
+    }
+  }
+}
+
+// Loss::Evaluate over host-provided pred (literal API)
+__global__ void k_logloss(const float* __restrict__ label, const float* __restrict__ pred, uint32_t n, double* out) {
+  double acc = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float y = label[i] > 0 ? 1.0f : -1.0f;
+    acc += log(1.0 + exp((double)(-y * pred[i])));
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
+
+// ---------------------------------------------------------------------------
+// Device Localizer::Compact (src/data/localizer.cc:11-103) around a stable
+// radix sort of (key, position) pairs.
+// ---------------------------------------------------------------------------
+// keys[i] = ReverseBytes(id % max_index), pos[i] = i   (localizer.cc:22-26)
+__global__ void k_loc_keys(const uint64_t* __restrict__ raw, uint32_t nnz, uint64_t max_index,
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    keys[i] = reverse_bytes(raw[i] % max_index);
+    pos[i] = i;
+  }
+}
+
+// head flags of runs of equal keys (localizer.cc:35-48)
+__global__ void k_loc_heads(const uint64_t* __restrict__ skeys, uint32_t nnz, uint32_t* __restrict__ head) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
+  }
+}
+
+// uid = inclusive_scan(head) - 1.  Emits the dictionary, the segment starts,
+// the compact index per nnz (RemapIndex, localizer.cc:63-77) and the
+// key-ordered occurrence view (row, value) the backward pass walks.
+__global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ spos,
+                           const uint32_t* __restrict__ head, const uint32_t* __restrict__ uid_incl, uint32_t nnz,
+                           uint32_t nrows, const uint32_t* __restrict__ offset, const float* __restrict__ value,
+                           uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
+                           uint32_t* __restrict__ s_row, float* __restrict__ s_val, uint32_t* __restrict__ d_U) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    const uint32_t uid = uid_incl[i] - 1;
+    const uint32_t pos = spos[i];
+    if (head[i]) {
+      feaids[uid] = skeys[i];
+      col_ptr[uid] = i;
+    }
+    index[pos] = uid;
+    // row of nnz position pos: last r with offset[r] <= pos
+    uint32_t lo = 0, hi = nrows;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (offset[mid] <= pos) lo = mid; else hi = mid;
+    }
+    s_row[i] = lo;
+    if (value) s_val[i] = value[pos];
+    if (i == nnz - 1) {
+      *d_U = uid + 1;
+      col_ptr[uid + 1] = nnz;
+    }
+  }
+}
+
+__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+
+// warm start (model preload for benchmarks / resume): one wave per unique key:
+// row gets w = w0, fea_cnt = cnt0 and an allocated, hash-initialised V.
+__global__ void __launch_bounds__(256) k_warm_start(TableView t, const uint64_t* __restrict__ keys, uint64_t n, float w0,
+                                                    float cnt0) {
+  const int lane = lane_id();
+  const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t u = wave; u < n; u += nwaves) {
+    const uint64_t key = keys[u];
+    uint32_t r = 0;
+    if (lane == 0) r = find_or_insert(t, key);
+    r = __shfl(r, 0, 64);
+    if (lane == 0) {
+      RowHdr h;
+      h.w = w0;
+      h.has_V = t.k > 0 ? 1u : 0u;
+      h.sqrt_g = 0.f;
+      h.z = 0.f;
+      h.fea_cnt = cnt0;
+      h.pad[0] = h.pad[1] = h.pad[2] = 0;
+      t.hdr[r] = h;
+    }
+    float* va = t.va + (size_t)r * (2 * t.kp);
+    for (int d = lane; d < t.kp; d += 64) {
+      va[d] = d < t.k ? hash_init_value(key, d, t.p.seed, t.p.V_init_scale) : 0.0f;
+      va[t.kp + d] = 0.0f;
+    }
+  }
+}
+
+// feacnt[u] = segment length (float), for reading the localizer's output back
+__global__ void k_loc_counts(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U, float* __restrict__ cnt) {
+  const uint32_t U = *d_U;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
+    cnt[u] = (float)(col_ptr[u + 1] - col_ptr[u]);
+  }
+}
+
+// table export: one thread per hash slot
+__global__ void k_export(TableView t, uint64_t nslots, uint64_t cap, uint64_t* keys, float* scal, int* has_V, float* V,
+                         unsigned long long* counter) {
+  for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = t.ht[s].key;
+    if (key == kEmptyKey) continue;
+    const unsigned long long o = atomicAdd(counter, 1ULL);
+    if (o >= cap) continue;
+    const uint32_t r = t.ht[s].row;
+    const RowHdr h = t.hdr[r];
+    keys[o] = key;
+    scal[o * 4 + 0] = h.fea_cnt;
+    scal[o * 4 + 1] = h.w;
+    scal[o * 4 + 2] = h.sqrt_g;
+    scal[o * 4 + 3] = h.z;
+    has_V[o] = h.has_V ? 1 : 0;
+    if (t.k > 0) {
+      const float* va = t.va + (size_t)r * (2 * t.kp);
+      for (int d = 0; d < t.k; ++d) {
+        V[o * 2 * t.k + d] = h.has_V ? va[d] : 0.f;
+        V[o * 2 * t.k + t.k + d] = h.has_V ? va[t.kp + d] : 0.f;
+      }
+    }
+  }
+}
+
+__global__ void k_import(TableView t, uint64_t n, const uint64_t* keys, const float* scal, const int* has_V, const float* V) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = find_or_insert(t, keys[i]);
+    RowHdr h;
+    h.fea_cnt = scal[i * 4 + 0];
+    h.w = scal[i * 4 + 1];
+    h.sqrt_g = scal[i * 4 + 2];
+    h.z = scal[i * 4 + 3];
+    h.has_V = has_V[i] ? 1u : 0u;
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    t.hdr[r] = h;
+    if (t.k > 0) {
+      float* va = t.va + (size_t)r * (2 * t.kp);
+      for (int d = 0; d < t.kp; ++d) {
+        va[d] = (has_V[i] && d < t.k) ? V[i * 2 * t.k + d] : 0.f;
+        va[t.kp + d] = (has_V[i] && d < t.k) ? V[i * 2 * t.k + t.k + d] : 0.f;
+      }
+    }
+  }
+}
+
+}  // namespace dfh

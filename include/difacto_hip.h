@@ -1,0 +1,206 @@
+/*
+ * difacto_hip.h — the C ABI of the MI355X-native FM/SGD worker path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, caller-owned buffers,
+ * int return codes (0 = ok; message via dfh_last_error()).  Each entry point
+ * names the reference interface (dmlc/difacto, file:line) it replaces, so the
+ * C++ adaptors in difacto_amd/host/ (HipFMLoss : Loss, DeviceStore : Store) and
+ * any other FFI (ctypes in difacto_amd/capi.py) bind 1:1.
+ *
+ * Conventions
+ *   - "keys" are the byte-reversed feature ids the reference's Localizer emits
+ *     (ReverseBytes(id % max_index), src/data/localizer.cc:24); ~0ULL is reserved.
+ *   - host-pointer calls ("literal" API) are synchronous: on return the outputs
+ *     are valid and the model state is updated.
+ *   - device-pointer calls are asynchronous on the context's HIP stream; use
+ *     dfh_ctx_sync() or stream-ordered work of your own.
+ *   - there is NO CPU fallback: every compute entry point runs HIP kernels on
+ *     the context's device and fails with DFH_ERR_HIP if that is impossible.
+ */
+#ifndef DIFACTO_HIP_H_
+#define DIFACTO_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DFH_OK = 0,
+  DFH_ERR_ARG = 1,      /* bad argument / reference CHECK would fail */
+  DFH_ERR_HIP = 2,      /* HIP runtime error */
+  DFH_ERR_CAPACITY = 3, /* model table is full */
+  DFH_ERR_STATE = 4     /* call sequence error (e.g. step before localize) */
+};
+
+/* Store value types — include/difacto/store.h:31-33 */
+enum { DFH_FEA_COUNT = 1, DFH_WEIGHT = 2, DFH_GRADIENT = 3 };
+
+/* how a lazily allocated embedding row is initialised */
+enum {
+  DFH_INIT_REFRAND = 0, /* bit-compatible with SGDUpdater::InitV's glibc rand_r chain
+                           (src/sgd/sgd_updater.cc:140-147); serial in key order */
+  DFH_INIT_HASH = 1     /* counter-based hash of (key, j, seed): order/sharding independent */
+};
+
+/* SGDUpdaterParam — src/sgd/sgd_param.h:66-107: same names, meanings, defaults */
+typedef struct {
+  float l1, l2, V_l2;
+  float lr, lr_beta, V_lr, V_lr_beta;
+  float V_init_scale;
+  int V_dim;
+  int V_threshold;
+  unsigned seed;
+  int init_mode; /* DFH_INIT_* */
+} dfh_updater_param;
+
+/* sgd::Progress — src/sgd/sgd_utils.h:40-75 */
+typedef struct {
+  float loss, penalty, auc, nnz_w, nrows;
+} dfh_progress;
+
+typedef struct dfh_ctx dfh_ctx;     /* a device + a HIP stream */
+typedef struct dfh_table dfh_table; /* one shard of the model: replaces Store+Updater state */
+typedef struct dfh_batch dfh_batch; /* a device-resident minibatch + its workspace */
+
+const char* dfh_last_error(void);
+void dfh_updater_param_default(dfh_updater_param* p, int V_dim);
+
+/* ---------------------------------------------------------------- context */
+/* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create one */
+int dfh_ctx_create(int device, void* stream, dfh_ctx** out);
+int dfh_ctx_destroy(dfh_ctx* ctx);
+int dfh_ctx_sync(dfh_ctx* ctx);
+void* dfh_ctx_stream(dfh_ctx* ctx);
+int dfh_ctx_device(dfh_ctx* ctx);
+
+/* optional per-kernel timing with HIP events recorded on the context's stream
+ * (what bench.py's roofline block reads); ids index total_ms[]/calls[] */
+enum {
+  DFH_K_LOCALIZE = 0, DFH_K_LOOKUP, DFH_K_FORWARD, DFH_K_BACKWARD, DFH_K_PULL, DFH_K_PUSH, DFH_K_MISC, DFH_K_COUNT
+};
+int dfh_ctx_set_timing(dfh_ctx* ctx, int enable);
+int dfh_ctx_get_timing(dfh_ctx* ctx, int reset, double* total_ms, uint64_t* calls); /* synchronises */
+const char* dfh_kernel_name(int id);
+
+/* ------------------------------------------------------- id transforms (a1) */
+/* ReverseBytes / EncodeFeaGrpID — include/difacto/base.h:39-51,60-63 (host helpers) */
+uint64_t dfh_reverse_bytes(uint64_t x);
+uint64_t dfh_encode_fea_grp_id(uint64_t x, int gid, int nbits);
+
+/* ------------------------------------------------------------ model table */
+/* Replaces SGDUpdater's unordered_map<feaid_t,SGDEntry> (src/sgd/sgd_updater.h:78)
+ * with a row store in HBM: capacity_rows fixed-stride rows + an open-addressing
+ * key index.  Unseen keys are inserted as zero rows on first touch, exactly as
+ * SGDUpdater::Get/Update do through model_[id] (sgd_updater.cc:44,66,87). */
+int dfh_table_create(dfh_ctx* ctx, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out);
+int dfh_table_destroy(dfh_table* t);
+int dfh_table_size(dfh_table* t, uint64_t* nkeys); /* synchronises */
+int dfh_table_param(dfh_table* t, dfh_updater_param* out);
+uint64_t dfh_table_bytes(dfh_table* t);
+
+/* Store::Pull(fea_ids, kWeight, vals, lens) -> SGDUpdater::Get
+ * (include/difacto/store.h:69-73, src/store/store_local.h:36-44, src/sgd/sgd_updater.cc:32-56).
+ * Host pointers.  vals capacity n*(1+V_dim), lens capacity n; ragged layout and
+ * lens in {1, 1+V_dim}; *nlens == 0 iff V_dim == 0 — as the reference. */
+int dfh_pull(dfh_table* t, const uint64_t* keys, size_t n, float* vals, size_t* nvals, int* lens, size_t* nlens);
+
+/* Store::Push(fea_ids, kFeaCount|kGradient, vals, lens) -> SGDUpdater::Update
+ * (include/difacto/store.h:53-57, src/store/store_local.h:24-34, src/sgd/sgd_updater.cc:58-148):
+ * FTRL on w, AdaGrad on V, lazy InitV.  Host pointers.  Keys must be unique. */
+int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const float* vals, size_t nvals,
+             const int* lens, size_t nlens);
+
+/* model I/O helpers (Updater::Save/Load are TODO in the reference, src/sgd/sgd_updater.h:44-50):
+ * dump every entry: keys[n], scal[n*4] = {fea_cnt,w,sqrt_g,z}, has_V[n], V[n*2*V_dim] */
+int dfh_table_export(dfh_table* t, uint64_t cap, uint64_t* keys, float* scal, int* has_V, float* V, uint64_t* n);
+int dfh_table_import(dfh_table* t, uint64_t n, const uint64_t* keys, const float* scal, const int* has_V, const float* V);
+
+/* warm start (resume / benchmark preload): insert n unique keys (DEVICE pointer)
+ * with w = w0, fea_cnt = cnt0 and an allocated V (hash init).  Asynchronous. */
+int dfh_table_warm_start(dfh_table* t, const uint64_t* d_keys, size_t n, float w0, float cnt0);
+
+/* ------------------------------------------------ literal Loss API (a6-a8) */
+/* FMLoss::Predict (src/loss/fm_loss.h:67-119).  Host pointers; pred is
+ * accumulated into (caller zeroes it, src/sgd/sgd_learner.cc:142).  w_pos/V_pos
+ * NULL => dense weights, no V (the V_dim==0 / LogitLoss case). */
+int dfh_fm_predict(dfh_ctx* ctx, int V_dim, size_t nrows, const size_t* offset, const uint32_t* index,
+                   const float* value, const float* weights, size_t nweights, const int* w_pos,
+                   const int* V_pos, size_t npos, float* pred);
+
+/* FMLoss::CalcGrad (src/loss/fm_loss.h:148-199).  Host pointers; grad (shape of
+ * weights) is accumulated into.  Stateless: recomputes X*V instead of relying
+ * on the preceding Predict's members. */
+int dfh_fm_calcgrad(dfh_ctx* ctx, int V_dim, size_t nrows, const size_t* offset, const uint32_t* index,
+                    const float* value, const float* label, const float* weights, size_t nweights,
+                    const int* w_pos, const int* V_pos, size_t npos, const float* pred, float* grad);
+
+/* Loss::Evaluate (include/difacto/loss.h:57-66): sum_i log(1+exp(-y_i pred_i)) */
+int dfh_loss_evaluate(dfh_ctx* ctx, const float* label, const float* pred, size_t n, float* objv);
+
+/* BinClassMetric::AUC (src/loss/bin_class_metric.h:35-56): returns AUC * n */
+int dfh_auc_times_n(dfh_ctx* ctx, const float* label, const float* pred, size_t n, float* auc_n);
+
+/* ------------------------------------------------- device-resident batches */
+int dfh_batch_create(dfh_ctx* ctx, size_t max_rows, size_t max_nnz, dfh_batch** out);
+int dfh_batch_destroy(dfh_batch* b);
+
+/* raw minibatch = what Reader::Value() hands the worker (dmlc::RowBlock<feaid_t>,
+ * src/reader/reader.h:49-51): CSR with u64 feature ids.  value may be NULL (binary). */
+int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint64_t* index,
+                        const float* value, const float* label);
+/* same, from DEVICE pointers (u32 offsets); copies into the batch's own buffers */
+int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t* d_offset,
+                          const uint64_t* d_index, const float* d_value, const float* d_label);
+
+/* Localizer::Compact on device (src/data/localizer.h:41-51, localizer.cc:11-103):
+ * keys = ReverseBytes(id % max_index), sorted unique keys + counts + compact
+ * index per nnz — bit-exact with the reference — plus the key-ordered view the
+ * backward pass's segmented sum walks. */
+int dfh_localize(dfh_batch* b, uint64_t max_index);
+/* already-localized batch from the host (what SGDLearner hands its batch thread,
+ * src/sgd/sgd_learner.cc:203-212): feaids sorted unique, compact u32 index */
+int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index,
+                                  const float* value, const float* label, const uint64_t* feaids,
+                                  const float* feacnt, size_t U);
+/* read back the localizer's outputs (any may be NULL); synchronises */
+int dfh_batch_get_localized(dfh_batch* b, size_t* U, uint64_t* feaids, float* feacnt, uint32_t* index);
+int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U); /* synchronises for U */
+
+/* ---------------------------------------------------------- the fused step */
+/* The batch executor of SGDLearner::IterateData (src/sgd/sgd_learner.cc:131-178)
+ * for one localized batch, entirely on device:
+ *   [push_cnt: Push(kFeaCount)] -> Pull -> Predict -> Evaluate(+penalty,+AUC)
+ *   -> [is_train: CalcGrad -> Push(kGradient) -> FTRL/AdaGrad in place].
+ * Asynchronous; metrics accumulate in the batch and are read with dfh_batch_progress. */
+int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt);
+int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset); /* synchronises */
+int dfh_batch_get_pred(dfh_batch* b, float* pred);                  /* synchronises */
+
+/* -------------------------------------------- sharded (multi-GPU) building blocks */
+/* Rows cross the wire in a fixed-stride layout of dfh_row_stride(V_dim) floats:
+ *   [w, has_V (0/1 as float), 0, 0 | V[0..V_dim) zero-padded to a multiple of 4]
+ * gradients use the same layout: [gw, has_V, 0, 0 | gV...].  All DEVICE pointers. */
+size_t dfh_row_stride(int V_dim);
+/* owner side of Pull: look up / insert n unique keys, write rows */
+int dfh_shard_pull(dfh_table* t, const uint64_t* d_keys, size_t n, float* d_rows);
+/* owner side of Push(kFeaCount) and Push(kGradient) for n unique keys */
+int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_cnt);
+int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_grads);
+/* worker side: Predict+Evaluate on pulled rows [U x stride], then (is_train)
+ * CalcGrad into d_grads [U x stride]; pointers to the batch's device feaids/cnt */
+int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows);
+int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_grads);
+int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float** d_feacnt, size_t* U);
+
+/* raw device memory for hosts without a HIP runtime of their own */
+int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);
+int dfh_free(dfh_ctx* ctx, void* dptr);
+int dfh_memcpy_h2d(dfh_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dfh_memcpy_d2h(dfh_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFACTO_HIP_H_ */

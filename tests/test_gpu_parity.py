@@ -1,0 +1,385 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/difacto_hip.h) against
+the CPU oracle on the same seeded inputs and against the reference's golden vectors.
+
+Tolerances (north_star): fp32 rtol 1e-5 on per-example logits and per-key
+gradients (plus an absolute floor scaled to the magnitude of the summed terms,
+because two fp32 evaluations that sum in different orders can only agree to
+eps * sum|terms|); feature-id hashing / indexing bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import random_batch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+U64MAX = 2 ** 64 - 1
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from difacto_amd import capi as m
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def assert_close(a, b, scale=None, rtol=RTOL, what=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, what
+    atol = 1e-6 * (1.0 if scale is None else float(scale))
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert np.all(err <= 0), "%s: max violation %g at %d (got %r want %r)" % (
+        what, err.max(), err.argmax(), a.flat[err.argmax()], b.flat[err.argmax()])
+
+
+def ragged_weights(rng, U, V_dim, oracle, frac_no_v=0.3, scale=0.1):
+    if V_dim == 0:
+        return (rng.normal(size=U) * scale).astype(np.float32), None, None
+    lens = np.where(rng.random(U) < frac_no_v, 1, 1 + V_dim).astype(np.int32)
+    w_pos, V_pos = oracle.get_pos(lens)
+    W = (rng.normal(size=int(lens.sum())) * scale).astype(np.float32)
+    return W, w_pos, V_pos
+
+
+# ------------------------------------------------------------------ golden vectors
+def _hasv_weights(ids, k):
+    U = len(ids)
+    W = np.zeros((U, k + 1), np.float32)
+    W[:, 0] = (ids / 5e4).astype(np.float32)
+    for j in range(1, k + 1):
+        W[:, j] = (ids * j / 5e5).astype(np.float32)
+    w_pos = (np.arange(U) * (k + 1)).astype(np.int32)
+    return W.reshape(-1).copy(), w_pos, w_pos + 1
+
+
+def test_golden_fm_loss_nov(ctx, oracle, rcv1):
+    """tests/cpp/fm_loss_test.cc:12-40 through dfh_fm_predict / dfh_fm_calcgrad"""
+    loc = oracle.localize(rcv1["offset"], rcv1["index"])
+    ids = oracle.reverse_bytes(loc["feaids"]).astype(np.int64)
+    w = (ids / 5e4).astype(np.float32)
+    pred = ctx.fm_predict(0, loc["offset"], loc["index"], rcv1["value"], w)
+    assert abs(ctx.loss_evaluate(rcv1["label"], pred) - 147.4672) < 1e-3
+    grad = ctx.fm_calcgrad(0, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], w, pred)
+    assert abs(float((grad.astype(np.float64) ** 2).sum()) - 90.5817) < 1e-3
+
+
+def test_golden_fm_loss_hasv(ctx, oracle, rcv1):
+    """tests/cpp/fm_loss_test.cc:42-83"""
+    loc = oracle.localize(rcv1["offset"], rcv1["index"])
+    ids = oracle.reverse_bytes(loc["feaids"]).astype(np.int64)
+    W, w_pos, V_pos = _hasv_weights(ids, 5)
+    pred = ctx.fm_predict(5, loc["offset"], loc["index"], rcv1["value"], W, w_pos, V_pos)
+    assert abs(ctx.loss_evaluate(rcv1["label"], pred) - 330.628) < 1e-3
+    grad = ctx.fm_calcgrad(5, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], W, pred, w_pos, V_pos)
+    assert abs(float((grad.astype(np.float64) ** 2).sum()) - 1.2378e3) < 1e-1
+
+
+# ------------------------------------------------------------------ literal Loss API
+@pytest.mark.parametrize("V_dim", [0, 1, 5, 8, 64, 100])
+@pytest.mark.parametrize("binary", [False, True])
+def test_literal_loss_vs_oracle(ctx, oracle, V_dim, binary):
+    rng = np.random.default_rng(1000 + V_dim + binary)
+    b = random_batch(rng, 257, 900, 50, binary=binary)  # ragged incl. empty rows
+    loc = oracle.localize(b["offset"], b["index"])
+    W, w_pos, V_pos = ragged_weights(rng, loc["U"], V_dim, oracle)
+    po = oracle.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], W, w_pos, V_pos)
+    pg = ctx.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], W, w_pos, V_pos)
+    assert_close(pg, po, what="pred")
+    go = oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], W, po, w_pos, V_pos)
+    gg = ctx.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], W, po, w_pos, V_pos)
+    assert_close(gg, go, scale=np.abs(go).max(), what="grad")
+    assert ctx.loss_evaluate(b["label"], po) == pytest.approx(oracle.loss_evaluate(b["label"], po), rel=1e-5)
+
+
+def test_literal_predict_accumulates(ctx, oracle):
+    """pred is `+=`-accumulated (SpMV::Times y += D x; sgd_learner.cc:142 zeroes it)"""
+    rng = np.random.default_rng(5)
+    b = random_batch(rng, 40, 100, 10)
+    loc = oracle.localize(b["offset"], b["index"])
+    W = rng.normal(size=loc["U"]).astype(np.float32)
+    p0 = rng.normal(size=40).astype(np.float32)
+    base = ctx.fm_predict(0, loc["offset"], loc["index"], b["value"], W)
+    acc = ctx.fm_predict(0, loc["offset"], loc["index"], b["value"], W, pred0=p0)
+    assert_close(acc, base + p0, what="accumulate")
+
+
+# ------------------------------------------------------------------ device Localizer
+@pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same"])
+def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case):
+    rng = np.random.default_rng(11)
+    mx = U64MAX
+    if case == "rcv1":
+        b = rcv1
+    elif case == "hash1000":
+        b, mx = rcv1, 1000
+    elif case == "random":
+        b = random_batch(rng, 300, 2 ** 64 - 1, 40)
+    elif case == "binary_big":
+        b = random_batch(rng, 2000, 5000, 39, binary=True, empty_rows=False)
+    elif case == "one_row":
+        b = random_batch(rng, 1, 50, 30, empty_rows=False)
+    else:
+        b = dict(offset=np.array([0, 3, 5], np.uint64), index=np.full(5, 12345, np.uint64),
+                 value=np.arange(5, dtype=np.float32), label=np.array([1, -1], np.float32))
+    nnz = int(b["offset"][-1])
+    bt = capi.Batch(ctx, len(b["label"]), max(nnz, 1))
+    bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+    bt.localize(mx)
+    got = bt.get_localized()
+    want = oracle.localize(b["offset"], b["index"], mx)
+    assert got["U"] == want["U"]
+    assert np.array_equal(got["feaids"], want["feaids"])
+    assert np.array_equal(got["feacnt"], want["feacnt"])
+    assert np.array_equal(got["index"], want["index"])
+    bt.close()
+
+
+def test_golden_localizer(capi, ctx, rcv1):
+    """tests/cpp/localizer_test.cc:12-49 on the device localizer"""
+    for mx, want in ((U64MAX, 65111856), (1000, 478817)):
+        bt = capi.Batch(ctx, 100, 9648)
+        bt.load_host(rcv1["offset"], rcv1["index"], rcv1["value"], rcv1["label"])
+        bt.localize(mx)
+        got = bt.get_localized()
+        assert sum(capi.reverse_bytes(int(k)) for k in got["feaids"]) == want
+        assert float(got["feacnt"].sum()) == 9648
+        bt.close()
+
+
+# ------------------------------------------------------------------ literal Store API
+@pytest.mark.parametrize("V_dim", [0, 4, 5, 64])
+@pytest.mark.parametrize("mode", ["hash", "refrand"])
+def test_store_trajectory_vs_oracle(capi, ctx, oracle, V_dim, mode):
+    """Pull / Push(kFeaCount) / Push(kGradient) over several batches and epochs:
+    FTRL(w), AdaGrad(V), lazy InitV.  Gradients come from the oracle so only the
+    store is under test."""
+    from oracle import bindings as ob
+    rng = np.random.default_rng(70 + V_dim)
+    kw = dict(V_dim=V_dim, l1=0.05, l2=0.01, lr=0.2, V_lr=0.1, V_l2=0.02, V_threshold=2, V_init_scale=0.3, seed=3)
+    om = ob.INIT_HASH if mode == "hash" else ob.INIT_REFRAND
+    dm = capi.INIT_HASH if mode == "hash" else capi.INIT_REFRAND
+    so = oracle.store_create(init_mode=om, **kw)
+    tb = capi.Table(ctx, 4096, init_mode=dm, **kw)
+    batches = [random_batch(rng, 50, 120, 12, binary=(i % 2 == 0)) for i in range(4)]
+    locs = [oracle.localize(b["offset"], b["index"]) for b in batches]
+    saw_v = False
+    for epoch in range(4):
+        for b, loc in zip(batches, locs):
+            if epoch == 0:
+                so.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
+                tb.push(loc["feaids"], capi.FEA_COUNT, loc["feacnt"])
+            vo, lo = so.pull(loc["feaids"])
+            vg, lg = tb.pull(loc["feaids"])
+            assert np.array_equal(lo, lg), (epoch, "lens")
+            assert_close(vg, vo, what="pulled weights epoch %d" % epoch, rtol=2e-5)
+            saw_v = saw_v or bool(np.any(lo > 1))
+            w_pos, V_pos = oracle.get_pos(lo) if V_dim else (None, None)
+            pred = oracle.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], vo, w_pos, V_pos)
+            grad = oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vo, pred, w_pos, V_pos)
+            so.push(loc["feaids"], ob.GRADIENT, grad, lo)
+            tb.push(loc["feaids"], capi.GRADIENT, grad, lg)
+    assert tb.size() == so.size()
+    assert saw_v == (V_dim > 0)
+    tb.close()
+
+
+def test_store_argument_checks(capi, ctx):
+    tb = capi.Table(ctx, 64, V_dim=2)
+    keys = np.array([5, 9], np.uint64)
+    with pytest.raises(capi.DfhError):  # CHECK_EQ(fea_ids.size(), values.size()), sgd_updater.cc:63
+        tb.push(keys, capi.FEA_COUNT, np.ones(3, np.float32))
+    with pytest.raises(capi.DfhError):  # CHECK_EQ(lens[i], V_dim+1), sgd_updater.cc:91
+        tb.push(keys, capi.GRADIENT, np.ones(2 + 5, np.float32), np.array([1, 6], np.int32))
+    with pytest.raises(capi.DfhError):  # CHECK(e.V != nullptr), sgd_updater.cc:92
+        tb.push(keys, capi.GRADIENT, np.ones(1 + 3, np.float32), np.array([1, 3], np.int32))
+    with pytest.raises(capi.DfhError):  # unknown value type, sgd_updater.cc:99
+        tb.push(keys, 7, np.ones(2, np.float32))
+    tb.close()
+    small = capi.Table(ctx, 4, V_dim=0)
+    with pytest.raises(capi.DfhError) as e:  # table full
+        small.pull(np.arange(1, 40, dtype=np.uint64))
+    assert e.value.code == 3
+    small.close()
+
+
+def test_table_export_import_roundtrip(capi, ctx, oracle):
+    rng = np.random.default_rng(3)
+    tb = capi.Table(ctx, 1024, V_dim=6, V_threshold=0, lr=0.5, l1=0.01, V_init_scale=0.2)
+    keys = np.unique(rng.integers(1, 2 ** 63, size=300).astype(np.uint64))
+    tb.push(keys, capi.FEA_COUNT, np.full(len(keys), 3, np.float32))
+    tb.push(keys, capi.GRADIENT, rng.normal(size=len(keys)).astype(np.float32))
+    v1, l1 = tb.pull(keys)
+    dump = tb.export()
+    assert len(dump["keys"]) == len(keys) and set(dump["keys"].tolist()) == set(keys.tolist())
+    tb2 = capi.Table(ctx, 1024, V_dim=6, V_threshold=0, lr=0.5, l1=0.01, V_init_scale=0.2)
+    tb2.import_(dump["keys"], dump["scal"], dump["has_V"], dump["V"])
+    v2, l2 = tb2.pull(keys)
+    assert np.array_equal(l1, l2) and np.array_equal(v1, v2)
+    assert np.any(l1 > 1)
+    tb.close()
+    tb2.close()
+
+
+# ------------------------------------------------------------------ the fused step
+def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True):
+    from oracle import bindings as ob
+    om = ob.INIT_HASH if mode == "hash" else ob.INIT_REFRAND
+    dm = capi.INIT_HASH if mode == "hash" else capi.INIT_REFRAND
+    so = oracle.store_create(init_mode=om, V_dim=V_dim, **kw)
+    tb = capi.Table(ctx, 1 << 16, V_dim=V_dim, init_mode=dm, **kw)
+    max_rows = max(len(b["label"]) for b in batches)
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    bt = capi.Batch(ctx, max_rows, max(max_nnz, 1))
+    locs = [oracle.localize(b["offset"], b["index"]) for b in batches]
+    for epoch in range(epochs):
+        for b, loc in zip(batches, locs):
+            if device_localize:
+                bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+                bt.localize()
+            else:
+                bt.load_localized_host(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"],
+                                       loc["feacnt"] if epoch == 0 else None)
+            bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+            pg = bt.pred()
+            prog_g = bt.progress(reset=True)
+            po, prog_o = so.sgd_step(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"],
+                                     feacnt=loc["feacnt"] if epoch == 0 else None, is_train=True)
+            assert_close(pg, po, rtol=5e-5, what="pred epoch %d" % epoch)
+            assert prog_g.loss == pytest.approx(prog_o.loss, rel=2e-5)
+            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=1e-4, abs=1e-6)
+            assert prog_g.nrows == prog_o.nrows
+    # final model state, key by key
+    allkeys = np.unique(np.concatenate([l["feaids"] for l in locs]))
+    vg, lg = tb.pull(allkeys)
+    vo, lo = so.pull(allkeys)
+    assert np.array_equal(lg, lo)
+    assert_close(vg, vo, rtol=2e-4, what="final weights")
+    n_with_v = int(np.sum(lo > 1)) if V_dim else 0
+    tb.close()
+    bt.close()
+    return n_with_v
+
+
+@pytest.mark.parametrize("V_dim", [0, 4, 5, 8, 64, 128])
+@pytest.mark.parametrize("mode", ["hash", "refrand"])
+def test_fused_step_vs_oracle(capi, ctx, oracle, V_dim, mode):
+    rng = np.random.default_rng(500 + V_dim)
+    batches = [random_batch(rng, 120, 400, 30, binary=(i % 2 == 1)) for i in range(3)]
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=1, V_init_scale=0.2, seed=9)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, 3, kw)
+    assert (n_with_v > 0) == (V_dim > 0)
+
+
+def test_fused_step_host_localized(capi, ctx, oracle):
+    rng = np.random.default_rng(77)
+    batches = [random_batch(rng, 64, 200, 20) for _ in range(2)]
+    kw = dict(l1=0.02, l2=0.0, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=1)
+    _run_fused_vs_oracle(capi, ctx, oracle, 8, "hash", batches, 3, kw, device_localize=False)
+
+
+def test_fused_step_hot_keys(capi, ctx, oracle):
+    """Zipf-like batch: a few keys occur in almost every row (long segments)"""
+    rng = np.random.default_rng(21)
+    nrows, s = 1500, 12
+    off = (np.arange(nrows + 1) * s).astype(np.uint64)
+    idx = np.minimum(rng.zipf(1.3, size=nrows * s), 5000).astype(np.uint64)
+    lab = np.where(rng.random(nrows) < 0.3, 1.0, -1.0).astype(np.float32)
+    b = dict(offset=off, index=idx, value=None, label=lab)
+    kw = dict(l1=0.01, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
+    _run_fused_vs_oracle(capi, ctx, oracle, 16, "hash", [b], 4, kw)
+
+
+SGD_BASIC = [69.314718, 69.314718, 67.151912, 61.414778, 56.244989, 53.218700, 51.248737, 49.846688,
+             48.650164, 47.698351, 46.924038, 46.388223, 45.970721, 45.499307, 45.102245, 44.798413,
+             44.565211, 44.386417, 44.240657, 44.109764]
+
+
+def test_golden_sgd_learner_basic_on_device(capi, ctx, rcv1):
+    """tests/cpp/sgd_learner_test.cc:9-49 — the 20-epoch FTRL trajectory, every
+    step (localize, pull, predict, evaluate, calcgrad, push, update) on the GPU"""
+    tb = capi.Table(ctx, 8192, V_dim=0, l1=1, l2=1, lr=1)
+    bt = capi.Batch(ctx, 100, 9648)
+    for epoch in range(20):
+        bt.load_host(rcv1["offset"], rcv1["index"], rcv1["value"], rcv1["label"])
+        bt.localize()
+        bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+        prog = bt.progress(reset=True)
+        assert abs(prog.loss - SGD_BASIC[epoch]) < 5e-5, (epoch, prog.loss)
+        assert prog.nrows == 100
+    tb.close()
+    bt.close()
+
+
+def test_validation_step_does_not_touch_model(capi, ctx, oracle):
+    rng = np.random.default_rng(8)
+    b = random_batch(rng, 60, 150, 15)
+    tb = capi.Table(ctx, 4096, V_dim=4, V_threshold=0, lr=0.2, l1=0.01)
+    bt = capi.Batch(ctx, 60, int(b["offset"][-1]))
+    bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+    bt.localize()
+    for _ in range(3):
+        bt.sgd_step(tb, is_train=True, push_cnt=True)
+    keys = bt.get_localized()["feaids"]
+    before = tb.pull(keys)
+    bt.sgd_step(tb, is_train=False)
+    after = tb.pull(keys)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    tb.close()
+    bt.close()
+
+
+# ------------------------------------------------------------------ sharded building blocks
+@pytest.mark.parametrize("V_dim", [0, 5, 64])
+def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
+    """owner-side pull -> worker forward/backward on packed rows -> owner-side push
+    gives the same model as the fused single-GPU step (world_size 1 of the N>1 path)"""
+    rng = np.random.default_rng(900 + V_dim)
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
+    batches = [random_batch(rng, 80, 300, 25, binary=(i == 1)) for i in range(2)]
+    L = capi.lib()
+    stride = capi.row_stride(V_dim)
+    ta = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # fused
+    tb = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # building blocks
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    ba = capi.Batch(ctx, 80, max_nnz)
+    bb = capi.Batch(ctx, 80, max_nnz)
+    d_rows, d_grads = C.c_void_p(), C.c_void_p()
+    assert L.dfh_malloc(ctx.h, max_nnz * stride * 4, C.byref(d_rows)) == 0
+    assert L.dfh_malloc(ctx.h, max_nnz * stride * 4, C.byref(d_grads)) == 0
+    for epoch in range(3):
+        for b in batches:
+            ba.load_host(b["offset"], b["index"], b["value"], b["label"])
+            ba.localize()
+            ba.sgd_step(ta, is_train=True, push_cnt=(epoch == 0))
+            bb.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bb.localize()
+            d_keys, d_cnt, U = bb.device_keys()
+            if epoch == 0:
+                tb.shard_push_count(d_keys, U, d_cnt)
+            tb.shard_pull(d_keys, U, d_rows)
+            bb.forward(V_dim, d_rows)
+            bb.backward(V_dim, d_rows, d_grads)
+            tb.shard_push_grad(d_keys, U, d_grads)
+            assert_close(bb.pred(), ba.pred(), what="pred")
+            pa, pb = ba.progress(), bb.progress()
+            assert pb.loss == pytest.approx(pa.loss, rel=1e-6)
+    keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
+    va, la = ta.pull(keys)
+    vb, lb = tb.pull(keys)
+    assert np.array_equal(la, lb)
+    assert_close(vb, va, rtol=2e-5, what="weights")
+    L.dfh_free(ctx.h, d_rows)
+    L.dfh_free(ctx.h, d_grads)
+    for o in (ta, tb, ba, bb):
+        o.close()
