@@ -61,7 +61,7 @@ def random_batch(rng, nrows, nfeat_space, max_nnz_row, binary=False, empty_rows=
     off = np.zeros(nrows + 1, np.uint64)
     off[1:] = np.cumsum(lens)
     nnz = int(off[-1])
-    idx = rng.integers(0, nfeat_space, size=nnz).astype(np.uint64)
+    idx = rng.integers(0, nfeat_space, size=nnz, dtype=np.uint64)
     val = None if binary else rng.normal(size=nnz).astype(np.float32)
     lab = np.where(rng.random(nrows) < 0.4, 1.0, -1.0).astype(np.float32)
     return dict(offset=off, index=idx, value=val, label=lab)
