@@ -282,7 +282,9 @@ int dispatch_L(int kp, F&& f) {
 
 int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp) {
   BatchView bv = batch_view(b);
-  int grid = grid_for_waves(b->nrows, b->ctx);
+  // one wave per example, all resident at once where possible: the kernel is
+  // bound by the latency of its dependent gathers, not by launch size
+  int grid = (int)std::max<size_t>(1, std::min<size_t>((b->nrows + 3) / 4, PROG_SLOTS));
   hipStream_t s = b->ctx->stream;
   TimeScope ts(b->ctx, DFH_K_FORWARD);
   int rc = dispatch_L(kp, [&](auto Lc) {
@@ -298,13 +300,18 @@ template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
                     uint32_t* need) {
   BatchView bv = batch_view(b);
-  // U lives on the device; nnz bounds it
-  int grid = grid_for_waves(b->nnz, b->ctx);
   hipStream_t s = b->ctx->stream;
+  const int L = lanes_for(kp);
+  // U lives on the device; nnz bounds it.  One launch, three roles (see k_backward):
+  // 256 keys per hot block, 4*BWD_MIDW keys per mid block, 4*(64/L) keys per small block.
+  const size_t nb_hot = std::min<size_t>((b->nnz + 255) / 256, 2048);
+  const size_t nb_mid = std::min<size_t>((b->nnz + 4 * BWD_MIDW - 1) / (4 * BWD_MIDW), 8192);
+  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, 32768);
   TimeScope ts(b->ctx, DFH_K_BACKWARD);
   int rc = dispatch_L(kp, [&](auto Lc) {
-    constexpr int L = decltype(Lc)::value;
-    hipLaunchKernelGGL((k_backward<L, FUSED>), dim3(grid), dim3(256), 0, s, bv, src, tv, grads, gstride, k, kp, need);
+    constexpr int LL = decltype(Lc)::value;
+    hipLaunchKernelGGL((k_backward<LL, FUSED>), dim3((unsigned)(nb_hot + nb_mid + nb_small)), dim3(256), 0, s, bv, src, tv,
+                       grads, gstride, k, kp, need, (uint32_t)nb_hot, (uint32_t)nb_mid);
   });
   if (rc) return rc;
   DFH_HIP(hipGetLastError());
@@ -971,10 +978,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
   DFH_ALLOC(b->d_slope, B, float);
-  DFH_ALLOC(b->d_prog, 8, double);
+  DFH_ALLOC(b->d_prog, 2 * PROG_SLOTS, double);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
-  DFH_HIP(hipMemsetAsync(b->d_prog, 0, 8 * sizeof(double), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_prog, 0, 2 * PROG_SLOTS * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
@@ -1221,7 +1228,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     }
   } else {
     BatchView bv = batch_view(b);
-    hipLaunchKernelGGL((k_penalty<1>), dim3(grid_for_waves(Nb, c)), dim3(256), 0, s, bv, src, t->v, k, kp);
+    hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(Nb, c), PROG_SLOTS)), dim3(256), 0, s, bv, src, t->v, k, kp);
     DFH_HIP(hipGetLastError());
   }
   return DFH_OK;
@@ -1246,17 +1253,22 @@ int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_gr
 
 int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
   DFH_ARG(b && out, "NULL argument");
-  double p[4] = {0, 0, 0, 0};
+  std::vector<double> p(2 * PROG_SLOTS);
   hipStream_t s = b->ctx->stream;
-  DFH_HIP(hipMemcpyAsync(p, b->d_prog, sizeof(p), hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipMemcpyAsync(p.data(), b->d_prog, p.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   DFH_HIP(hipStreamSynchronize(s));
-  out->loss = (float)p[0];
-  out->penalty = (float)p[1];
-  out->auc = (float)p[2];
+  double loss = 0, pen = 0;
+  for (int i = 0; i < PROG_SLOTS; ++i) {
+    loss += p[PROG_LOSS * PROG_SLOTS + i];
+    pen += p[PROG_PENALTY * PROG_SLOTS + i];
+  }
+  out->loss = (float)loss;
+  out->penalty = (float)pen;
+  out->auc = 0;
   out->nnz_w = 0;
   out->nrows = b->nrows_seen;
   if (reset) {
-    DFH_HIP(hipMemsetAsync(b->d_prog, 0, 8 * sizeof(double), s));
+    DFH_HIP(hipMemsetAsync(b->d_prog, 0, 2 * PROG_SLOTS * sizeof(double), s));
     b->nrows_seen = 0;
   }
   return DFH_OK;

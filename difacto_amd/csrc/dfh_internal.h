@@ -85,7 +85,7 @@ struct BatchView {
   float* pred;              // [nrows]
   float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
   float* xv;                // [nrows x kp]
-  double* prog;             // [4]: loss, penalty, auc, spare
+  double* prog;             // [2][PROG_SLOTS] per-block partials: logloss, penalty
 };
 
 // ------------------------------------------------------------- error plumbing

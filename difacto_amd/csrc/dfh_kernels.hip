@@ -3,7 +3,7 @@
 // Kernel inventory (DESIGN.md has the roofline of each):
 //   k_lookup          keys -> table rows (insert-on-miss) [+ Push(kFeaCount)]
 //   k_forward<L>      fused gather + FMLoss::Predict + logistic slope + logloss
-//   k_backward<L,F>   wavefront segmented sum over duplicate keys = FMLoss::CalcGrad,
+//   k_backward<L,F>   segmented sum over duplicate keys = FMLoss::CalcGrad,
 //                     F=1: fused in-place FTRL/AdaGrad (SGDUpdater::Update)
 //   k_pull_rows / k_push_grad / k_push_count   owner side of the sharded store
 //   k_refrand_*       rand_r-compatible lazy InitV (parity mode)
@@ -268,12 +268,20 @@ __global__ void k_refrand_advance(TableView t, const uint32_t* __restrict__ tota
 //
 // One wavefront per example.  A V row is read by L = kp/4 lanes as one float4
 // each (16 B/lane: k=64 -> 16 lanes x 16 B = two full 128 B lines), so a wave
-// has G = 64/L rows in flight per step.  The wave first stages up to 64 nnz of
-// the example (one coalesced index load, one gather of {row, w, has_V}), then
-// the groups walk the staged nnz with cross-lane broadcasts.
+// has G = 64/L rows in flight per load instruction.  The wave first stages up
+// to 64 nnz of the example (one coalesced index load, one gather of
+// {row, w, has_V}), then the groups walk the staged nnz with cross-lane
+// broadcasts, issuing FWD_DEPTH independent row loads before consuming any
+// (the kernel is latency-bound on the random gather: depth, not width, is
+// what fills the memory pipe).
 //
 //   pred_i = sum_j x_ij w_j + 1/2 sum_d [ (sum_j x_ij V_jd)^2 - sum_j x_ij^2 V_jd^2 ]
 // ---------------------------------------------------------------------------
+constexpr int FWD_DEPTH = 8;
+// progress partials: prog[kind * PROG_SLOTS + blockIdx.x], summed on the host
+constexpr int PROG_SLOTS = 16384;
+constexpr int PROG_LOSS = 0, PROG_PENALTY = 1;
+
 template <int L>
 __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k, int kp) {
   constexpr int G = 64 / L;
@@ -308,18 +316,27 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
       }
       const int cnt = min(64u, end - base);
       if (k > 0) {
-#pragma unroll 4
-        for (int t0 = 0; t0 < cnt; t0 += G) {
-          const int t = t0 + grp;
-          const uint32_t rr = __shfl(r, t, 64);
-          const float xx = __shfl(x, t, 64);
-          const uint32_t hh = __shfl(hv, t, 64);
-          if (t < cnt && hh != 0 && sub_ok) {
-            const float4 v = ld4(src.vbase + (size_t)rr * src.vstride + sub * 4);
-            xv.x += v.x * xx; xv.y += v.y * xx; xv.z += v.z * xx; xv.w += v.w * xx;
+        for (int t0 = 0; t0 < cnt; t0 += FWD_DEPTH * G) {
+          float4 v[FWD_DEPTH];
+          float xs[FWD_DEPTH];
+#pragma unroll
+          for (int q = 0; q < FWD_DEPTH; ++q) {
+            const int t = t0 + q * G + grp;
+            const uint32_t rr = __shfl(r, t & 63, 64);
+            const float xx = __shfl(x, t & 63, 64);
+            const uint32_t hh = __shfl(hv, t & 63, 64);
+            // the row load does not wait for has_V: a row without V holds zeros
+            const bool ok = t < cnt && sub_ok;
+            xs[q] = (ok && hh != 0) ? xx : 0.f;
+            v[q] = ok ? ld4(src.vbase + (size_t)rr * src.vstride + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < FWD_DEPTH; ++q) {
+            const float xx = xs[q];
+            xv.x += v[q].x * xx; xv.y += v[q].y * xx; xv.z += v[q].z * xx; xv.w += v[q].w * xx;
             const float x2 = xx * xx;
-            xxvv.x += (v.x * v.x) * x2; xxvv.y += (v.y * v.y) * x2;
-            xxvv.z += (v.z * v.z) * x2; xxvv.w += (v.w * v.w) * x2;
+            xxvv.x += (v[q].x * v[q].x) * x2; xxvv.y += (v[q].y * v[q].y) * x2;
+            xxvv.z += (v[q].z * v[q].z) * x2; xxvv.w += (v[q].w * v[q].w) * x2;
           }
         }
       }
@@ -346,147 +363,336 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
       loss_acc += log(1.0 + exp((double)(-y * pred)));       // loss.h:63
     }
   }
-  // one atomic per block for the batch's logloss
+  // the batch's logloss: one private slot per block (same-address atomics
+  // serialise at ~12 ns each on this chip: 2k blocks would cost 25 us)
   __shared__ double blk[4];
   if (lane == 0) blk[threadIdx.x >> 6] = loss_acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = blk[0] + blk[1] + blk[2] + blk[3];
-    if (s != 0.0) atomicAdd(&b.prog[0], s);
-  }
+  if (threadIdx.x == 0) atomicAdd(&b.prog[PROG_LOSS * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], blk[0] + blk[1] + blk[2] + blk[3]);
 }
 
 // ---------------------------------------------------------------------------
 // k_backward<L, FUSED>: FMLoss::CalcGrad (src/loss/fm_loss.h:148-199) as a
-// wavefront segmented sum over the key-ordered occurrence list the Localizer's
-// sort leaves behind (runs of equal key, src/data/localizer.cc:28), one
-// wavefront per unique key:
+// segmented sum over the key-ordered occurrence list the Localizer's sort
+// leaves behind (runs of equal key, src/data/localizer.cc:28):
 //   gw_u   = sum_occ x p_i
 //   gV_u,d = sum_occ x (p_i XV_i,d) - V_u,d sum_occ x^2 p_i
 // FUSED: apply SGDUpdater::Update for the key in place (FTRL on w, AdaGrad on
 // V, lazy InitV) — no gradient ever reaches HBM.
 // !FUSED: write [gw, has_V, 0, 0 | gV] rows of `gstride` floats (exchange layout).
+//
+// Segment lengths are Zipf-distributed (1 .. ~B/8), so ONE launch runs three
+// roles, chosen by blockIdx (long tasks first so they start early):
+//   hot   blocks [0, nb_hot):   256 keys scanned per block; keys with
+//                               cnt > BWD_MID are taken one at a time by the
+//                               whole block (4 waves, partials combined in LDS)
+//   mid   next nb_mid blocks:   each wave scans BWD_MIDW keys and takes those
+//                               with BWD_SMALL < cnt <= BWD_MID, whole wave per key
+//   small the rest:             one L-lane group per key (G keys per wave),
+//                               occurrences summed serially in row order — the
+//                               reference's own order
+// Every key is handled by exactly one role; nothing is communicated between
+// blocks.  The kernel is bound by the latency of dependent random accesses, so
+// each role issues all of a key's independent loads (header, V row, AdaGrad
+// row, occurrence list) before consuming any; V rows are read speculatively
+// (a row without V holds zeros, in the table and in packed rows alike).
 // ---------------------------------------------------------------------------
+constexpr uint32_t BWD_SMALL = 8;
+constexpr uint32_t BWD_MID = 256;
+constexpr int BWD_MIDW = 16;
+constexpr int BWD_DEPTH = 4;
+
+struct KeySums {
+  float gw;    // sum p x
+  float xxp;   // sum p x^2
+  float4 gv;   // sum (XV p) x, this lane's 4 dims
+};
+
+struct KeyRow {   // what a role prefetches for one key
+  uint32_t r;
+  float w_old;
+  bool has_v;
+  float sqrt_g, z, fea_cnt;
+  float4 v, acc;  // this lane's slices
+};
+
+template <bool FUSED>
+__device__ __forceinline__ KeyRow load_key_row(const RowSrc& src, const TableView& t, uint32_t u, int sub, bool sub_ok,
+                                               int k, int kp) {
+  KeyRow kr;
+  kr.r = src.urow ? src.urow[u] : u;
+  const float* wp = src.wbase + (size_t)kr.r * src.wstride;
+  kr.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  kr.acc = kr.v;
+  kr.sqrt_g = kr.z = kr.fea_cnt = 0.f;
+  // independent loads, issued back to back
+  float4 h0 = ld4(wp);  // table: {w, has_V, sqrt_g, z}; packed: {w, has_V, 0, 0}
+  if (k > 0 && sub_ok) {
+    kr.v = ld4(src.vbase + (size_t)kr.r * src.vstride + sub * 4);
+    if (FUSED) kr.acc = ld4(t.va + (size_t)kr.r * (2 * kp) + kp + sub * 4);
+  }
+  if (FUSED) kr.fea_cnt = t.hdr[kr.r].fea_cnt;
+  kr.w_old = h0.x;
+  kr.has_v = k > 0 && __float_as_uint(h0.y) != 0;
+  kr.sqrt_g = h0.z;
+  kr.z = h0.w;
+  if (!kr.has_v) kr.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  return kr;
+}
+
+// Everything after the sums, executed by the L lanes of ONE group (the caller
+// masks the others).
+template <int L, bool FUSED>
+__device__ __forceinline__ void finish_key(const BatchView& b, const TableView& t, uint32_t u, const KeyRow& kr, int sub,
+                                           bool sub_ok, KeySums s, float* __restrict__ grads, size_t gstride, int k,
+                                           int kp, uint32_t* __restrict__ need_init, double& pen_acc) {
+  float4 gv = s.gv;
+  const float4 v = kr.v;
+  if (kr.has_v) {
+    // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198)
+    gv.x -= v.x * s.xxp; gv.y -= v.y * s.xxp; gv.z -= v.z * s.xxp; gv.w -= v.w * s.xxp;
+  }
+  if (!FUSED) {
+    float* g = grads + (size_t)u * gstride;
+    if (sub == 0) st4(g, make_float4(s.gw, kr.has_v ? 1.0f : 0.0f, 0.f, 0.f));
+    if (sub_ok && k > 0) st4(g + 4 + sub * 4, kr.has_v ? gv : make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
+  if (kr.has_v && sub_ok) pen_acc += 0.5 * (double)t.p.V_l2 * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w);
+  RowHdr* hp = t.hdr + kr.r;
+  if (sub == 0) {
+    const float w_old = kr.w_old;
+    pen_acc += (double)t.p.l1 * fabs((double)w_old) + 0.5 * (double)t.p.l2 * (double)w_old * (double)w_old;
+    // SGDUpdater::Update(kGradient) for this key (sgd_updater.cc:86-95)
+    float sqrt_g = kr.sqrt_g, z = kr.z;
+    const float w_new = ftrl_update_w(s.gw, w_old, sqrt_g, z, t.p);
+    // one 16 B store of {w, has_V, sqrt_g, z}
+    uint32_t hv = kr.has_v ? 1u : 0u;
+    // lazy InitV when w leaves zero (sgd_updater.cc:122-126)
+    if (w_old == 0 && w_new != 0 && k > 0 && !kr.has_v && kr.fea_cnt > (float)t.p.V_threshold) {
+      if (t.p.init_mode == DFH_INIT_HASH) {
+        init_v_hash_row(t, kr.r, b.feaids[u]);
+        hv = 1u;
+      } else {
+        need_init[u] = 1;
+      }
+    }
+    st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));
+  }
+  if (kr.has_v && sub_ok) {
+    float* va = t.va + (size_t)kr.r * (2 * kp);
+    float4 acc = kr.acc;
+    float4 nv = v;
+    adagrad_update_v(gv.x, nv.x, acc.x, t.p);
+    adagrad_update_v(gv.y, nv.y, acc.y, t.p);
+    adagrad_update_v(gv.z, nv.z, acc.z, t.p);
+    adagrad_update_v(gv.w, nv.w, acc.w, t.p);
+    // padded coordinates (>= k) stay exactly zero
+    const int d0 = sub * 4;
+    if (d0 + 0 >= k) { nv.x = 0.f; acc.x = 0.f; }
+    if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
+    if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
+    if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
+    st4(va + sub * 4, nv);
+    st4(va + kp + sub * 4, acc);
+  }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of the per-lane penalty partials into one of PROG_SLOTS slots
+// (distinct addresses: no same-address atomic serialisation)
+__device__ __forceinline__ void flush_penalty(const BatchView& b, double pen_acc) {
+  __shared__ double pen_blk[8];
+  pen_acc = wave_sum_d(pen_acc);
+  if (lane_id() == 0) pen_blk[threadIdx.x >> 6] = pen_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += pen_blk[i];
+    if (t != 0.0) atomicAdd(&b.prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
+  }
+}
+
+// partial sums of occurrences [beg,end) taken by this wave: tiles of 64
+// starting at tile w0, stride wstep tiles; result: gw/xxp wave-reduced, gv
+// reduced across groups (every group holds the sums of its lane slice)
+template <int L>
+__device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_t beg, uint32_t end, uint32_t w0,
+                                                     uint32_t wstep, bool want_v, bool sub_ok, int grp, int sub, int kp) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  KeySums s;
+  s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint32_t base = beg + w0 * 64; base < end; base += wstep * 64) {
+    const uint32_t j = base + lane;
+    const bool valid = j < end;
+    uint32_t row = 0;
+    float x = 0.f, p = 0.f;
+    if (valid) {
+      row = b.s_row[j];
+      x = b.s_val ? b.s_val[j] : 1.0f;
+      p = b.slope[row];
+      s.gw += p * x;          // spmv.h:160-163
+      s.xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
+    }
+    if (want_v) {
+      const int cnt = min(64u, end - base);
+      for (int t0 = 0; t0 < cnt; t0 += BWD_DEPTH * G) {
+        float4 a[BWD_DEPTH];
+        float xs[BWD_DEPTH], ps[BWD_DEPTH];
+#pragma unroll
+        for (int q = 0; q < BWD_DEPTH; ++q) {
+          const int tt = t0 + q * G + grp;
+          const uint32_t rowi = __shfl(row, tt & 63, 64);
+          const float xx = __shfl(x, tt & 63, 64);
+          const float pp = __shfl(p, tt & 63, 64);
+          const bool ok = tt < cnt && sub_ok;
+          xs[q] = ok ? xx : 0.f;
+          ps[q] = pp;
+          a[q] = ok ? ld4(b.xv + (size_t)rowi * kp + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < BWD_DEPTH; ++q) {
+          const float pp = ps[q], xx = xs[q];
+          s.gv.x += (a[q].x * pp) * xx; s.gv.y += (a[q].y * pp) * xx;
+          s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
+        }
+      }
+    }
+  }
+  s.gw = wave_sum(s.gw);
+  s.xxp = wave_sum(s.xxp);
+  if (want_v) {
+    s.gv.x = cross_group_sum<L>(s.gv.x); s.gv.y = cross_group_sum<L>(s.gv.y);
+    s.gv.z = cross_group_sum<L>(s.gv.z); s.gv.w = cross_group_sum<L>(s.gv.w);
+  }
+  return s;
+}
+
 template <int L, bool FUSED>
 __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
-                                                  size_t gstride, int k, int kp, uint32_t* __restrict__ need_init) {
+                                                  size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
+                                                  uint32_t nb_hot, uint32_t nb_mid) {
   constexpr int G = 64 / L;
+  constexpr int NW = 4;
+  __shared__ float part[NW][2 + 256];  // hot role, per wave: gw, xxp, gv[kp <= 256]
+  __shared__ uint32_t hot_u[256];
+  __shared__ uint32_t hot_n;
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int w = threadIdx.x >> 6;
   const uint32_t U = *b.d_U;
   double pen_acc = 0.0;
 
-  for (uint32_t u = wave; u < U; u += nwaves) {
-    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
-    const uint32_t r = src.urow ? src.urow[u] : u;
-    const float* wp = src.wbase + (size_t)r * src.wstride;
-    const float2 wf = *reinterpret_cast<const float2*>(wp);
-    const float w_old = wf.x;
-    const bool has_v = k > 0 && __float_as_uint(wf.y) != 0;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_v && sub_ok) v = ld4(src.vbase + (size_t)r * src.vstride + sub * 4);
-
-    float gw = 0.f, xxp = 0.f;
-    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t base = beg; base < end; base += 64) {
-      const uint32_t j = base + lane;
-      const bool valid = j < end;
-      uint32_t row = 0;
-      float x = 0.f, p = 0.f;
-      if (valid) {
-        row = b.s_row[j];
-        x = b.s_val ? b.s_val[j] : 1.0f;
-        p = b.slope[row];
-        gw += p * x;          // spmv.h:160-163: y_j += x_i * value
-        xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
-      }
-      if (has_v) {
-        const int cnt = min(64u, end - base);
-#pragma unroll 4
-        for (int t0 = 0; t0 < cnt; t0 += G) {
-          const int tt = t0 + grp;
-          const uint32_t rowi = __shfl(row, tt, 64);
-          const float xx = __shfl(x, tt, 64);
-          const float pp = __shfl(p, tt, 64);
-          if (tt < cnt && sub_ok) {
-            const float4 a = ld4(b.xv + (size_t)rowi * kp + sub * 4);
-            // (XV_i * p_i) * x as fm_loss.h:192-198
-            gv.x += (a.x * pp) * xx; gv.y += (a.y * pp) * xx;
-            gv.z += (a.z * pp) * xx; gv.w += (a.w * pp) * xx;
+  if (blockIdx.x < nb_hot) {
+    // ---- hot role
+    for (uint32_t u0 = blockIdx.x * 256; u0 < U; u0 += nb_hot * 256) {
+      if (threadIdx.x == 0) hot_n = 0;
+      __syncthreads();
+      const uint32_t mine = u0 + threadIdx.x;
+      if (mine < U && b.col_ptr[mine + 1] - b.col_ptr[mine] > BWD_MID) hot_u[atomicAdd(&hot_n, 1u)] = mine;
+      __syncthreads();
+      const uint32_t n = hot_n;
+      for (uint32_t q = 0; q < n; ++q) {
+        // LDS slot order is arbitrary but a key's result does not depend on it
+        const uint32_t u = hot_u[q];
+        const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+        const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+        KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
+        __syncthreads();  // previous key's partials consumed
+        if (grp == 0) {
+          if (sub == 0) { part[w][0] = s.gw; part[w][1] = s.xxp; }
+          if (sub_ok) {
+            part[w][2 + sub * 4 + 0] = s.gv.x; part[w][2 + sub * 4 + 1] = s.gv.y;
+            part[w][2 + sub * 4 + 2] = s.gv.z; part[w][2 + sub * 4 + 3] = s.gv.w;
           }
         }
-      }
-    }
-    gw = wave_sum(gw);
-    if (has_v) {
-      xxp = wave_sum(xxp);
-      gv.x = cross_group_sum<L>(gv.x); gv.y = cross_group_sum<L>(gv.y);
-      gv.z = cross_group_sum<L>(gv.z); gv.w = cross_group_sum<L>(gv.w);
-      // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198)
-      gv.x -= v.x * xxp; gv.y -= v.y * xxp; gv.z -= v.z * xxp; gv.w -= v.w * xxp;
-    }
-
-    if (!FUSED) {
-      float* g = grads + (size_t)u * gstride;
-      if (lane == 0) st4(g, make_float4(gw, has_v ? 1.0f : 0.0f, 0.f, 0.f));
-      if (grp == 0 && sub_ok && k > 0) st4(g + 4 + sub * 4, has_v ? gv : make_float4(0.f, 0.f, 0.f, 0.f));
-    } else {
-      // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
-      float pen = 0.f;
-      if (grp == 0 && has_v && sub_ok) pen = 0.5f * t.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-      pen = wave_sum(pen);
-      if (lane == 0) pen_acc += (double)pen + (double)t.p.l1 * fabs((double)w_old) + 0.5 * (double)t.p.l2 * (double)w_old * (double)w_old;
-
-      // SGDUpdater::Update(kGradient) for this key (sgd_updater.cc:86-95)
-      RowHdr* hp = t.hdr + r;
-      if (lane == 0) {
-        float sqrt_g = hp->sqrt_g, z = hp->z;
-        const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
-        hp->w = w_new;
-        hp->sqrt_g = sqrt_g;
-        hp->z = z;
-        // lazy InitV when w leaves zero (sgd_updater.cc:122-126)
-        if (w_old == 0 && w_new != 0 && k > 0 && !has_v && hp->fea_cnt > (float)t.p.V_threshold) {
-          if (t.p.init_mode == DFH_INIT_HASH) {
-            init_v_hash_row(t, r, b.feaids[u]);
-            hp->has_V = 1;
-          } else {
-            need_init[u] = 1;
+        __syncthreads();
+        if (w == 0 && grp == 0) {
+          KeySums tot;
+          tot.gw = 0.f; tot.xxp = 0.f; tot.gv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int i = 0; i < NW; ++i) {
+            tot.gw += part[i][0];
+            tot.xxp += part[i][1];
+            if (sub_ok) {
+              tot.gv.x += part[i][2 + sub * 4 + 0]; tot.gv.y += part[i][2 + sub * 4 + 1];
+              tot.gv.z += part[i][2 + sub * 4 + 2]; tot.gv.w += part[i][2 + sub * 4 + 3];
+            }
           }
+          finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc);
         }
       }
-      if (has_v && grp == 0 && sub_ok) {
-        float* va = t.va + (size_t)r * (2 * kp);
-        float4 acc = ld4(va + kp + sub * 4);
-        float4 nv = v;
-        // padded coordinates (>= k) stay exactly zero: g = 0 + V_l2*0
-        adagrad_update_v(gv.x, nv.x, acc.x, t.p);
-        adagrad_update_v(gv.y, nv.y, acc.y, t.p);
-        adagrad_update_v(gv.z, nv.z, acc.z, t.p);
-        adagrad_update_v(gv.w, nv.w, acc.w, t.p);
-        const int d0 = sub * 4;
-        if (d0 + 0 >= k) { nv.x = 0.f; acc.x = 0.f; }
-        if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
-        if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
-        if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
-        st4(va + sub * 4, nv);
-        st4(va + kp + sub * 4, acc);
+      __syncthreads();
+    }
+  } else if (blockIdx.x < nb_hot + nb_mid) {
+    // ---- mid role
+    const uint32_t wave = (blockIdx.x - nb_hot) * NW + w;
+    const uint32_t nwaves = nb_mid * NW;
+    for (uint32_t u0 = wave * BWD_MIDW; u0 < U; u0 += nwaves * BWD_MIDW) {
+      const uint32_t mine = u0 + lane;
+      uint32_t my_beg = 0, my_cnt = 0;
+      if (lane < BWD_MIDW && mine < U) {
+        my_beg = b.col_ptr[mine];
+        my_cnt = b.col_ptr[mine + 1] - my_beg;
+      }
+      unsigned long long todo = __ballot(my_cnt > BWD_SMALL && my_cnt <= BWD_MID);
+      while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t u = u0 + src_lane;
+        const uint32_t beg = __shfl(my_beg, src_lane, 64);
+        const uint32_t end = beg + __shfl(my_cnt, src_lane, 64);
+        const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+        KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
+        if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
       }
     }
-  }
-  if (FUSED) {
-    __shared__ double blk[4];
-    if (lane == 0) blk[threadIdx.x >> 6] = pen_acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double s = blk[0] + blk[1] + blk[2] + blk[3];
-      if (s != 0.0) atomicAdd(&b.prog[1], s);
+  } else {
+    // ---- small role
+    const uint32_t wave = (blockIdx.x - nb_hot - nb_mid) * NW + w;
+    const uint32_t nwaves = (gridDim.x - nb_hot - nb_mid) * NW;
+    for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
+      const uint32_t u = u0 + grp;
+      if (u >= U) continue;
+      const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+      if (end - beg > BWD_SMALL) continue;  // taken by the mid / hot roles
+      const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+      KeySums s;
+      s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t j0 = beg; j0 < end; j0 += BWD_DEPTH) {
+        float4 a[BWD_DEPTH];
+        float xs[BWD_DEPTH], ps[BWD_DEPTH];
+#pragma unroll
+        for (int q = 0; q < BWD_DEPTH; ++q) {
+          const uint32_t j = j0 + q;
+          const bool ok = j < end;
+          const uint32_t row = ok ? b.s_row[j] : 0;
+          xs[q] = ok ? (b.s_val ? b.s_val[j] : 1.0f) : 0.f;
+          ps[q] = ok ? b.slope[row] : 0.f;
+          a[q] = (ok && k > 0 && sub_ok) ? ld4(b.xv + (size_t)row * kp + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < BWD_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
+          const float pp = ps[q], xx = xs[q];
+          s.gw += pp * xx;
+          s.xxp += pp * (xx * xx);
+          s.gv.x += (a[q].x * pp) * xx; s.gv.y += (a[q].y * pp) * xx;
+          s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
+        }
+      }
+      finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
     }
   }
+  if (FUSED) flush_penalty(b, pen_acc);
 }
 
 // penalty only (validation batches: no backward pass)
@@ -510,7 +716,7 @@ __global__ void __launch_bounds__(256) k_penalty(BatchView b, RowSrc src, TableV
     pen = wave_sum(pen);
     if (lane == 0) pen_acc += (double)pen + (double)t.p.l1 * fabs((double)wf.x) + 0.5 * (double)t.p.l2 * (double)wf.x * (double)wf.x;
   }
-  if (lane == 0 && pen_acc != 0.0) atomicAdd(&b.prog[1], pen_acc);
+  flush_penalty(b, lane == 0 ? pen_acc : 0.0);
 }
 
 // ---------------------------------------------------------------------------
