@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--no-prefill", action="store_true", help="start from an empty model instead of a warm one")
     ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--no-pipeline", action="store_true", help="prepare and train on one stream")
     return ap.parse_args()
 
 
@@ -128,19 +129,30 @@ def main():
         off32 = hb["offset"].astype(np.uint32)
         dev.append((capi.DeviceBuffer.from_numpy(ctx, off32), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
                     capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
-    bt = capi.Batch(ctx, B, B * S)
+    # two batch objects: batch t+1 is copied in, localized and looked up on the
+    # preparation stream while batch t trains on the main stream
+    ctx.set_pipeline(not args.no_pipeline)
+    bts = [capi.Batch(ctx, B, B * S), capi.Batch(ctx, B, B * S)]
+    bt = bts[0]
+
+    def prep(i):
+        o, x, l = dev[i % nd]
+        b = bts[i % 2]
+        b.load_device(B, B * S, o.ptr, x.ptr, None, l.ptr)
+        b.localize()
+        b.lookup(table)
 
     def step(i):
-        o, x, l = dev[i % nd]
-        bt.load_device(B, B * S, o.ptr, x.ptr, None, l.ptr)
-        bt.localize()
-        bt.sgd_step(table, is_train=True, push_cnt=True)
+        prep(i + 1)
+        bts[i % 2].sgd_step(table, is_train=True, push_cnt=True)
 
+    prep(0)
     for i in range(args.warmup):
         step(i)
     ctx.sync()
     torch.cuda.synchronize()
-    bt.progress(reset=True)
+    for b in bts:
+        b.progress(reset=True)
     if not args.no_timing:
         ctx.set_timing(True)
         ctx.get_timing(reset=True)
@@ -150,7 +162,10 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prog = bt.progress(reset=True)
+    progs = [b.progress(reset=True) for b in bts]
+    prog = capi.Progress()
+    prog.loss = sum(p.loss for p in progs)
+    prog.nrows = sum(p.nrows for p in progs)
     timing = {} if args.no_timing else ctx.get_timing(reset=True)
     ctx.set_timing(False)
     _, _, U_last = bt.shape()
@@ -181,7 +196,7 @@ def main():
                    "rows_per_step": B, "nnz_per_row": S, "unique_keys_last_batch": int(U_last),
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
                    "model_keys": int(nkeys), "prefilled": not args.no_prefill, "hyper": HYPER,
-                   "distinct_batches": nd},
+                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "kernel_ms_per_step": {n: (v[0] / max(args.steps, 1)) for n, v in timing.items() if v[1] > 0},

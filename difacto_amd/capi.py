@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup",
 ]
 K_COUNT = 7
 
@@ -113,6 +113,8 @@ def lib():
     L.dfh_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.dfh_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.dfh_table_warm_start.argtypes = [vp, vp, sz, f32, f32]
+    L.dfh_ctx_set_pipeline.argtypes = [vp, i32]
+    L.dfh_batch_lookup.argtypes = [vp, vp]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
@@ -163,6 +165,10 @@ class Context:
 
     def sync(self):
         _ck(lib().dfh_ctx_sync(self.h))
+
+    def set_pipeline(self, on=True):
+        """prepare batch t+1 (copy, localize, lookup) on a second stream while batch t trains"""
+        _ck(lib().dfh_ctx_set_pipeline(self.h, 1 if on else 0))
 
     def set_timing(self, on=True):
         _ck(lib().dfh_ctx_set_timing(self.h, 1 if on else 0))
@@ -324,6 +330,9 @@ class Batch:
     def localize(self, max_index=U64MAX):
         """Localizer::Compact on device"""
         _ck(lib().dfh_localize(self.h, max_index))
+
+    def lookup(self, table):
+        _ck(lib().dfh_batch_lookup(table.h, self.h))
 
     def load_localized_host(self, offset, index, value, label, feaids, feacnt=None):
         offset = np.ascontiguousarray(offset, np.uint64)

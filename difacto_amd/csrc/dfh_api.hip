@@ -21,6 +21,11 @@ struct dfh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream for batch preparation (copies, Localizer, key lookup) so that
+  // batch t+1 is prepared while batch t trains; == stream unless pipelining is on
+  hipStream_t prep = nullptr;
+  hipStream_t prep_own = nullptr;
+  bool pipeline = false;
   // monotonic scratch for the literal (host-pointer) calls
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -39,6 +44,7 @@ namespace {
 struct TimeScope {
   dfh_ctx* c;
   int id;
+  hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
   static hipEvent_t get(dfh_ctx* c) {
     if (!c->pool.empty()) {
@@ -50,15 +56,15 @@ struct TimeScope {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
   }
-  TimeScope(dfh_ctx* ctx, int kid) : c(ctx), id(kid) {
+  TimeScope(dfh_ctx* ctx, int kid, hipStream_t s = nullptr) : c(ctx), id(kid), st(s ? s : ctx->stream) {
     if (!c->timing) return;
     a = get(c);
     b = get(c);
-    if (a && b) (void)hipEventRecord(a, c->stream);
+    if (a && b) (void)hipEventRecord(a, st);
   }
   ~TimeScope() {
     if (!c->timing || !a || !b) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->spans.push_back({id, a, b});
   }
 };
@@ -106,7 +112,52 @@ struct dfh_batch {
   size_t xv_floats = 0;
   double* d_prog = nullptr;
   float nrows_seen = 0;
+  // pipelining: prep-stream work -> ev_ready -> main-stream step -> ev_free -> next prep
+  hipEvent_t ev_ready = nullptr, ev_free = nullptr;
+  bool ready_pending = false, free_pending = false;
+  dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
 };
+
+namespace {
+// prep-stream work on a batch must not overwrite buffers a queued step still reads
+int prep_begin(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  if (c->prep != c->stream && b->free_pending) {
+    DFH_HIP(hipStreamWaitEvent(c->prep, b->ev_free, 0));
+    b->free_pending = false;
+  }
+  return DFH_OK;
+}
+int prep_end(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  if (c->prep != c->stream) {
+    DFH_HIP(hipEventRecord(b->ev_ready, c->prep));
+    b->ready_pending = true;
+  }
+  return DFH_OK;
+}
+int main_begin(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  if (b->ready_pending) {
+    DFH_HIP(hipStreamWaitEvent(c->stream, b->ev_ready, 0));
+    b->ready_pending = false;
+  }
+  return DFH_OK;
+}
+int main_end(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  if (c->prep != c->stream) {
+    DFH_HIP(hipEventRecord(b->ev_free, c->stream));
+    b->free_pending = true;
+  }
+  return DFH_OK;
+}
+int sync_all(dfh_ctx* c) {
+  if (c->prep != c->stream) DFH_HIP(hipStreamSynchronize(c->prep));
+  DFH_HIP(hipStreamSynchronize(c->stream));
+  return DFH_OK;
+}
+}  // namespace
 
 namespace {
 
@@ -369,6 +420,7 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
     }
     c->own_stream = true;
   }
+  c->prep = c->stream;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   *out = c;
@@ -385,6 +437,10 @@ int dfh_ctx_destroy(dfh_ctx* c) {
     hipEventDestroy(sp.b);
   }
   for (auto e : c->pool) hipEventDestroy(e);
+  if (c->prep_own) {
+    hipStreamSynchronize(c->prep_own);
+    hipStreamDestroy(c->prep_own);
+  }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return DFH_OK;
@@ -392,7 +448,20 @@ int dfh_ctx_destroy(dfh_ctx* c) {
 
 int dfh_ctx_sync(dfh_ctx* c) {
   DFH_ARG(c, "ctx is NULL");
-  DFH_HIP(hipStreamSynchronize(c->stream));
+  return sync_all(c);
+}
+
+int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
+  DFH_ARG(c, "ctx is NULL");
+  int rc = sync_all(c);
+  if (rc) return rc;
+  if (enable) {
+    if (!c->prep_own) DFH_HIP(hipStreamCreateWithFlags(&c->prep_own, hipStreamNonBlocking));
+    c->prep = c->prep_own;
+  } else {
+    c->prep = c->stream;
+  }
+  c->pipeline = enable != 0;
   return DFH_OK;
 }
 void* dfh_ctx_stream(dfh_ctx* c) { return c ? c->stream : nullptr; }
@@ -406,7 +475,10 @@ int dfh_ctx_set_timing(dfh_ctx* c, int enable) {
 
 int dfh_ctx_get_timing(dfh_ctx* c, int reset, double* total_ms, uint64_t* calls) {
   DFH_ARG(c, "ctx is NULL");
-  DFH_HIP(hipStreamSynchronize(c->stream));
+  {
+    int rc = sync_all(c);
+    if (rc) return rc;
+  }
   for (auto& sp : c->spans) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
@@ -568,7 +640,7 @@ int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const f
   }
   hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (const uint32_t*)nullptr, (uint32_t)n, refrand ? t->d_urow : (uint32_t*)nullptr, d_cnt,
-                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr);
+                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr, 0);
   DFH_HIP(hipGetLastError());
   if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
   return DFH_OK;
@@ -981,6 +1053,8 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_prog, 2 * PROG_SLOTS, double);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
+  DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
+  DFH_HIP(hipEventCreateWithFlags(&b->ev_free, hipEventDisableTiming));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, 2 * PROG_SLOTS * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
@@ -991,7 +1065,9 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
 int dfh_batch_destroy(dfh_batch* b) {
   if (!b) return DFH_OK;
   hipSetDevice(b->ctx->device);
-  hipStreamSynchronize(b->ctx->stream);
+  sync_all(b->ctx);
+  if (b->ev_ready) hipEventDestroy(b->ev_ready);
+  if (b->ev_free) hipEventDestroy(b->ev_free);
   void* ptrs[] = {b->d_raw,   b->d_offset, b->d_value,   b->d_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_pred,  b->d_slope, b->d_xv,
@@ -1012,8 +1088,10 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   const size_t base = offset[0], nnz = off32[nrows];
   DFH_ARG(nnz <= b->max_nnz, "dfh_batch_load_host: nnz exceeds max_nnz");
   DFH_ARG(nnz == 0 || index, "index is NULL");
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->ctx->prep;
   DFH_HIP(hipSetDevice(b->ctx->device));
+  rc = prep_begin(b);
+  if (rc) return rc;
   DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, index + base, nnz * 8, hipMemcpyHostToDevice, s));
   if (nnz && value) DFH_HIP(hipMemcpyAsync(b->d_value, value + base, nnz * 4, hipMemcpyHostToDevice, s));
@@ -1024,6 +1102,7 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   b->has_value = value != nullptr;
   b->has_cnt = false;
   b->localized = false;
+  b->looked_up = nullptr;
   return DFH_OK;
 }
 
@@ -1031,7 +1110,11 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
                           const float* d_value, const float* d_label) {
   DFH_ARG(b && d_offset && d_label && (nnz == 0 || d_index), "dfh_batch_load_device: NULL argument");
   DFH_ARG(nrows >= 1 && nrows <= b->max_rows && nnz <= b->max_nnz, "dfh_batch_load_device: shape out of range");
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->ctx->prep;
+  {
+    int rc = prep_begin(b);
+    if (rc) return rc;
+  }
   DFH_HIP(hipMemcpyAsync(b->d_offset, d_offset, (nrows + 1) * 4, hipMemcpyDeviceToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, d_index, nnz * 8, hipMemcpyDeviceToDevice, s));
   if (nnz && d_value) DFH_HIP(hipMemcpyAsync(b->d_value, d_value, nnz * 4, hipMemcpyDeviceToDevice, s));
@@ -1041,6 +1124,7 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
   b->has_value = d_value != nullptr;
   b->has_cnt = false;
   b->localized = false;
+  b->looked_up = nullptr;
   return DFH_OK;
 }
 
@@ -1048,17 +1132,22 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
   DFH_ARG(max_index != 0, "max_index must be nonzero");
   dfh_ctx* c = b->ctx;
-  hipStream_t s = c->stream;
+  hipStream_t s = c->prep;
   const uint32_t N = (uint32_t)b->nnz;
+  {
+    int rc = prep_begin(b);
+    if (rc) return rc;
+  }
+  b->looked_up = nullptr;
   if (N == 0) {
     // reference would index an empty vector (localizer.cc:35); define: no keys
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, b->d_U, 0u);
     DFH_HIP(hipMemsetAsync(b->d_col_ptr, 0, 4, s));
     b->localized = true;
-    return DFH_OK;
+    return prep_end(b);
   }
   const int g = grid_for_threads(N, c);
-  TimeScope ts(c, DFH_K_LOCALIZE);
+  TimeScope* tsp = new TimeScope(c, DFH_K_LOCALIZE, s);
   hipLaunchKernelGGL(k_loc_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
   size_t tb = b->temp_bytes;
   DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_keys, b->d_skeys, b->d_pos, b->d_spos, (size_t)N, 0, 64, s));
@@ -1068,10 +1157,31 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   hipLaunchKernelGGL(k_loc_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
                      b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                      b->d_s_row, b->d_s_val, b->d_U);
+  delete tsp;
   DFH_HIP(hipGetLastError());
   b->localized = true;
   b->has_cnt = false;
-  return DFH_OK;
+  return prep_end(b);
+}
+
+int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
+  DFH_ARG(t && b && t->ctx == b->ctx, "dfh_batch_lookup: bad argument");
+  if (!b->localized) {
+    set_error("dfh_batch_lookup: batch is not localized");
+    return DFH_ERR_STATE;
+  }
+  dfh_ctx* c = b->ctx;
+  if (b->nnz == 0) return DFH_OK;
+  int rc = prep_begin(b);
+  if (rc) return rc;
+  {
+    TimeScope ts(c, DFH_K_LOOKUP, c->prep);
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, c->prep, t->v, b->d_feaids, b->d_U, 0u,
+                       b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0);
+  }
+  DFH_HIP(hipGetLastError());
+  b->looked_up = t;
+  return prep_end(b);
 }
 
 int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,
@@ -1105,8 +1215,11 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
         if (value) s_val[q] = value[base + j];
       }
   }
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->ctx->prep;
   DFH_HIP(hipSetDevice(b->ctx->device));
+  rc = prep_begin(b);
+  if (rc) return rc;
+  b->looked_up = nullptr;
   uint32_t U32 = (uint32_t)U;
   DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
   if (nnz) {
@@ -1128,7 +1241,7 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   b->has_value = value != nullptr;
   b->has_cnt = feacnt != nullptr;
   b->localized = true;
-  return DFH_OK;
+  return prep_end(b);
 }
 
 int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
@@ -1138,6 +1251,8 @@ int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
   if (U) {
     DFH_ARG(b->localized, "batch is not localized");
     uint32_t u = 0;
+    int rc = sync_all(b->ctx);
+    if (rc) return rc;
     DFH_HIP(hipMemcpyAsync(&u, b->d_U, 4, hipMemcpyDeviceToHost, b->ctx->stream));
     DFH_HIP(hipStreamSynchronize(b->ctx->stream));
     *U = u;
@@ -1170,7 +1285,7 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
   if (d_feaids) *d_feaids = b->d_feaids;
   if (d_feacnt) {
     if (!b->has_cnt) {
-      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, b->ctx)), dim3(256), 0, b->ctx->stream, b->d_col_ptr,
+      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, b->ctx)), dim3(256), 0, b->ctx->prep, b->d_col_ptr,
                          b->d_U, b->d_feacnt);
       DFH_HIP(hipGetLastError());
       b->has_cnt = true;
@@ -1199,16 +1314,25 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   if (b->nnz == 0) {
     // rows without features: pred = 0 for every example; nothing to pull or push
     RowSrc src = table_src(t, b->d_urow);
-    return launch_forward(b, src, k, kp);
+    rc = main_begin(b);
+    if (rc) return rc;
+    rc = launch_forward(b, src, k, kp);
+    if (rc) return rc;
+    return main_end(b);
   }
   const bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && k > 0;
   const uint32_t Nb = (uint32_t)b->nnz;  // upper bound of U for grids
-  // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217)
-  {
+  rc = main_begin(b);
+  if (rc) return rc;
+  // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217).  When
+  // dfh_batch_lookup already resolved the rows on the prep stream only the count
+  // push remains (it must stay ordered with the previous step's update).
+  const bool pre = b->looked_up == t;
+  if (!pre || push_cnt) {
     TimeScope ts(c, DFH_K_LOOKUP);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? 1 : 0,
-                       refrand ? b->d_need : (uint32_t*)nullptr);
+                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0);
   }
   DFH_HIP(hipGetLastError());
   if (push_cnt && refrand) {
@@ -1231,7 +1355,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(Nb, c), PROG_SLOTS)), dim3(256), 0, s, bv, src, t->v, k, kp);
     DFH_HIP(hipGetLastError());
   }
-  return DFH_OK;
+  return main_end(b);
 }
 
 int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows) {
@@ -1240,6 +1364,8 @@ int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows) {
   int rc = ensure_xv(b, kp);
   if (rc) return rc;
   b->nrows_seen += (float)b->nrows;
+  rc = main_begin(b);
+  if (rc) return rc;
   return launch_forward(b, packed_src(d_rows, V_dim), V_dim, kp);
 }
 
@@ -1248,13 +1374,19 @@ int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_gr
   const int kp = (V_dim + 3) / 4 * 4;
   if (b->nnz == 0) return DFH_OK;
   TableView dummy{};
-  return launch_backward<false>(b, packed_src(d_rows, V_dim), dummy, d_grads, dfh_row_stride(V_dim), V_dim, kp, nullptr);
+  int rc = launch_backward<false>(b, packed_src(d_rows, V_dim), dummy, d_grads, dfh_row_stride(V_dim), V_dim, kp, nullptr);
+  if (rc) return rc;
+  return main_end(b);
 }
 
 int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
   DFH_ARG(b && out, "NULL argument");
   std::vector<double> p(2 * PROG_SLOTS);
   hipStream_t s = b->ctx->stream;
+  {
+    int rc = sync_all(b->ctx);
+    if (rc) return rc;
+  }
   DFH_HIP(hipMemcpyAsync(p.data(), b->d_prog, p.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   DFH_HIP(hipStreamSynchronize(s));
   double loss = 0, pen = 0;

@@ -176,12 +176,14 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
 // ---------------------------------------------------------------------------
 __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
-                         const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init) {
+                         const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
+                         int rows_known) {
   uint32_t n = d_n ? *d_n : n_static;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
     uint64_t key = keys[u];
-    uint32_t r = find_or_insert(t, key);
-    if (urow) urow[u] = r;
+    // rows_known: urow was filled by an earlier (prep-stream) lookup of the same keys
+    uint32_t r = rows_known ? urow[u] : find_or_insert(t, key);
+    if (urow && !rows_known) urow[u] = r;
     if (push_cnt) {
       float c = cnt ? cnt[u] : (float)(col_ptr[u + 1] - col_ptr[u]);
       RowHdr& h = t.hdr[r];

@@ -75,6 +75,13 @@ int dfh_ctx_sync(dfh_ctx* ctx);
 void* dfh_ctx_stream(dfh_ctx* ctx);
 int dfh_ctx_device(dfh_ctx* ctx);
 
+/* Pipelining: with enable != 0 batch preparation (dfh_batch_load_*, dfh_localize,
+ * dfh_batch_lookup) runs on a second HIP stream, so batch t+1 is prepared while
+ * batch t trains — the overlap the reference gets from its reader thread
+ * (src/sgd/sgd_learner.cc:196-224).  Ordering per batch object is kept with
+ * events inside the library; use two dfh_batch objects alternately. */
+int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
+
 /* optional per-kernel timing with HIP events recorded on the context's stream
  * (what bench.py's roofline block reads); ids index total_ms[]/calls[] */
 enum {
@@ -159,6 +166,11 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
  * index per nnz — bit-exact with the reference — plus the key-ordered view the
  * backward pass's segmented sum walks. */
 int dfh_localize(dfh_batch* b, uint64_t max_index);
+/* resolve the batch's unique keys to table rows ahead of dfh_sgd_step (inserting
+ * unseen keys as zero rows, src/sgd/sgd_updater.cc:44); runs with the preparation
+ * work.  Optional: dfh_sgd_step does it itself when this was not called. */
+int dfh_batch_lookup(dfh_table* t, dfh_batch* b);
+
 /* already-localized batch from the host (what SGDLearner hands its batch thread,
  * src/sgd/sgd_learner.cc:203-212): feaids sorted unique, compact u32 index */
 int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index,

@@ -383,3 +383,44 @@ def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
     L.dfh_free(ctx.h, d_grads)
     for o in (ta, tb, ba, bb):
         o.close()
+
+
+def test_pipelined_prep_matches_serial(capi, oracle):
+    """preparing batch t+1 on the second stream while batch t trains gives the
+    same predictions and the same model as the serial order"""
+    rng = np.random.default_rng(31)
+    batches = [random_batch(rng, 200, 500, 30, binary=(i % 2 == 0), empty_rows=False) for i in range(6)]
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=5)
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    results = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0)
+        ctx.set_pipeline(pipelined)
+        tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
+        bts = [capi.Batch(ctx, 200, max_nnz), capi.Batch(ctx, 200, max_nnz)]
+
+        def prep(i):
+            b = batches[i % len(batches)]
+            bts[i % 2].load_host(b["offset"], b["index"], b["value"], b["label"])
+            bts[i % 2].localize()
+            bts[i % 2].lookup(tb)
+
+        preds = []
+        nsteps = 18
+        prep(0)
+        for i in range(nsteps):
+            if i + 1 < nsteps:
+                prep(i + 1)
+            bts[i % 2].sgd_step(tb, is_train=True, push_cnt=(i < len(batches)))
+            if i % 5 == 4:
+                preds.append(bts[i % 2].pred())
+        keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
+        results.append((preds, tb.pull(keys)))
+        for o in bts + [tb]:
+            o.close()
+        ctx.close()
+    (p0, (v0, l0)), (p1, (v1, l1)) = results
+    assert np.array_equal(l0, l1)
+    for a, b in zip(p0, p1):
+        assert_close(b, a, what="pred")
+    assert_close(v1, v0, rtol=2e-5, what="weights")
