@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option",
 ]
 K_COUNT = 7
 
@@ -115,6 +115,7 @@ def lib():
     L.dfh_table_warm_start.argtypes = [vp, vp, sz, f32, f32]
     L.dfh_ctx_set_pipeline.argtypes = [vp, i32]
     L.dfh_batch_lookup.argtypes = [vp, vp]
+    L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
@@ -330,6 +331,9 @@ class Batch:
     def localize(self, max_index=U64MAX):
         """Localizer::Compact on device"""
         _ck(lib().dfh_localize(self.h, max_index))
+
+    def set_option(self, name, value):
+        _ck(lib().dfh_batch_set_option(self.h, name.encode(), int(value)))
 
     def lookup(self, table):
         _ck(lib().dfh_batch_lookup(table.h, self.h))

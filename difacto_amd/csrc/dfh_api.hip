@@ -8,6 +8,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dfh_kernels.hip"
+#include "dfh_localize.hip"
 
 using namespace dfh;
 
@@ -100,6 +101,11 @@ struct dfh_batch {
   uint32_t *d_pos = nullptr, *d_spos = nullptr, *d_head = nullptr, *d_uid = nullptr;
   void* d_temp = nullptr;
   size_t temp_bytes = 0;
+  // sample-sort localizer workspace
+  uint64_t *d_spl_key = nullptr, *d_first_key = nullptr, *d_last_key = nullptr, *d_smp_key = nullptr;
+  uint32_t *d_smp_pos = nullptr, *d_spl_pos = nullptr, *d_packed = nullptr, *d_hist = nullptr, *d_run_off = nullptr, *d_bstart = nullptr,
+           *d_nheads = nullptr, *d_bpos = nullptr, *d_btotal = nullptr, *d_ubase = nullptr, *d_cont = nullptr;
+  size_t max_tiles = 0;
   // localized view
   uint64_t* d_feaids = nullptr;
   float* d_feacnt = nullptr;
@@ -115,6 +121,8 @@ struct dfh_batch {
   // pipelining: prep-stream work -> ev_ready -> main-stream step -> ev_free -> next prep
   hipEvent_t ev_ready = nullptr, ev_free = nullptr;
   bool ready_pending = false, free_pending = false;
+  bool force_radix = false;        // tests: take the library-sort path of dfh_localize
+  bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
 };
 
@@ -1038,6 +1046,22 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_head, N, uint32_t);
   DFH_ALLOC(b->d_uid, N, uint32_t);
   DFH_ALLOC(b->d_temp, b->temp_bytes, char);
+  b->max_tiles = (N + SS_TILE - 1) / SS_TILE;
+  DFH_ALLOC(b->d_spl_key, SS_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_smp_key, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint64_t);
+  DFH_ALLOC(b->d_smp_pos, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_first_key, SS_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_last_key, SS_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_spl_pos, SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_packed, N, uint32_t);
+  DFH_ALLOC(b->d_hist, b->max_tiles * SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_run_off, b->max_tiles * SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_bstart, SS_MAX_BUCKETS + 1, uint32_t);
+  DFH_ALLOC(b->d_nheads, SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_bpos, N, uint32_t);
+  DFH_ALLOC(b->d_btotal, SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_ubase, SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_cont, SS_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
   DFH_ALLOC(b->d_feacnt, N, float);
   DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
@@ -1071,7 +1095,8 @@ int dfh_batch_destroy(dfh_batch* b) {
   void* ptrs[] = {b->d_raw,   b->d_offset, b->d_value,   b->d_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_pred,  b->d_slope, b->d_xv,
-                  b->d_prog};
+                  b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
+                  b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1148,20 +1173,76 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   }
   const int g = grid_for_threads(N, c);
   TimeScope* tsp = new TimeScope(c, DFH_K_LOCALIZE, s);
-  hipLaunchKernelGGL(k_loc_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
-  size_t tb = b->temp_bytes;
-  DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_keys, b->d_skeys, b->d_pos, b->d_spos, (size_t)N, 0, 64, s));
-  hipLaunchKernelGGL(k_loc_heads, dim3(g), dim3(256), 0, s, b->d_skeys, N, b->d_head);
-  tb = b->temp_bytes;
-  DFH_HIP(rocprim::inclusive_scan(b->d_temp, tb, b->d_head, b->d_uid, (size_t)N, rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(k_loc_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
-                     b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
-                     b->d_s_row, b->d_s_val, b->d_U);
+  const size_t P_want = (N + SS_AVG_BUCKET - 1) / SS_AVG_BUCKET;
+  if (P_want <= SS_MAX_BUCKETS && !b->force_radix) {
+    // hand-written sample sort (dfh_localize.hip)
+    SSView v;
+    v.raw = b->d_raw;
+    v.n = N;
+    v.max_index = max_index;
+    v.P = (int)std::max<size_t>(1, P_want);
+    v.ntiles = (int)((N + SS_TILE - 1) / SS_TILE);
+    v.force_global = b->force_sort_fallback ? 1 : 0;
+    v.smp_key = b->d_smp_key;
+    v.smp_pos = b->d_smp_pos;
+    v.spl_key = b->d_spl_key;
+    v.spl_pos = b->d_spl_pos;
+    v.packed = b->d_packed;
+    v.hist = b->d_hist;
+    v.run_off = b->d_run_off;
+    v.bstart = b->d_bstart;
+    v.btotal = b->d_btotal;
+    v.bkeys = b->d_keys;
+    v.bpos = b->d_bpos;
+    v.ubase = b->d_ubase;
+    v.cont = b->d_cont;
+    v.skeys = b->d_skeys;
+    v.spos = b->d_spos;
+    v.luid = b->d_uid;
+    v.head = b->d_head;
+    v.first_key = b->d_first_key;
+    v.last_key = b->d_last_key;
+    v.nheads = b->d_nheads;
+    const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
+    hipLaunchKernelGGL(k_ss_splitters, dim3((S + 15) / 16), dim3(256), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+    hipLaunchKernelGGL(k_ss_count, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_ss_scan, dim3((v.P + SS_SCAN_BUCKETS - 1) / SS_SCAN_BUCKETS), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_ss_scatter, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_ss_sort, dim3(v.P), dim3(SS_SORT_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_ss_emit, dim3(v.P), dim3(256), 0, s, v, b->d_pos,
+                       b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                       b->d_s_val, b->d_U);
+  } else {
+    // very large batches: library LSD radix sort
+    hipLaunchKernelGGL(k_loc_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
+    size_t tb = b->temp_bytes;
+    DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_keys, b->d_skeys, b->d_pos, b->d_spos, (size_t)N, 0, 64, s));
+    hipLaunchKernelGGL(k_loc_heads, dim3(g), dim3(256), 0, s, b->d_skeys, N, b->d_head);
+    tb = b->temp_bytes;
+    DFH_HIP(rocprim::inclusive_scan(b->d_temp, tb, b->d_head, b->d_uid, (size_t)N, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_loc_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
+                       b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
+                       b->d_s_row, b->d_s_val, b->d_U);
+  }
   delete tsp;
   DFH_HIP(hipGetLastError());
   b->localized = true;
   b->has_cnt = false;
   return prep_end(b);
+}
+
+int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
+  DFH_ARG(b && name, "NULL argument");
+  if (std::string(name) == "force_radix_sort") {
+    b->force_radix = value != 0;
+    return DFH_OK;
+  }
+  if (std::string(name) == "force_sort_fallback") {
+    b->force_sort_fallback = value != 0;
+    return DFH_OK;
+  }
+  set_error(std::string("unknown batch option ") + name);
+  return DFH_ERR_ARG;
 }
 
 int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {

@@ -166,6 +166,11 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
  * index per nnz — bit-exact with the reference — plus the key-ordered view the
  * backward pass's segmented sum walks. */
 int dfh_localize(dfh_batch* b, uint64_t max_index);
+/* tuning / test switches: "force_radix_sort" = 1 makes dfh_localize take its
+ * large-batch path (library LSD radix sort) whatever the batch size;
+ * "force_sort_fallback" = 1 sorts every bucket through the oversize-bucket path */
+int dfh_batch_set_option(dfh_batch* b, const char* name, int value);
+
 /* resolve the batch's unique keys to table rows ahead of dfh_sgd_step (inserting
  * unseen keys as zero rows, src/sgd/sgd_updater.cc:44); runs with the preparation
  * work.  Optional: dfh_sgd_step does it itself when this was not called. */

@@ -115,8 +115,10 @@ def test_literal_predict_accumulates(ctx, oracle):
 
 
 # ------------------------------------------------------------------ device Localizer
-@pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same"])
-def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case):
+@pytest.mark.parametrize("path", ["sample_sort", "radix", "sample_sort_fallback"])
+@pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same", "criteo_like",
+                                  "bias_feature", "sorted_input", "clustered"])
+def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     rng = np.random.default_rng(11)
     mx = U64MAX
     if case == "rcv1":
@@ -129,11 +131,37 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case):
         b = random_batch(rng, 2000, 5000, 39, binary=True, empty_rows=False)
     elif case == "one_row":
         b = random_batch(rng, 1, 50, 30, empty_rows=False)
+    elif case == "criteo_like":
+        from difacto_amd import synth
+        b = synth.CriteoSynth(total_ids=200000, seed=3).batch(3000)  # 117 k pairs, Zipf duplicates, many buckets
+    elif case == "bias_feature":
+        # one feature present in every row (a segment far larger than a bucket) + noise
+        nr, s = 9000, 5
+        idx = rng.integers(0, 2 ** 40, size=(nr, s), dtype=np.uint64)
+        idx[:, 2] = 77
+        b = dict(offset=(np.arange(nr + 1) * s).astype(np.uint64), index=idx.reshape(-1), value=None,
+                 label=np.ones(nr, np.float32))
+    elif case == "clustered":
+        # almost every id lives in one narrow key range, a few are spread out: the splitters
+        # land on the spread ones and one bucket overflows its LDS capacity -> the global
+        # merge path of k_ss_sort must still give the exact result
+        nr, s = 3000, 8
+        idx = rng.integers(0, 2 ** 64 - 1, size=nr * s, dtype=np.uint64)
+        jam = rng.random(nr * s) < 0.97
+        idx[jam] = rng.integers(0, 50000, size=int(jam.sum()), dtype=np.uint64) << np.uint64(44)
+        b = dict(offset=(np.arange(nr + 1) * s).astype(np.uint64), index=idx, value=None, label=np.ones(nr, np.float32))
+    elif case == "sorted_input":
+        nr, s = 4000, 8
+        idx = np.sort(rng.integers(0, 2 ** 62, size=nr * s, dtype=np.uint64))
+        b = dict(offset=(np.arange(nr + 1) * s).astype(np.uint64), index=idx, value=rng.normal(size=nr * s).astype(np.float32),
+                 label=np.ones(nr, np.float32))
     else:
         b = dict(offset=np.array([0, 3, 5], np.uint64), index=np.full(5, 12345, np.uint64),
                  value=np.arange(5, dtype=np.float32), label=np.array([1, -1], np.float32))
     nnz = int(b["offset"][-1])
     bt = capi.Batch(ctx, len(b["label"]), max(nnz, 1))
+    bt.set_option("force_radix_sort", path == "radix")
+    bt.set_option("force_sort_fallback", path == "sample_sort_fallback")
     bt.load_host(b["offset"], b["index"], b["value"], b["label"])
     bt.localize(mx)
     got = bt.get_localized()
