@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges",
 ]
 K_COUNT = 7
 
@@ -116,6 +116,7 @@ def lib():
     L.dfh_ctx_set_pipeline.argtypes = [vp, i32]
     L.dfh_batch_lookup.argtypes = [vp, vp]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
@@ -382,6 +383,12 @@ class Batch:
 
     def backward(self, V_dim, d_rows, d_grads):
         _ck(lib().dfh_batch_backward(self.h, V_dim, _dp(d_rows), _dp(d_grads)))
+
+    def key_ranges(self, nparts):
+        """bounds[nparts+1]: shard d owns feaids[bounds[d]:bounds[d+1]] (key-range partition)"""
+        out = np.zeros(nparts + 1, np.uint32)
+        _ck(lib().dfh_batch_key_ranges(self.h, nparts, _p(out)))
+        return out
 
     def device_keys(self):
         a, b, u = C.c_void_p(), C.c_void_p(), C.c_size_t(0)

@@ -1377,6 +1377,26 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
   return DFH_OK;
 }
 
+int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds) {
+  DFH_ARG(b && b->localized && bounds && nparts >= 1 && nparts <= 1024, "dfh_batch_key_ranges: bad argument");
+  dfh_ctx* c = b->ctx;
+  int rc = ensure_scratch(c, (size_t)(nparts + 1) * 4 + 256);
+  if (rc) return rc;
+  uint32_t* d_bounds = static_cast<uint32_t*>(c->scratch);
+  // span = ceil(2^64 / nparts): shard d owns keys in [d*span, (d+1)*span)
+  const uint64_t span = nparts == 1 ? ~0ULL : (~0ULL / (uint64_t)nparts) + 1;
+  hipStream_t s = c->prep;
+  if (b->nnz == 0) {
+    for (int d = 0; d <= nparts; ++d) bounds[d] = 0;
+    return DFH_OK;
+  }
+  hipLaunchKernelGGL(k_key_ranges, dim3((nparts + 256) / 256), dim3(256), 0, s, b->d_feaids, b->d_U, nparts, span, d_bounds);
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipMemcpyAsync(bounds, d_bounds, (size_t)(nparts + 1) * 4, hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  return DFH_OK;
+}
+
 // ------------------------------------------------------------ the fused step
 int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   DFH_ARG(t && b, "dfh_sgd_step: NULL argument");

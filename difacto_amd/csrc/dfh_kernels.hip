@@ -973,6 +973,25 @@ __global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* _
 
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 
+// bounds[d] = first unique key of the batch owned by shard d (keys ascending; owner = key / span)
+__global__ void k_key_ranges(const uint64_t* __restrict__ feaids, const uint32_t* __restrict__ d_U, int nparts,
+                             uint64_t span, uint32_t* __restrict__ bounds) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d > nparts) return;
+  const uint32_t U = *d_U;
+  if (d == nparts) {
+    bounds[d] = U;
+    return;
+  }
+  const uint64_t first = (uint64_t)d * span;  // d < nparts so this does not overflow
+  uint32_t lo = 0, hi = U;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (feaids[mid] < first) lo = mid + 1; else hi = mid;
+  }
+  bounds[d] = lo;
+}
+
 // warm start (model preload for benchmarks / resume): one wave per unique key:
 // row gets w = w0, fea_cnt = cnt0 and an allocated, hash-initialised V.
 __global__ void __launch_bounds__(256) k_warm_start(TableView t, const uint64_t* __restrict__ keys, uint64_t n, float w0,

@@ -210,6 +210,11 @@ int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const fl
 int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows);
 int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_grads);
 int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float** d_feacnt, size_t* U);
+/* key-range partition of the batch's (ascending) unique keys over nparts shards:
+ * shard d owns keys in [d*span, (d+1)*span), span = ceil(2^64/nparts) — the range
+ * partitioning ReverseBytes exists for (include/difacto/base.h:29-38).  HOST output
+ * bounds[nparts+1]: shard d gets feaids[bounds[d] .. bounds[d+1]).  Synchronises. */
+int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds);
 
 /* raw device memory for hosts without a HIP runtime of their own */
 int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);

@@ -1,0 +1,118 @@
+"""Test double for difacto_amd.sharded's compute backend: the CPU oracle stands in
+for the HIP kernels so the exchange logic (key-range partition, all_to_all_v of
+keys / rows / gradients, sequential application in source-rank order) can be
+exercised with gloo on CPU.  TEST INFRASTRUCTURE ONLY."""
+import numpy as np
+import torch
+
+from oracle import bindings as ob
+
+U64MAX = 2 ** 64 - 1
+
+
+def row_stride(V_dim):
+    return 4 + (V_dim + 3) // 4 * 4
+
+
+class OracleBackend:
+    def __init__(self, V_dim, hyper):
+        self.o = ob.Oracle()
+        self.store = self.o.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
+        self.V_dim = V_dim
+        self.stride = row_stride(V_dim)
+        self.device = torch.device("cpu")
+        self.loss = 0.0
+        self.nrows = 0.0
+
+    # worker side
+    def load_and_localize(self, b):
+        self.b = b
+        self.loc = self.o.localize(b["offset"], b["index"])
+
+    def unique_keys(self):
+        return (torch.from_numpy(self.loc["feaids"].view(np.int64).copy()),
+                torch.from_numpy(self.loc["feacnt"].copy()))
+
+    def key_ranges(self, world):
+        span = U64MAX if world == 1 else U64MAX // world + 1
+        firsts = np.array([min(d * span, U64MAX) for d in range(world)], dtype=np.uint64)
+        b = np.searchsorted(self.loc["feaids"], firsts, side="left").astype(np.int64)
+        return np.concatenate([b, [self.loc["U"]]])
+
+    def _ragged(self, rows):
+        rows = rows.numpy()
+        k = self.V_dim
+        has_v = rows[:, 1] != 0
+        lens = np.where(has_v, 1 + k, 1).astype(np.int32)
+        vals = []
+        for r, hv in zip(rows, has_v):
+            vals.append(r[0:1])
+            if hv:
+                vals.append(r[4:4 + k])
+        W = np.concatenate(vals).astype(np.float32) if len(vals) else np.zeros(0, np.float32)
+        return W, lens
+
+    def forward(self, rows):
+        W, lens = self._ragged(rows)
+        self._W, self._lens = W, lens
+        if self.V_dim:
+            self._wp, self._vp = self.o.get_pos(lens)
+        else:
+            self._wp = self._vp = None
+        self._pred = self.o.fm_predict(self.V_dim, self.loc["offset"], self.loc["index"], self.b["value"], W, self._wp, self._vp)
+        self.loss += self.o.loss_evaluate(self.b["label"], self._pred)
+        self.nrows += len(self._pred)
+
+    def backward(self, rows, grads):
+        g = self.o.fm_calcgrad(self.V_dim, self.loc["offset"], self.loc["index"], self.b["value"], self.b["label"],
+                               self._W, self._pred, self._wp, self._vp)
+        out = grads.numpy()
+        out[:] = 0
+        k = self.V_dim
+        p = 0
+        for u, l in enumerate(self._lens):
+            out[u, 0] = g[p]
+            p += 1
+            if l > 1:
+                out[u, 1] = 1.0
+                out[u, 4:4 + k] = g[p:p + k]
+                p += k
+
+    def pred(self):
+        return self._pred
+
+    # owner side
+    def owner_push_count(self, keys, cnt):
+        if keys.numel():
+            self.store.push(keys.numpy().view(np.uint64), ob.FEA_COUNT, cnt.numpy())
+
+    def owner_pull(self, keys, rows):
+        if not keys.numel():
+            return
+        vals, lens = self.store.pull(keys.numpy().view(np.uint64))
+        out = rows.numpy()
+        out[:] = 0
+        k = self.V_dim
+        p = 0
+        for u in range(keys.numel()):
+            out[u, 0] = vals[p]
+            p += 1
+            if k and lens[u] > 1:
+                out[u, 1] = 1.0
+                out[u, 4:4 + k] = vals[p:p + k]
+                p += k
+
+    def owner_push_grad(self, keys, grads):
+        if not keys.numel():
+            return
+        g = grads.numpy()
+        k = self.V_dim
+        vals, lens = [], []
+        for r in g:
+            vals.append(r[0:1])
+            if k and r[1] != 0:
+                vals.append(r[4:4 + k])
+                lens.append(1 + k)
+            else:
+                lens.append(1)
+        self.store.push(keys.numpy().view(np.uint64), ob.GRADIENT, np.concatenate(vals), np.array(lens, np.int32) if k else None)

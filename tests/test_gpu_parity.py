@@ -452,3 +452,48 @@ def test_pipelined_prep_matches_serial(capi, oracle):
     for a, b in zip(p0, p1):
         assert_close(b, a, what="pred")
     assert_close(v1, v0, rtol=2e-5, what="weights")
+
+
+def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
+    """difacto_amd.sharded with the HIP backend (RCCL, world_size 1): the
+    pull -> forward/backward on packed rows -> push path equals the fused step"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from difacto_amd import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(55)
+        kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
+        batches = [random_batch(rng, 150, 2 ** 64 - 1 if i else 500, 25, binary=(i == 1)) for i in range(3)]
+        max_nnz = max(int(b["offset"][-1]) for b in batches)
+        be = sharded.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
+        w = sharded.ShardedWorker(be)
+        ctx = capi.Context(0)
+        tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
+        bt = capi.Batch(ctx, 150, max_nnz)
+        for epoch in range(3):
+            for b in batches:
+                be.load_and_localize(b)
+                info = w.step(is_train=True, push_cnt=(epoch == 0))
+                bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+                bt.localize()
+                bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+                assert info["sent"] == info["received"] == [info["unique"]]
+                assert_close(be.pred(), bt.pred(), what="pred")
+        keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
+        va, la = tb.pull(keys)
+        vb, lb = be.table.pull(keys)
+        assert np.array_equal(la, lb)
+        assert_close(vb, va, rtol=2e-5, what="weights")
+        be.close()
+        for o in (bt, tb):
+            o.close()
+        ctx.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
