@@ -224,6 +224,14 @@ class Context:
                                   len(weights), _p(w_pos), _p(V_pos), npos, _p(pred), _p(grad)))
         return grad
 
+    def auc_times_n(self, label, pred):
+        """BinClassMetric::AUC (src/loss/bin_class_metric.h:35-56): AUC * n"""
+        label = np.ascontiguousarray(label, np.float32)
+        pred = np.ascontiguousarray(pred, np.float32)
+        o = C.c_float(0)
+        _ck(lib().dfh_auc_times_n(self.h, _p(label), _p(pred), len(pred), C.byref(o)))
+        return o.value
+
     def loss_evaluate(self, label, pred):
         label = np.ascontiguousarray(label, np.float32)
         pred = np.ascontiguousarray(pred, np.float32)

@@ -121,6 +121,8 @@ struct dfh_batch {
   // pipelining: prep-stream work -> ev_ready -> main-stream step -> ev_free -> next prep
   hipEvent_t ev_ready = nullptr, ev_free = nullptr;
   bool ready_pending = false, free_pending = false;
+  bool compute_auc = false;        // dfh_sgd_step also accumulates BinClassMetric::AUC per batch
+  uint32_t *d_auc_keys = nullptr, *d_auc_skeys = nullptr, *d_auc_lab = nullptr, *d_auc_slab = nullptr;
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
   bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
@@ -351,6 +353,21 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp) {
     hipLaunchKernelGGL((k_forward<L>), dim3(grid), dim3(256), 0, s, bv, src, k, kp);
   });
   if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+// BinClassMetric::AUC of the batch's predictions, accumulated into the progress block
+int launch_auc(dfh_batch* b) {
+  hipStream_t s = b->ctx->stream;
+  const uint32_t n = (uint32_t)b->nrows;
+  hipLaunchKernelGGL(k_auc_keys, dim3(grid_for_threads(n, b->ctx)), dim3(256), 0, s, b->d_pred, b->d_label, n, b->d_auc_keys,
+                     b->d_auc_lab);
+  size_t tb = b->temp_bytes;
+  // NB: d_temp is shared with the localizer's library-sort path, which only runs on the prep stream of
+  // ANOTHER batch object; within one batch the step follows its own preparation
+  DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, (size_t)n, 0, 32, s));
+  hipLaunchKernelGGL(k_auc_area, dim3(1), dim3(1024), 0, s, b->d_auc_slab, n, b->d_prog + PROG_AUC * PROG_SLOTS);
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
@@ -1025,7 +1042,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, N, 0, 64, c->stream);
   rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N, rocprim::plus<uint32_t>(), c->stream);
-  b->temp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+  size_t auc_bytes = 0;
+  rocprim::radix_sort_pairs(nullptr, auc_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                            (uint32_t*)nullptr, B, 0, 32, c->stream);
+  b->temp_bytes = std::max(std::max(sort_bytes, scan_bytes), auc_bytes) + 256;
 #define DFH_ALLOC(ptr, count, type)                                                        \
   do {                                                                                     \
     hipError_t e__ = hipMalloc(reinterpret_cast<void**>(&(ptr)), (count) * sizeof(type));  \
@@ -1074,12 +1094,16 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
   DFH_ALLOC(b->d_slope, B, float);
-  DFH_ALLOC(b->d_prog, 2 * PROG_SLOTS, double);
+  DFH_ALLOC(b->d_prog, 2 * PROG_SLOTS + 64, double);
+  DFH_ALLOC(b->d_auc_keys, B, uint32_t);
+  DFH_ALLOC(b->d_auc_skeys, B, uint32_t);
+  DFH_ALLOC(b->d_auc_lab, B, uint32_t);
+  DFH_ALLOC(b->d_auc_slab, B, uint32_t);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
   DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
   DFH_HIP(hipEventCreateWithFlags(&b->ev_free, hipEventDisableTiming));
-  DFH_HIP(hipMemsetAsync(b->d_prog, 0, 2 * PROG_SLOTS * sizeof(double), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
@@ -1096,7 +1120,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_pred,  b->d_slope, b->d_xv,
                   b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
-                  b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont};
+                  b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1235,6 +1259,10 @@ int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
   DFH_ARG(b && name, "NULL argument");
   if (std::string(name) == "force_radix_sort") {
     b->force_radix = value != 0;
+    return DFH_OK;
+  }
+  if (std::string(name) == "compute_auc") {
+    b->compute_auc = value != 0;
     return DFH_OK;
   }
   if (std::string(name) == "force_sort_fallback") {
@@ -1443,6 +1471,10 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   RowSrc src = table_src(t, b->d_urow);
   rc = launch_forward(b, src, k, kp);
   if (rc) return rc;
+  if (b->compute_auc) {
+    rc = launch_auc(b);
+    if (rc) return rc;
+  }
   if (is_train) {
     if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
     rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need);
@@ -1482,7 +1514,7 @@ int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_gr
 
 int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
   DFH_ARG(b && out, "NULL argument");
-  std::vector<double> p(2 * PROG_SLOTS);
+  std::vector<double> p(2 * PROG_SLOTS + 1);
   hipStream_t s = b->ctx->stream;
   {
     int rc = sync_all(b->ctx);
@@ -1497,11 +1529,11 @@ int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
   }
   out->loss = (float)loss;
   out->penalty = (float)pen;
-  out->auc = 0;
+  out->auc = (float)p[PROG_AUC * PROG_SLOTS];
   out->nnz_w = 0;
   out->nrows = b->nrows_seen;
   if (reset) {
-    DFH_HIP(hipMemsetAsync(b->d_prog, 0, 2 * PROG_SLOTS * sizeof(double), s));
+    DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), s));
     b->nrows_seen = 0;
   }
   return DFH_OK;
@@ -1516,9 +1548,38 @@ int dfh_batch_get_pred(dfh_batch* b, float* pred) {
 }
 
 int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n, float* auc_n) {
-  (void)c; (void)label; (void)pred; (void)n; (void)auc_n;
-  set_error("dfh_auc_times_n: not implemented yet");
-  return DFH_ERR_STATE;
+  DFH_ARG(c && auc_n, "NULL argument");
+  *auc_n = 1.0f;
+  if (n == 0) return DFH_OK;
+  DFH_ARG(label && pred && n < 0xFFFFFFF0ULL, "dfh_auc_times_n: bad argument");
+  DFH_HIP(hipSetDevice(c->device));
+  size_t tb = 0;
+  rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
+                            c->stream);
+  int rc = ensure_scratch(c, 2 * padded<float>(n) + 4 * padded<uint32_t>(n) + tb + 1024);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  float* d_l = cv.take<float>(n);
+  float* d_p = cv.take<float>(n);
+  uint32_t* k0 = cv.take<uint32_t>(n);
+  uint32_t* k1 = cv.take<uint32_t>(n);
+  uint32_t* l0 = cv.take<uint32_t>(n);
+  uint32_t* l1 = cv.take<uint32_t>(n);
+  double* d_o = cv.take<double>(1);
+  char* temp = cv.take<char>(tb + 16);
+  hipStream_t s = c->stream;
+  DFH_HIP(hipMemcpyAsync(d_l, label, n * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_p, pred, n * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemsetAsync(d_o, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_auc_keys, dim3(grid_for_threads(n, c)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, k0, l0);
+  DFH_HIP(rocprim::radix_sort_pairs(temp, tb, k0, k1, l0, l1, n, 0, 32, s));
+  hipLaunchKernelGGL(k_auc_area, dim3(1), dim3(1024), 0, s, l1, (uint32_t)n, d_o);
+  DFH_HIP(hipGetLastError());
+  double o = 0;
+  DFH_HIP(hipMemcpyAsync(&o, d_o, sizeof(double), hipMemcpyDeviceToHost, s));
+  DFH_HIP(hipStreamSynchronize(s));
+  *auc_n = (float)o;
+  return DFH_OK;
 }
 
 }  // extern "C"

@@ -282,7 +282,7 @@ __global__ void k_refrand_advance(TableView t, const uint32_t* __restrict__ tota
 constexpr int FWD_DEPTH = 8;
 // progress partials: prog[kind * PROG_SLOTS + blockIdx.x], summed on the host
 constexpr int PROG_SLOTS = 16384;
-constexpr int PROG_LOSS = 0, PROG_PENALTY = 1;
+constexpr int PROG_LOSS = 0, PROG_PENALTY = 1, PROG_AUC = 2;  // [PROG_AUC * PROG_SLOTS] is a single accumulator
 
 template <int L>
 __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k, int kp) {
@@ -1027,6 +1027,64 @@ __global__ void k_loc_counts(const uint32_t* __restrict__ col_ptr, const uint32_
   const uint32_t U = *d_U;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
     cnt[u] = (float)(col_ptr[u + 1] - col_ptr[u]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BinClassMetric::AUC (src/loss/bin_class_metric.h:35-56): sort by prediction,
+// area = sum over negatives of the positives ranked below them.
+// k_auc_keys: order-preserving u32 image of the float prediction + label bit.
+// k_auc_area: one block walks the sorted labels (n is a minibatch: ~1e4).
+// ---------------------------------------------------------------------------
+__global__ void k_auc_keys(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
+                           uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t b = __float_as_uint(pred[i]);
+    keys[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    pos[i] = label[i] > 0 ? 1u : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_auc_area(const uint32_t* __restrict__ sorted_pos, uint32_t n, double* __restrict__ out_slot) {
+  __shared__ uint32_t wsum[16];
+  __shared__ double dsum[16];
+  uint32_t carry = 0;  // positives seen so far (identical in every thread)
+  double area = 0.0;
+  for (uint32_t base = 0; base < n; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t p = i < n ? sorted_pos[i] : 0u;
+    uint32_t s = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(s, o, 64);
+      if ((int)(threadIdx.x & 63) >= o) s += y;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) woff += wsum[w];
+      tot += wsum[w];
+    }
+    if (i < n && p == 0) area += (double)(carry + woff + s);  // cum_tp at a negative
+    carry += tot;
+  }
+  area = wave_sum_d(area);
+  if ((threadIdx.x & 63) == 0) dsum[threadIdx.x >> 6] = area;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < 16; ++w) a += dsum[w];
+    const double tp = (double)carry, nn = (double)n;
+    double auc_n;
+    if (carry == 0 || carry == n) {
+      auc_n = 1.0;  // :51 (the reference returns 1, not n)
+    } else {
+      a /= tp * (nn - tp);
+      auc_n = (a < 0.5 ? 1.0 - a : a) * nn;
+    }
+    *out_slot += auc_n;
   }
 }
 

@@ -1,0 +1,278 @@
+/**
+ * sgd_learner.cc — see sgd_learner.h.  Reference: src/sgd/sgd_learner.cc.
+ */
+#include "./sgd_learner.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <thread>
+#include "./hip_fm_loss.h"
+#include "./host_localizer.h"
+#include "./libsvm_reader.h"
+#include "data/row_block.h"
+
+namespace difacto {
+
+DMLC_REGISTER_PARAMETER(SGDLearnerParam);
+DMLC_REGISTER_PARAMETER(SGDUpdaterParam);
+DMLC_REGISTER_PARAMETER(DeviceParam);
+DMLC_REGISTER_PARAMETER(FMLossParam);
+
+SGDLearner::~SGDLearner() {
+  for (auto& b : batch_)
+    if (b) dfh_batch_destroy(b);
+  delete loss_;
+  delete store_;
+}
+
+// reference: SGDLearner::Init, sgd_learner.cc:229-246 — every stage consumes
+// the keys it knows and hands the rest on; what is left is returned (and warned about by main)
+KWArgs SGDLearner::Init(const KWArgs& kwargs) {
+  auto remain = Learner::Init(kwargs);
+  remain = param_.InitAllowUnknown(remain);
+  CHECK(param_.data_format == "libsvm") << "data_format " << param_.data_format
+                                         << " is not supported by this build (libsvm text only)";
+  auto updater = new DeviceSGDUpdater();
+  remain = updater->Init(remain);
+  remain.push_back(std::make_pair("V_dim", std::to_string(updater->param().V_dim)));
+  store_ = Store::Create();
+  store_->SetUpdater(std::shared_ptr<Updater>(updater));
+  remain = store_->Init(remain);
+  loss_ = Loss::Create(param_.loss, blk_nthreads_);
+  remain = loss_->Init(remain);
+  if (param_.model_in.size()) LoadModel();
+  return remain;
+}
+
+// reference: SGDLearner::RunScheduler, sgd_learner.cc:31-68
+void SGDLearner::RunScheduler() {
+  real_t pre_loss = 0, pre_val_auc = 0;
+  for (int k = 0; k < param_.max_num_epochs; ++k) {
+    sgd::Progress train_prog;
+    LOG(INFO) << "Start epoch " << k;
+    RunEpoch(k, sgd::Job::kTraining, &train_prog);
+    LOG(INFO) << " - Training: " << train_prog.TextString();
+    sgd::Progress val_prog;
+    if (param_.data_val.size()) {
+      RunEpoch(k, sgd::Job::kValidation, &val_prog);
+      LOG(INFO) << " - Validation: " << val_prog.TextString();
+    }
+    for (const auto& cb : epoch_end_callback_) cb(k, train_prog, val_prog);
+
+    real_t eps = std::fabs(train_prog.loss - pre_loss) / pre_loss;
+    if (eps < param_.stop_rel_objv) {
+      LOG(INFO) << "Change of loss [" << eps << "] < stop_rel_objv [" << param_.stop_rel_objv << "]";
+      break;
+    }
+    if (val_prog.auc > 0) {
+      eps = (val_prog.auc - pre_val_auc) / val_prog.nrows;
+      if (eps < param_.stop_val_auc) {
+        LOG(INFO) << "Change of validation AUC [" << eps << "] < stop_val_auc [" << param_.stop_val_auc << "]";
+        break;
+      }
+    }
+    if (k + 1 >= param_.max_num_epochs) LOG(INFO) << "Reach maximal number of epochs";
+    pre_loss = train_prog.loss;
+    pre_val_auc = val_prog.auc;
+  }
+  if (param_.model_out.size()) SaveModel();
+}
+
+// reference: SGDLearner::RunEpoch, sgd_learner.cc:70-94
+void SGDLearner::RunEpoch(int epoch, int job_type, sgd::Progress* prog) {
+  tracker_->SetMonitor([prog](int node_id, const std::string& rets) { prog->Merge(rets); });
+  const int n = store_->NumWorkers() * param_.num_jobs_per_epoch;
+  std::vector<std::pair<int, std::string>> jobs(n);
+  for (int i = 0; i < n; ++i) {
+    jobs[i].first = 0;
+    sgd::Job job;
+    job.type = job_type;
+    job.epoch = epoch;
+    job.num_parts = n;
+    job.part_idx = i;
+    job.SerializeToString(&jobs[i].second);
+  }
+  tracker_->Issue(jobs);
+  while (tracker_->NumRemains()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+}
+
+// reference: SGDLearner::Process, sgd_learner.h:42-53
+void SGDLearner::Process(const std::string& args, std::string* rets) {
+  sgd::Progress prog;
+  sgd::Job job;
+  job.ParseFromString(args);
+  if (job.type == sgd::Job::kTraining || job.type == sgd::Job::kValidation) IterateData(job, &prog);
+  prog.SerializeToString(rets);
+}
+
+void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
+  if (GetUpdater()->device_param().device_path == "literal") {
+    IterateDataLiteral(job, prog);
+  } else {
+    IterateDataFused(job, prog);
+  }
+}
+
+// ---- the fused worker loop: sgd_learner.cc:129-227 on the device
+void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) {
+  const bool train = job.type == sgd::Job::kTraining;
+  const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
+  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
+                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  dfh_ctx* ctx = DeviceContext::Get();
+  dfh_table* table = GetUpdater()->table();
+  DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
+  auto ensure = [&](size_t rows, size_t nnz) {
+    if (batch_[0] && rows <= batch_rows_ && nnz <= batch_nnz_) return;
+    for (auto& b : batch_) {
+      if (b) {
+        dfh_progress p;
+        DFH_CALL(dfh_batch_progress(b, &p, 1));  // never pending here: drained at the end of every job
+        dfh_batch_destroy(b);
+        b = nullptr;
+      }
+    }
+    batch_rows_ = std::max(rows, batch_rows_);
+    batch_nnz_ = std::max(nnz * 2, batch_nnz_);
+    for (auto& b : batch_) {
+      DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &b));
+      DFH_CALL(dfh_batch_set_option(b, "compute_auc", 1));  // sgd_learner.cc:153-155
+    }
+  };
+  // prepare batch t+1 (H2D copy, Localizer, key lookup) while batch t trains
+  auto prepare = [&](int slot) {
+    const auto& blk = reader.Value();
+    // a growing batch would need a new buffer while the other slot may be in flight: drain first
+    if (!batch_[0] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
+      DFH_CALL(dfh_ctx_sync(ctx));
+      sgd::Progress keep;
+      for (auto& b : batch_) {
+        if (!b) continue;
+        dfh_progress p;
+        DFH_CALL(dfh_batch_progress(b, &p, 1));
+        keep.loss += p.loss; keep.penalty += p.penalty; keep.auc += p.auc; keep.nrows += p.nrows;
+      }
+      progress->Merge(keep);
+      ensure(blk.size, blk.offset[blk.size] - blk.offset[0]);
+    }
+    dfh_batch* b = batch_[slot];
+    DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
+    DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
+    DFH_CALL(dfh_batch_lookup(table, b));
+  };
+  bool have = reader.Next();
+  int i = 0;
+  if (have) prepare(0);
+  while (have) {
+    const int cur = i & 1;
+    const bool have_next = reader.Next();
+    if (have_next) prepare(cur ^ 1);
+    DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+    have = have_next;
+    ++i;
+  }
+  for (auto& b : batch_) {
+    if (!b) continue;
+    dfh_progress p;
+    DFH_CALL(dfh_batch_progress(b, &p, 1));
+    sgd::Progress q;
+    q.loss = p.loss; q.penalty = p.penalty; q.auc = p.auc; q.nrows = p.nrows;
+    progress->Merge(q);
+  }
+  uint64_t nkeys;
+  DFH_CALL(dfh_table_size(table, &nkeys));  // surfaces a full table as an error
+}
+
+// reference: SGDLearner::GetPos, sgd_learner.cc:113-127
+void SGDLearner::GetPos(const SArray<int>& len, SArray<int>* w_pos, SArray<int>* V_pos) {
+  const size_t n = len.size();
+  w_pos->resize(n);
+  V_pos->resize(n);
+  int p = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int l = len[i];
+    (*w_pos)[i] = l == 0 ? -1 : p;
+    (*V_pos)[i] = l > 1 ? p + 1 : -1;
+    p += l;
+  }
+}
+
+// reference: SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273
+real_t SGDLearner::EvaluatePenalty(const SArray<real_t>& weights, const SArray<int>& w_pos, const SArray<int>& V_pos) {
+  double objv = 0;
+  const auto& param = GetUpdater()->param();
+  if (w_pos.size()) {
+    for (int p : w_pos) {
+      if (p == -1) continue;
+      const double w = weights[p];
+      objv += param.l1 * std::fabs(w) + .5 * param.l2 * w * w;
+    }
+    for (int p : V_pos) {
+      if (p == -1) continue;
+      for (int i = 0; i < param.V_dim; ++i) {
+        const double V = weights[p + i];
+        objv += .5 * param.V_l2 * V * V;
+      }
+    }
+  } else {
+    for (auto wf : weights) {
+      const double w = wf;
+      objv += param.l1 * std::fabs(w) + .5 * param.l2 * w * w;
+    }
+  }
+  return static_cast<real_t>(objv);
+}
+
+// ---- the literal worker loop: the reference's sequence of interface calls
+void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress) {
+  const bool train = job.type == sgd::Job::kTraining;
+  const bool push_cnt = train && job.epoch == 0;
+  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
+                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  while (reader.Next()) {
+    dmlc::data::RowBlockContainer<unsigned> data;
+    auto feaids = std::make_shared<std::vector<feaid_t>>();
+    auto feacnt = std::make_shared<std::vector<real_t>>();
+    Localizer lc(-1, blk_nthreads_);
+    lc.Compact(reader.Value(), &data, feaids.get(), push_cnt ? feacnt.get() : nullptr);
+    SArray<feaid_t> keys(feaids);
+    if (push_cnt) store_->Wait(store_->Push(keys, Store::kFeaCount, SArray<real_t>(feacnt), {}));
+    SArray<real_t> values;
+    SArray<int> lengths;
+    store_->Wait(store_->Pull(keys, Store::kWeight, &values, &lengths));
+    auto blk = data.GetBlock();
+    progress->nrows += blk.size;
+    SArray<real_t> pred(blk.size);
+    SArray<int> w_pos, V_pos;
+    GetPos(lengths, &w_pos, &V_pos);
+    std::vector<SArray<char>> inputs = {SArray<char>(values), SArray<char>(w_pos), SArray<char>(V_pos)};
+    loss_->Predict(blk, inputs, &pred);
+    progress->loss += loss_->Evaluate(blk.label, pred);
+    progress->penalty += EvaluatePenalty(values, w_pos, V_pos);
+    float auc_n = 0;
+    DFH_CALL(dfh_auc_times_n(DeviceContext::Get(), blk.label, pred.data(), pred.size(), &auc_n));
+    progress->auc += auc_n;
+    if (train) {
+      SArray<real_t> grads(values.size());
+      inputs.push_back(SArray<char>(pred));
+      loss_->CalcGrad(blk, inputs, &grads);
+      store_->Wait(store_->Push(keys, Store::kGradient, grads, lengths));
+    }
+  }
+}
+
+void SGDLearner::SaveModel() {
+  std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(param_.model_out.c_str(), "w"));
+  GetUpdater()->Save(true, fo.get());
+  LOG(INFO) << "model saved to " << param_.model_out;
+}
+
+void SGDLearner::LoadModel() {
+  std::unique_ptr<dmlc::Stream> fi(dmlc::Stream::Create(param_.model_in.c_str(), "r"));
+  bool has_aux = false;
+  GetUpdater()->Load(fi.get(), &has_aux);
+  LOG(INFO) << "model loaded from " << param_.model_in << (has_aux ? " (with optimiser state)" : "");
+}
+
+}  // namespace difacto

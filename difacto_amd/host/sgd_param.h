@@ -1,0 +1,85 @@
+/**
+ * sgd_param.h — configuration of the SGD learner and its updater: the same keys,
+ * types, ranges and defaults as the reference's src/sgd/sgd_param.h, so that
+ * its .conf files work unchanged; plus the keys of the device build.
+ */
+#ifndef DIFACTO_HOST_SGD_PARAM_H_
+#define DIFACTO_HOST_SGD_PARAM_H_
+#include <string>
+#include "difacto/base.h"
+#include "dmlc/parameter.h"
+
+namespace difacto {
+
+/*! \brief reference: SGDLearnerParam, sgd_param.h:12-64 */
+struct SGDLearnerParam : public dmlc::Parameter<SGDLearnerParam> {
+  std::string data_in;       // training data: a file (required)
+  std::string data_val;      // optional validation data
+  std::string data_format;   // "libsvm"
+  std::string model_out;     // where to save the model after training
+  std::string model_in;      // model to start from
+  std::string loss;          // "fm" (default) or "logit"
+  int max_num_epochs;
+  int batch_size;            // required
+  int shuffle;               // shuffle buffer = batch_size * shuffle rows
+  float neg_sampling;        // keep probability of a negative example
+  int num_jobs_per_epoch;    // file parts per worker and epoch
+  real_t stop_rel_objv;      // stop if |objv - prev| / prev < this
+  real_t stop_val_auc;       // stop if validation AUC gain < this
+  DMLC_DECLARE_PARAMETER(SGDLearnerParam) {
+    DMLC_DECLARE_FIELD(data_format).set_default("libsvm");
+    DMLC_DECLARE_FIELD(data_in);
+    DMLC_DECLARE_FIELD(data_val).set_default("");
+    DMLC_DECLARE_FIELD(model_out).set_default("");
+    DMLC_DECLARE_FIELD(model_in).set_default("");
+    DMLC_DECLARE_FIELD(loss).set_default("fm");
+    DMLC_DECLARE_FIELD(max_num_epochs).set_default(20);
+    DMLC_DECLARE_FIELD(num_jobs_per_epoch).set_default(10);
+    DMLC_DECLARE_FIELD(batch_size);
+    DMLC_DECLARE_FIELD(shuffle).set_default(10);
+    DMLC_DECLARE_FIELD(neg_sampling).set_default(1);
+    DMLC_DECLARE_FIELD(stop_rel_objv).set_default(1e-5);
+    DMLC_DECLARE_FIELD(stop_val_auc).set_default(1e-5);
+  }
+};
+
+/*! \brief reference: SGDUpdaterParam, sgd_param.h:66-107 */
+struct SGDUpdaterParam : public dmlc::Parameter<SGDUpdaterParam> {
+  float l1, l2, V_l2;
+  float lr, lr_beta, V_lr, V_lr_beta;
+  float V_init_scale;
+  int V_dim;
+  int V_threshold;
+  unsigned int seed;
+  DMLC_DECLARE_PARAMETER(SGDUpdaterParam) {
+    DMLC_DECLARE_FIELD(l1).set_range(0, 1e10).set_default(1);
+    DMLC_DECLARE_FIELD(l2).set_range(0, 1e10).set_default(0);
+    DMLC_DECLARE_FIELD(V_l2).set_range(0, 1e10).set_default(.01);
+    DMLC_DECLARE_FIELD(lr).set_range(0, 10).set_default(.01);
+    DMLC_DECLARE_FIELD(lr_beta).set_range(0, 1e10).set_default(1);
+    DMLC_DECLARE_FIELD(V_lr).set_range(0, 1e10).set_default(.01);
+    DMLC_DECLARE_FIELD(V_lr_beta).set_range(0, 10).set_default(1);
+    DMLC_DECLARE_FIELD(V_init_scale).set_range(0, 10).set_default(.01);
+    DMLC_DECLARE_FIELD(V_threshold).set_default(10);
+    DMLC_DECLARE_FIELD(V_dim);
+    DMLC_DECLARE_FIELD(seed).set_default(0);
+  }
+};
+
+/*! \brief keys that exist only in the device build (all optional) */
+struct DeviceParam : public dmlc::Parameter<DeviceParam> {
+  /*! \brief rows of the model table in HBM (the reference's hash map grows without bound) */
+  unsigned long long table_capacity;
+  /*! \brief "hash": order-independent V init; "refrand": the reference's rand_r chain, bit for bit */
+  std::string V_init;
+  /*! \brief "fused": the whole worker step on device; "literal": Store/Loss calls with host arrays */
+  std::string device_path;
+  DMLC_DECLARE_PARAMETER(DeviceParam) {
+    DMLC_DECLARE_FIELD(table_capacity).set_default(1ULL << 22);
+    DMLC_DECLARE_FIELD(V_init).set_default("refrand");
+    DMLC_DECLARE_FIELD(device_path).set_default("fused");
+  }
+};
+
+}  // namespace difacto
+#endif  // DIFACTO_HOST_SGD_PARAM_H_

@@ -168,7 +168,9 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
 int dfh_localize(dfh_batch* b, uint64_t max_index);
 /* tuning / test switches: "force_radix_sort" = 1 makes dfh_localize take its
  * large-batch path (library LSD radix sort) whatever the batch size;
- * "force_sort_fallback" = 1 sorts every bucket through the oversize-bucket path */
+ * "force_sort_fallback" = 1 sorts every bucket through the oversize-bucket path;
+ * "compute_auc" = 1 makes dfh_sgd_step accumulate BinClassMetric::AUC (x nrows) of every
+ * batch into dfh_progress.auc, as src/sgd/sgd_learner.cc:153-155 does */
 int dfh_batch_set_option(dfh_batch* b, const char* name, int value);
 
 /* resolve the batch's unique keys to table rows ahead of dfh_sgd_step (inserting

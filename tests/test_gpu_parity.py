@@ -497,3 +497,35 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 10000])
+def test_auc_vs_oracle(capi, ctx, oracle, n):
+    """BinClassMetric::AUC on device (ties in pred are ordered arbitrarily by the
+    reference's std::sort, so the comparison uses tie-free predictions)"""
+    rng = np.random.default_rng(n)
+    pred = np.unique((rng.normal(size=n) * 3).astype(np.float32))
+    rng.shuffle(pred)
+    lab = np.where(rng.random(len(pred)) < 0.3, 1.0, 0.0).astype(np.float32)
+    assert ctx.auc_times_n(lab, pred) == pytest.approx(oracle.auc_times_n(lab, pred), rel=1e-6)
+    ones = np.ones(len(pred), np.float32)
+    assert ctx.auc_times_n(ones, pred) == 1.0 and ctx.auc_times_n(0 * ones, pred) == 1.0  # bin_class_metric.h:51
+
+
+def test_fused_step_auc(capi, ctx, oracle):
+    rng = np.random.default_rng(4)
+    b = random_batch(rng, 300, 2000, 20, empty_rows=False)
+    kw = dict(l1=0.01, l2=0.0, lr=0.2, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.3, seed=1)
+    tb = capi.Table(ctx, 1 << 14, V_dim=4, **kw)
+    bt = capi.Batch(ctx, 300, int(b["offset"][-1]))
+    bt.set_option("compute_auc", 1)
+    for it in range(3):
+        bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+        bt.localize()
+        bt.sgd_step(tb, is_train=True, push_cnt=(it == 0))
+        pred = bt.pred()
+        prog = bt.progress(reset=True)
+        if len(np.unique(pred)) == len(pred):
+            assert prog.auc == pytest.approx(oracle.auc_times_n(b["label"], pred), rel=1e-6)
+    tb.close()
+    bt.close()

@@ -1,0 +1,61 @@
+"""The C++ host side (include/difacto/*.h over the C ABI): builds on CPU, runs on the GPU box."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "golden", "rcv1_100.libsvm")
+
+
+@pytest.fixture(scope="module")
+def built():
+    from difacto_amd import build
+    build.build_hip()
+    build.build_host()
+    return os.path.join(ROOT, "build")
+
+
+def test_host_binaries_build(built):
+    for exe in ("difacto", "difacto_host_tests"):
+        assert os.access(os.path.join(built, exe), os.X_OK)
+    # the CLI prints usage without arguments, like the reference (src/main.cc:39-42)
+    r = subprocess.run([os.path.join(built, "difacto")], capture_output=True, text=True, timeout=60)
+    assert "usage: difacto key1=val1" in r.stderr
+
+
+def test_cli_fails_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([os.path.join(built, "difacto"), "data_in=" + DATA, "batch_size=100", "V_dim=0"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "dfh_ctx_create" in r.stderr  # no CPU fallback
+
+
+@pytest.mark.gpu
+def test_host_interface_tests_on_gpu(built):
+    """FMLoss.NoV/HasV, Localizer.*, SGDLearner.Basic (fused + literal), Store/model I/O through the C++ interfaces"""
+    r = subprocess.run([os.path.join(built, "difacto_host_tests"), DATA], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "ALL HOST TESTS PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_trains_from_conf(built, tmp_path):
+    model = os.path.join(tmp_path, "model.bin")
+    r = subprocess.run([os.path.join(built, "difacto"), "argfile=" + os.path.join(ROOT, "example", "rcv1_fm.conf"),
+                        "model_out=" + model, "bogus_key=1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    print(r.stderr[-3000:])
+    assert r.returncode == 0
+    assert "Start epoch 0" in r.stderr and "Validation: loss = " in r.stderr and "AUC = " in r.stderr
+    assert "Unrecognized keyword argument" in r.stderr and "bogus_key" in r.stderr  # src/main.cc:25-31
+    losses = [float(l.split("loss = ")[1].split(",")[0]) for l in r.stderr.splitlines() if "Training: loss" in l]
+    assert len(losses) >= 2 and losses[-1] < losses[0]
+    assert os.path.getsize(model) > 100
+    # resume from the saved model: the first epoch starts where the last one ended
+    r2 = subprocess.run([os.path.join(built, "difacto"), "argfile=" + os.path.join(ROOT, "example", "rcv1_fm.conf"),
+                         "model_in=" + model, "max_num_epochs=1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0 and "model loaded from" in r2.stderr
+    first = [float(l.split("loss = ")[1].split(",")[0]) for l in r2.stderr.splitlines() if "Training: loss" in l][0]
+    assert first < losses[0]

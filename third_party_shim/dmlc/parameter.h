@@ -18,6 +18,7 @@
 #ifndef SHIM_DMLC_PARAMETER_H_
 #define SHIM_DMLC_PARAMETER_H_
 #include <cstddef>
+#include <limits>
 #include <map>
 #include <memory>
 #include <sstream>
