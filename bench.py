@@ -44,6 +44,21 @@ HYPER = dict(l1=0.0, l2=0.0, V_l2=0.01, lr=0.01, lr_beta=1.0, V_lr=0.01, V_lr_be
              V_threshold=0, seed=0)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/r01_pmc_hbm_traffic.json,
+    collected with `rocprofv3 --pmc ... -- python bench.py` on the default workload), or None"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        for name, v in d.items():
+            if name.replace(" ", "") == kernel.replace(" ", ""):
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(batches, V_dim, nbatches):
     """the reference CPU path (oracle/_ref: the reference's own Localizer/SGDUpdater/FMLoss
     compiled here) or the C port, timed on this box's host cores over `nbatches` batches"""
@@ -177,7 +192,7 @@ def main():
         fwd_ms = timing["forward"][0] / timing["forward"][1]
         achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", kernel="k_forward", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBPS, traffic=None,
+                        frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<%d>" % max(1, (k + 3) // 4 * 4 // 4)),
                         algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms)
     nb = args.cpu_batches
     cpu = None
