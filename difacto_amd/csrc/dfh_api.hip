@@ -26,6 +26,9 @@ struct dfh_ctx {
   // batch t+1 is prepared while batch t trains; == stream unless pipelining is on
   hipStream_t prep = nullptr;
   hipStream_t prep_own = nullptr;
+  // auxiliary stream: the long-segment half of the backward pass runs beside the short-segment half
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pipeline = false;
   // monotonic scratch for the literal (host-pointer) calls
   void* scratch = nullptr;
@@ -103,7 +106,7 @@ struct dfh_batch {
   size_t temp_bytes = 0;
   // sample-sort localizer workspace
   uint64_t *d_spl_key = nullptr, *d_first_key = nullptr, *d_last_key = nullptr, *d_smp_key = nullptr;
-  uint32_t *d_smp_pos = nullptr, *d_spl_pos = nullptr, *d_packed = nullptr, *d_hist = nullptr, *d_run_off = nullptr, *d_bstart = nullptr,
+  uint32_t *d_smp_rank = nullptr, *d_smp_pos = nullptr, *d_spl_pos = nullptr, *d_packed = nullptr, *d_hist = nullptr, *d_run_off = nullptr, *d_bstart = nullptr,
            *d_nheads = nullptr, *d_bpos = nullptr, *d_btotal = nullptr, *d_ubase = nullptr, *d_cont = nullptr;
   size_t max_tiles = 0;
   // localized view
@@ -113,6 +116,7 @@ struct dfh_batch {
   float* d_s_val = nullptr;
   uint32_t* d_U = nullptr;
   // step workspace
+  uint32_t* d_nnz_row = nullptr;
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
   float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
   size_t xv_floats = 0;
@@ -164,6 +168,7 @@ int main_end(dfh_batch* b) {
 }
 int sync_all(dfh_ctx* c) {
   if (c->prep != c->stream) DFH_HIP(hipStreamSynchronize(c->prep));
+  DFH_HIP(hipStreamSynchronize(c->aux));
   DFH_HIP(hipStreamSynchronize(c->stream));
   return DFH_OK;
 }
@@ -305,6 +310,7 @@ BatchView batch_view(const dfh_batch* b) {
   v.s_row = b->d_s_row;
   v.s_val = b->has_value ? b->d_s_val : nullptr;
   v.urow = b->d_urow;
+  v.nnz_row = nullptr;
   v.pred = b->d_pred;
   v.slope = b->d_slope;
   v.xv = b->d_xv;
@@ -341,8 +347,9 @@ int dispatch_L(int kp, F&& f) {
   return DFH_OK;
 }
 
-int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp) {
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_rows = false) {
   BatchView bv = batch_view(b);
+  if (use_nnz_rows) bv.nnz_row = b->d_nnz_row;
   // one wave per example, all resident at once where possible: the kernel is
   // bound by the latency of its dependent gathers, not by launch size
   int grid = (int)std::max<size_t>(1, std::min<size_t>((b->nrows + 3) / 4, PROG_SLOTS));
@@ -378,17 +385,30 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
-  // U lives on the device; nnz bounds it.  One launch, three roles (see k_backward):
-  // 256 keys per hot block, 4*BWD_MIDW keys per mid block, 4*(64/L) keys per small block.
+  dfh_ctx* c = b->ctx;
+  // U lives on the device; nnz bounds it.  Two launches that touch disjoint keys and run side by side:
+  //   k_backward_big   (aux stream)  256 keys scanned per hot block, 4*BWD_MIDW keys per mid block
+  //   k_backward_small (main stream) 4*(64/L) keys per block and iteration, grid-stride
   const size_t nb_hot = std::min<size_t>((b->nnz + 255) / 256, 2048);
   const size_t nb_mid = std::min<size_t>((b->nnz + 4 * BWD_MIDW - 1) / (4 * BWD_MIDW), 8192);
-  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, 32768);
-  TimeScope ts(b->ctx, DFH_K_BACKWARD);
+  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, (size_t)c->num_cu * 8 * 2);
+  // debugging aid: DFH_BWD_ROLES=<bitmask> runs only some roles (1 hot, 2 mid, 4 small); results are then wrong
+  static const uint32_t role_mask = getenv("DFH_BWD_ROLES") ? (uint32_t)atoi(getenv("DFH_BWD_ROLES")) : 7u;
+  static const uint32_t dbg_small = getenv("DFH_BWD_DBG") ? (uint32_t)atoi(getenv("DFH_BWD_DBG")) : 0u;
+  TimeScope ts(c, DFH_K_BACKWARD);
+  DFH_HIP(hipEventRecord(c->ev_fork, s));
+  DFH_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
-    hipLaunchKernelGGL((k_backward<LL, FUSED>), dim3((unsigned)(nb_hot + nb_mid + nb_small)), dim3(256), 0, s, bv, src, tv,
-                       grads, gstride, k, kp, need, (uint32_t)nb_hot, (uint32_t)nb_mid);
+    if (role_mask & 3u)
+      hipLaunchKernelGGL((k_backward_big<LL, FUSED>), dim3((unsigned)(nb_hot + nb_mid)), dim3(256), 0, c->aux, bv, src, tv,
+                         grads, gstride, k, kp, need, (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask);
+    if (role_mask & 4u)
+      hipLaunchKernelGGL((k_backward_small<LL, FUSED>), dim3((unsigned)nb_small), dim3(256), 0, s, bv, src, tv, grads,
+                         gstride, k, kp, need, dbg_small);
   });
+  DFH_HIP(hipEventRecord(c->ev_join, c->aux));
+  DFH_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   if (rc) return rc;
   DFH_HIP(hipGetLastError());
   return DFH_OK;
@@ -446,6 +466,13 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
     c->own_stream = true;
   }
   c->prep = c->stream;
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_error("dfh_ctx_create: cannot create auxiliary stream/events");
+    delete c;
+    return DFH_ERR_HIP;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   *out = c;
@@ -462,6 +489,12 @@ int dfh_ctx_destroy(dfh_ctx* c) {
     hipEventDestroy(sp.b);
   }
   for (auto e : c->pool) hipEventDestroy(e);
+  if (c->aux) {
+    hipStreamSynchronize(c->aux);
+    hipStreamDestroy(c->aux);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
+  }
   if (c->prep_own) {
     hipStreamSynchronize(c->prep_own);
     hipStreamDestroy(c->prep_own);
@@ -1070,6 +1103,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_spl_key, SS_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_smp_key, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint64_t);
   DFH_ALLOC(b->d_smp_pos, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_smp_rank, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint32_t);
   DFH_ALLOC(b->d_first_key, SS_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_last_key, SS_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_spl_pos, SS_MAX_BUCKETS, uint32_t);
@@ -1090,6 +1124,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_s_val, N, float);
   DFH_ALLOC(b->d_U, 64, uint32_t);
   DFH_ALLOC(b->d_urow, N, uint32_t);
+  DFH_ALLOC(b->d_nnz_row, N, uint32_t);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1118,8 +1153,8 @@ int dfh_batch_destroy(dfh_batch* b) {
   if (b->ev_free) hipEventDestroy(b->ev_free);
   void* ptrs[] = {b->d_raw,   b->d_offset, b->d_value,   b->d_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
-                  b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_pred,  b->d_slope, b->d_xv,
-                  b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
+                  b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_nnz_row, b->d_pred,  b->d_slope, b->d_xv,
+                  b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_smp_rank, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
                   b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -1209,6 +1244,7 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     v.force_global = b->force_sort_fallback ? 1 : 0;
     v.smp_key = b->d_smp_key;
     v.smp_pos = b->d_smp_pos;
+    v.smp_rank = b->d_smp_rank;
     v.spl_key = b->d_spl_key;
     v.spl_pos = b->d_spl_pos;
     v.packed = b->d_packed;
@@ -1228,7 +1264,12 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     v.last_key = b->d_last_key;
     v.nheads = b->d_nheads;
     const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
-    hipLaunchKernelGGL(k_ss_splitters, dim3((S + 15) / 16), dim3(256), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+    hipLaunchKernelGGL(k_ss_sample, dim3(grid_for_threads(std::max<size_t>(b->nrows, S), c)), dim3(256), 0, s, v,
+                       (uint32_t)b->nrows, b->d_offset, b->d_pos);
+    {
+      const uint32_t nt = (S + 255) / 256;
+      hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
+    }
     hipLaunchKernelGGL(k_ss_count, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
     hipLaunchKernelGGL(k_ss_scan, dim3((v.P + SS_SCAN_BUCKETS - 1) / SS_SCAN_BUCKETS), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_ss_scatter, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
@@ -1287,6 +1328,8 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
     TimeScope ts(c, DFH_K_LOOKUP, c->prep);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, c->prep, t->v, b->d_feaids, b->d_U, 0u,
                        b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0);
+    hipLaunchKernelGGL(k_nnz_rows, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, c->prep, b->d_index, b->d_urow,
+                       (uint32_t)b->nnz, b->d_nnz_row);
   }
   DFH_HIP(hipGetLastError());
   b->looked_up = t;
@@ -1469,7 +1512,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     if (rc) return rc;
   }
   RowSrc src = table_src(t, b->d_urow);
-  rc = launch_forward(b, src, k, kp);
+  rc = launch_forward(b, src, k, kp, pre);
   if (rc) return rc;
   if (b->compute_auc) {
     rc = launch_auc(b);

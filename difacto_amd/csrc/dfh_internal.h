@@ -82,6 +82,7 @@ struct BatchView {
   const uint32_t* s_row;    // [nnz] row of each occurrence, key order (ties: row order)
   const float* s_val;       // [nnz] value of each occurrence, key order, or NULL
   uint32_t* urow;           // [U] table row of each unique key (filled by lookup)
+  const uint32_t* nnz_row;  // [nnz] urow[index[j]] when precomposed (dfh_batch_lookup), else NULL
   float* pred;              // [nrows]
   float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
   float* xv;                // [nrows x kp]

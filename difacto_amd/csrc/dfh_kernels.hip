@@ -168,6 +168,12 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
   }
 }
 
+constexpr uint32_t BWD_SMALL = 8;
+constexpr uint32_t BWD_MID = 256;
+constexpr int BWD_MIDW = 16;
+constexpr int BWD_DEPTH = 4;
+constexpr int BWD_SMALL_DEPTH = 2;
+
 // ---------------------------------------------------------------------------
 // k_lookup: one thread per unique key.  urow[u] = row of feaids[u] (inserted as
 // a zero row if unseen: sgd_updater.cc:44).  With cnt != NULL it also applies
@@ -307,9 +313,13 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
       float x = 0.f;
       uint32_t hv = 0;
       if (valid) {
-        uint32_t u = b.index[j];
         x = b.value ? b.value[j] : 1.0f;
-        r = src.urow ? src.urow[u] : u;
+        if (b.nnz_row) {
+          r = b.nnz_row[j];  // urow[index[j]] composed ahead of time on the preparation stream
+        } else {
+          const uint32_t u = b.index[j];
+          r = src.urow ? src.urow[u] : u;
+        }
         const float* wp = src.wbase + (size_t)r * src.wstride;
         // {w, has_V} are adjacent: one 8 B load
         float2 wf = *reinterpret_cast<const float2*>(wp);
@@ -362,7 +372,9 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
       const float y = b.label[i] > 0 ? 1.0f : -1.0f;
       b.pred[i] = pred;
       b.slope[i] = -y / (1.0f + expf(y * pred));            // fm_loss.h:160
-      loss_acc += log(1.0 + exp((double)(-y * pred)));       // loss.h:63
+      // log(1 + exp(-y pred)) (loss.h:63) in its stable fp32 form; the batch sum is kept in double
+      const float m = -y * pred;
+      loss_acc += (double)(fmaxf(m, 0.f) + log1pf(expf(-fabsf(m))));
     }
   }
   // the batch's logloss: one private slot per block (same-address atomics
@@ -399,10 +411,6 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
 // row, occurrence list) before consuming any; V rows are read speculatively
 // (a row without V holds zeros, in the table and in packed rows alike).
 // ---------------------------------------------------------------------------
-constexpr uint32_t BWD_SMALL = 8;
-constexpr uint32_t BWD_MID = 256;
-constexpr int BWD_MIDW = 16;
-constexpr int BWD_DEPTH = 4;
 
 struct KeySums {
   float gw;    // sum p x
@@ -578,10 +586,9 @@ __device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_
 }
 
 template <int L, bool FUSED>
-__global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
-                                                  size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
-                                                  uint32_t nb_hot, uint32_t nb_mid) {
-  constexpr int G = 64 / L;
+__global__ void __launch_bounds__(256) k_backward_big(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
+                                                      size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
+                                                      uint32_t nb_hot, uint32_t nb_mid, uint32_t role_mask) {
   constexpr int NW = 4;
   __shared__ float part[NW][2 + 256];  // hot role, per wave: gw, xxp, gv[kp <= 256]
   __shared__ uint32_t hot_u[256];
@@ -595,7 +602,9 @@ __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, Table
   double pen_acc = 0.0;
 
   if (blockIdx.x < nb_hot) {
-    // ---- hot role
+    // ---- hot role: 256 keys scanned per block; keys with cnt > BWD_MID are taken one at a
+    // time by the whole block (4 waves, partials combined in LDS in a fixed order)
+    if (!(role_mask & 1u)) return;
     for (uint32_t u0 = blockIdx.x * 256; u0 < U; u0 += nb_hot * 256) {
       if (threadIdx.x == 0) hot_n = 0;
       __syncthreads();
@@ -635,8 +644,10 @@ __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, Table
       }
       __syncthreads();
     }
-  } else if (blockIdx.x < nb_hot + nb_mid) {
-    // ---- mid role
+  } else {
+    // ---- mid role: each wave scans BWD_MIDW keys and takes those with
+    // BWD_SMALL < cnt <= BWD_MID one after the other, whole wave per key
+    if (!(role_mask & 2u)) return;
     const uint32_t wave = (blockIdx.x - nb_hot) * NW + w;
     const uint32_t nwaves = nb_mid * NW;
     for (uint32_t u0 = wave * BWD_MIDW; u0 < U; u0 += nwaves * BWD_MIDW) {
@@ -658,23 +669,45 @@ __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, Table
         if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
       }
     }
-  } else {
-    // ---- small role
-    const uint32_t wave = (blockIdx.x - nb_hot - nb_mid) * NW + w;
-    const uint32_t nwaves = (gridDim.x - nb_hot - nb_mid) * NW;
+  }
+  if (FUSED) flush_penalty(b, pen_acc);
+}
+
+// ---- small segments (cnt <= BWD_SMALL): one L-lane group per key, G keys per wave,
+// occurrences summed serially in row order (the reference's own order).  Its own
+// launch so that it gets its own register budget (8 waves/SIMD): the kernel is a
+// chain of dependent random accesses and only occupancy hides them.  Runs
+// concurrently with k_backward_big (other stream): the two touch disjoint keys.
+template <int L, bool FUSED>
+__global__ void __launch_bounds__(256, 8) k_backward_small(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
+                                                           size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t dbg) {
+  constexpr int G = 64 / L;
+  constexpr int NW = 4;
+  const int lane = lane_id();
+  const int grp = lane / L;
+  const int sub = lane % L;
+  const bool sub_ok = sub * 4 < kp;
+  const int w = threadIdx.x >> 6;
+  const uint32_t U = *b.d_U;
+  double pen_acc = 0.0;
+  {
+    const uint32_t wave = blockIdx.x * NW + w;
+    const uint32_t nwaves = gridDim.x * NW;
     for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
-      const uint32_t u = u0 + grp;
-      if (u >= U) continue;
-      const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
-      if (end - beg > BWD_SMALL) continue;  // taken by the mid / hot roles
+      // no branch before the loads: the segment bounds, the row id and then the row itself are
+      // requested for every lane group (keys left to the mid / hot roles waste one speculative read)
+      const uint32_t u = min(u0 + grp, U - 1);
+      const uint32_t beg = b.col_ptr[u], end_all = b.col_ptr[u + 1];
       const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+      const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL;
+      const uint32_t end = mine ? end_all : beg;
       KeySums s;
       s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (uint32_t j0 = beg; j0 < end; j0 += BWD_DEPTH) {
-        float4 a[BWD_DEPTH];
-        float xs[BWD_DEPTH], ps[BWD_DEPTH];
+      for (uint32_t j0 = beg; j0 < ((dbg & 2u) ? beg : end); j0 += BWD_SMALL_DEPTH) {
+        float4 a[BWD_SMALL_DEPTH];
+        float xs[BWD_SMALL_DEPTH], ps[BWD_SMALL_DEPTH];
 #pragma unroll
-        for (int q = 0; q < BWD_DEPTH; ++q) {
+        for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {
           const uint32_t j = j0 + q;
           const bool ok = j < end;
           const uint32_t row = ok ? b.s_row[j] : 0;
@@ -683,7 +716,7 @@ __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, Table
           a[q] = (ok && k > 0 && sub_ok) ? ld4(b.xv + (size_t)row * kp + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int q = 0; q < BWD_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
+        for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
           const float pp = ps[q], xx = xs[q];
           s.gw += pp * xx;
           s.xxp += pp * (xx * xx);
@@ -691,7 +724,11 @@ __global__ void __launch_bounds__(256) k_backward(BatchView b, RowSrc src, Table
           s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
         }
       }
-      finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+      if (dbg & 1u) {
+        pen_acc += s.gv.x + s.gw + kr.v.x + kr.acc.y + kr.z;
+      } else if (mine) {
+        finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+      }
     }
   }
   if (FUSED) flush_penalty(b, pen_acc);
@@ -972,6 +1009,13 @@ __global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* _
 }
 
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+
+// nnz_row[j] = urow[index[j]]: the table row of every nnz, so that the forward kernel's gather
+// chain is offset -> nnz_row -> {w, V} instead of offset -> index -> urow -> w -> V
+__global__ void k_nnz_rows(const uint32_t* __restrict__ index, const uint32_t* __restrict__ urow, uint32_t nnz,
+                           uint32_t* __restrict__ nnz_row) {
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += gridDim.x * blockDim.x) nnz_row[j] = urow[index[j]];
+}
 
 // bounds[d] = first unique key of the batch owned by shard d (keys ascending; owner = key / span)
 __global__ void k_key_ranges(const uint64_t* __restrict__ feaids, const uint32_t* __restrict__ d_U, int nparts,

@@ -9,9 +9,9 @@
 // launches, ~110 us measured with rocPRIM).  Instead, one partition pass and
 // one local pass:
 //
-//   k_ss_splitters  strided samples of the composite (key, pos), rank of every
-//                   sample among all samples (LDS, whole chip): every
-//                   SS_OVERSAMPLE-th becomes a splitter; also the row of every nnz
+//   k_ss_sample     jittered samples of the composite (key, pos); also the row of every nnz
+//   k_ss_rank       rank of every sample among all samples, tiled over the whole
+//                   chip: every SS_OVERSAMPLE-th becomes a splitter
 //   k_ss_count      per tile: bucket of every pair (binary search over the
 //                   splitters in LDS) + LDS histogram; the LDS atomic's return
 //                   value is the pair's rank inside (tile, bucket)
@@ -46,7 +46,7 @@ constexpr int SS_LDS_CAP = 2048;      // pairs a bucket may hold to be sorted in
 constexpr int SS_TILE = 4096;         // pairs per block in count / scatter
 constexpr int SS_TILE_THREADS = 512;
 constexpr int SS_PER_THREAD = SS_TILE / SS_TILE_THREADS;
-constexpr int SS_SORT_THREADS = 256;
+constexpr int SS_SORT_THREADS = 512;
 constexpr int SS_SCAN_BUCKETS = 64;   // buckets per block in k_ss_scan
 
 struct SSView {
@@ -56,8 +56,9 @@ struct SSView {
   int P;                  // buckets
   int ntiles;
   int force_global;       // tests: sort every bucket through the global-memory path
-  uint64_t* smp_key;      // [P * SS_OVERSAMPLE] strided samples of the composite (key, pos)
+  uint64_t* smp_key;      // [P * SS_OVERSAMPLE] jittered samples of the composite (key, pos)
   uint32_t* smp_pos;
+  uint32_t* smp_rank;     // [P * SS_OVERSAMPLE] sorted position of every sample
   uint64_t* spl_key;      // [P] splitters (bucket b holds composites in [spl[b-1], spl[b]) )
   uint32_t* spl_pos;
   uint32_t* packed;       // [N] bucket << 16 | rank-in-(tile,bucket)
@@ -118,67 +119,53 @@ __device__ __forceinline__ uint32_t ss_sample_pos(uint32_t t, uint32_t stride, u
   return min(t * stride + j, n - 1);
 }
 
-// ---- splitters by parallel ranking: the composites are distinct, so the rank
-// of a sample (number of smaller samples) is its sorted position.  Every block
-// stages all samples in LDS and ranks 16 of them, 16 lanes per sample each
-// scanning a 1/16 slice.
-__global__ void __launch_bounds__(256) k_ss_splitters(SSView v, uint32_t nrows, const uint32_t* __restrict__ offset,
-                                                      uint32_t* __restrict__ rowid) {
-  __shared__ uint64_t sk[SS_MAX_BUCKETS * SS_OVERSAMPLE];
-  __shared__ uint32_t sp[SS_MAX_BUCKETS * SS_OVERSAMPLE];
+// ---- sampling: the S = SS_OVERSAMPLE * P jittered samples of the composite (key, pos);
+// side job, independent of the sort until k_ss_emit: rowid[pos] = row of nnz position pos
+__global__ void __launch_bounds__(256) k_ss_sample(SSView v, uint32_t nrows, const uint32_t* __restrict__ offset,
+                                                   uint32_t* __restrict__ rowid) {
   const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
   // jittered stratified sampling: sample t is a hashed position inside its own stratum
   // [t*stride, (t+1)*stride) (distinct by construction).  A plain stride aliases with the
   // row structure — 39 features per row, stride 63: only 13 of the 39 slots were ever
   // sampled and whole slots collapsed into one bucket.
   const uint32_t stride = max(1u, v.n / S);
-  // the strided samples of the composite (key, pos), straight from the raw ids
-  for (uint32_t t0 = threadIdx.x; t0 < S; t0 += blockDim.x * 8) {  // 8 independent loads in flight
-    uint64_t k[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint32_t t = t0 + u * blockDim.x;
-      k[u] = t < S ? v.raw[ss_sample_pos(t, stride, v.n)] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint32_t t = t0 + u * blockDim.x;
-      if (t < S) {
-        sk[t] = make_key(k[u], v.max_index);
-        sp[t] = ss_sample_pos(t, stride, v.n);
-      }
-    }
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  for (uint32_t t = tid; t < S; t += nthreads) {
+    const uint32_t i = ss_sample_pos(t, stride, v.n);
+    v.smp_key[t] = make_key(v.raw[i], v.max_index);
+    v.smp_pos[t] = i;
+    v.smp_rank[t] = 0;
   }
-  // side job, independent of the sort until k_ss_emit: rowid[pos] = row of nnz position pos
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+  for (uint32_t r = tid; r < nrows; r += nthreads) {
     const uint32_t e = offset[r + 1];
     for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
   }
+}
+
+// ---- ranking of the samples, tiled over the whole chip: block (i, j) compares 256 "row"
+// samples (one per thread, in registers) with 256 "column" samples (LDS broadcast reads) and
+// adds the partial ranks with one atomic per sample.  The composites are distinct, so the
+// final rank of a sample is its sorted position; every SS_OVERSAMPLE-th becomes a splitter
+// (picked up by k_ss_count).  (One block sorting the samples costs 50-60 us: a single CU is
+// issue-bound on it.)
+__global__ void __launch_bounds__(256) k_ss_rank(SSView v) {
+  __shared__ uint64_t ck[256];
+  __shared__ uint32_t cp[256];
+  const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
+  const uint32_t ntile = (S + 255) / 256;
+  const uint32_t ti = blockIdx.x / ntile, tj = blockIdx.x % ntile;
+  const uint32_t col = tj * 256 + threadIdx.x;
+  ck[threadIdx.x] = col < S ? v.smp_key[col] : ~0ULL;
+  cp[threadIdx.x] = col < S ? v.smp_pos[col] : ~0u;
+  const uint32_t row = ti * 256 + threadIdx.x;
+  const uint64_t mk = row < S ? v.smp_key[row] : 0;
+  const uint32_t mp = row < S ? v.smp_pos[row] : 0;
   __syncthreads();
-  const uint32_t smp = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const uint32_t q = threadIdx.x & 15;
+  const uint32_t lim = min(256u, S - tj * 256);
   uint32_t rank = 0;
-  uint64_t mk = 0;
-  uint32_t mp = 0;
-  if (smp < S) {
-    mk = sk[smp];
-    mp = sp[smp];
-#pragma unroll 4
-    for (uint32_t j = q; j < S; j += 16) rank += comp_less(sk[j], sp[j], mk, mp) ? 1u : 0u;
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) rank += __shfl_xor(rank, o, 64);
-  if (smp < S && q == 0) {
-    // bucket b = composites in [spl[b-1], spl[b]); spl[P-1] = +inf
-    if (rank > 0 && rank % SS_OVERSAMPLE == 0) {
-      v.spl_key[rank / SS_OVERSAMPLE - 1] = mk;
-      v.spl_pos[rank / SS_OVERSAMPLE - 1] = mp;
-    }
-    if (smp == 0) {
-      v.spl_key[v.P - 1] = ~0ULL;
-      v.spl_pos[v.P - 1] = ~0u;
-    }
-  }
+#pragma unroll 8
+  for (uint32_t j = 0; j < lim; ++j) rank += comp_less(ck[j], cp[j], mk, mp) ? 1u : 0u;
+  if (row < S && rank) atomicAdd(&v.smp_rank[row], rank);
 }
 
 // ---- count: bucket + rank-in-(tile,bucket) of every pair; per-tile histogram
@@ -187,10 +174,30 @@ __global__ void __launch_bounds__(SS_TILE_THREADS) k_ss_count(SSView v) {
   __shared__ uint32_t sp[SS_MAX_BUCKETS];
   __shared__ uint32_t hist[SS_MAX_BUCKETS];
   const int P = v.P;
-  for (int b = threadIdx.x; b < P; b += blockDim.x) {
-    sk[b] = v.spl_key[b];
-    sp[b] = v.spl_pos[b];
-    hist[b] = 0;
+  for (int b = threadIdx.x; b < P; b += blockDim.x) hist[b] = 0;
+  // splitters: sample with rank r = m * SS_OVERSAMPLE (m >= 1) is splitter m-1; spl[P-1] = +inf
+  {
+    const uint32_t S = (uint32_t)P * SS_OVERSAMPLE;
+    for (uint32_t t0 = threadIdx.x; t0 < S; t0 += blockDim.x * 8) {  // 8 independent rank loads in flight
+      uint32_t r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t t = t0 + u * blockDim.x;
+        r[u] = t < S ? v.smp_rank[t] : 1u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t t = t0 + u * blockDim.x;
+        if (r[u] > 0 && r[u] % SS_OVERSAMPLE == 0) {
+          sk[r[u] / SS_OVERSAMPLE - 1] = v.smp_key[t];
+          sp[r[u] / SS_OVERSAMPLE - 1] = v.smp_pos[t];
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
+      sk[P - 1] = ~0ULL;
+      sp[P - 1] = ~0u;
+    }
   }
   const uint32_t base = blockIdx.x * SS_TILE;
   uint64_t key[SS_PER_THREAD];
