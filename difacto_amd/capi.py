@@ -60,6 +60,15 @@ def lib():
         raise FileNotFoundError(
             "%s is missing: build it with `python -m difacto_amd.build` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # Load order matters when PyTorch is used in the same process (multi-GPU driver, bench.py):
+    # torch bundles its own libamdhip64; if ours (linked to the system ROCm runtime of the same
+    # soname) is mapped first, torch later brings up a second HIP runtime and sees no GPU.
+    # Importing torch first makes both share one runtime.
+    if os.environ.get("DIFACTO_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32, u64, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_float
     PP = C.POINTER

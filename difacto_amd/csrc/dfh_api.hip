@@ -391,7 +391,8 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   //   k_backward_small (main stream) 4*(64/L) keys per block and iteration, grid-stride
   const size_t nb_hot = std::min<size_t>((b->nnz + 255) / 256, 2048);
   const size_t nb_mid = std::min<size_t>((b->nnz + 4 * BWD_MIDW - 1) / (4 * BWD_MIDW), 8192);
-  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, (size_t)c->num_cu * 8 * 2);
+  static const size_t small_mult = getenv("DFH_BWD_SMALL_BLOCKS_PER_CU") ? (size_t)atoi(getenv("DFH_BWD_SMALL_BLOCKS_PER_CU")) : 16;
+  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, (size_t)c->num_cu * small_mult);
   // debugging aid: DFH_BWD_ROLES=<bitmask> runs only some roles (1 hot, 2 mid, 4 small); results are then wrong
   static const uint32_t role_mask = getenv("DFH_BWD_ROLES") ? (uint32_t)atoi(getenv("DFH_BWD_ROLES")) : 7u;
   static const uint32_t dbg_small = getenv("DFH_BWD_DBG") ? (uint32_t)atoi(getenv("DFH_BWD_DBG")) : 0u;
@@ -514,7 +515,15 @@ int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
   int rc = sync_all(c);
   if (rc) return rc;
   if (enable) {
-    if (!c->prep_own) DFH_HIP(hipStreamCreateWithFlags(&c->prep_own, hipStreamNonBlocking));
+    if (!c->prep_own) {
+      // highest priority: the preparation kernels are small and latency-bound; behind the wide
+      // forward/backward launches of the main stream their blocks would wait for free slots
+      int lo = 0, hi = 0;
+      DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const char* pr = getenv("DFH_PREP_PRIORITY");
+      int prio = pr ? atoi(pr) : hi;
+      DFH_HIP(hipStreamCreateWithPriority(&c->prep_own, hipStreamNonBlocking, prio));
+    }
     c->prep = c->prep_own;
   } else {
     c->prep = c->stream;

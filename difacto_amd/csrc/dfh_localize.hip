@@ -280,20 +280,28 @@ __global__ void __launch_bounds__(SS_TILE_THREADS) k_ss_scatter(SSView v) {
   __shared__ uint32_t off[SS_MAX_BUCKETS];
   __shared__ uint32_t wsum[SS_TILE_THREADS / 64];
   const int P = v.P;
-  // exclusive scan of btotal[0..P): two consecutive buckets per thread
+  // exclusive scan of btotal[0..P): BPT consecutive buckets per thread
   {
-    const int b0 = threadIdx.x * 2;
-    const uint32_t t0 = b0 < P ? v.btotal[b0] : 0u;
-    const uint32_t t1 = b0 + 1 < P ? v.btotal[b0 + 1] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<SS_TILE_THREADS / 64>(t0 + t1, wsum, &total);
-    if (b0 < P) off[b0] = ex;
-    if (b0 + 1 < P) off[b0 + 1] = ex + t0;
-    if (blockIdx.x == 0) {
-      if (b0 < P) v.bstart[b0] = ex;
-      if (b0 + 1 < P) v.bstart[b0 + 1] = ex + t0;
-      if (threadIdx.x == 0) v.bstart[P] = total;
+    constexpr int BPT = SS_MAX_BUCKETS / SS_TILE_THREADS;
+    const int b0 = threadIdx.x * BPT;
+    uint32_t tt[BPT];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      tt[q] = b0 + q < P ? v.btotal[b0 + q] : 0u;
+      sum += tt[q];
     }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<SS_TILE_THREADS / 64>(sum, wsum, &total);
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      if (b0 + q < P) {
+        off[b0 + q] = ex;
+        if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
+      }
+      ex += tt[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
   }
   const uint32_t base = blockIdx.x * SS_TILE;
   uint64_t raw[SS_PER_THREAD];

@@ -461,11 +461,11 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
     import torch
     import torch.distributed as dist
     from difacto_amd import sharded
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29700 + os.getpid() % 200), rank=0,
+                                world_size=1)
     try:
         rng = np.random.default_rng(55)
         kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
@@ -527,5 +527,40 @@ def test_fused_step_auc(capi, ctx, oracle):
         prog = bt.progress(reset=True)
         if len(np.unique(pred)) == len(pred):
             assert prog.auc == pytest.approx(oracle.auc_times_n(b["label"], pred), rel=1e-6)
+    tb.close()
+    bt.close()
+
+
+def test_config_c2_rcv1_vdim8(capi, ctx, oracle, rcv1):
+    """BASELINE.json configs[1]: rcv1 rows, FM V_dim=8, batch 100 (example/rcv1_sgd.conf shape),
+    per-example logits and per-key gradients against the CPU path at rtol 1e-5, plus the
+    training trajectory of the fused step (reference's rand_r V init)"""
+    from oracle import bindings as ob
+    kw = dict(l1=0.1, l2=0.0, lr=0.1, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.01, seed=0)
+    so = oracle.store_create(init_mode=ob.INIT_REFRAND, V_dim=8, **kw)
+    tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_REFRAND, **kw)
+    bt = capi.Batch(ctx, 100, 9648)
+    loc = oracle.localize(rcv1["offset"], rcv1["index"])
+    for epoch in range(6):
+        # literal check on the model of this epoch: same pulled weights -> logits and gradients
+        vals, lens = so.pull(loc["feaids"])
+        wp, vp = oracle.get_pos(lens)
+        po = oracle.fm_predict(8, loc["offset"], loc["index"], rcv1["value"], vals, wp, vp)
+        go = oracle.fm_calcgrad(8, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], vals, po, wp, vp)
+        pg = ctx.fm_predict(8, loc["offset"], loc["index"], rcv1["value"], vals, wp, vp)
+        gg = ctx.fm_calcgrad(8, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], vals, po, wp, vp)
+        assert_close(pg, po, what="C2 logits epoch %d" % epoch)
+        assert_close(gg, go, scale=np.abs(go).max(), what="C2 gradients epoch %d" % epoch)
+        # one fused training step on the device vs the oracle's
+        bt.load_host(rcv1["offset"], rcv1["index"], rcv1["value"], rcv1["label"])
+        bt.localize()
+        bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+        ps, _ = so.sgd_step(loc["offset"], loc["index"], rcv1["value"], rcv1["label"], loc["feaids"],
+                            feacnt=loc["feacnt"] if epoch == 0 else None, is_train=True)
+        assert_close(bt.pred(), ps, rtol=5e-5, what="C2 fused logits epoch %d" % epoch)
+    vg, lg = tb.pull(loc["feaids"])
+    vo, lo = so.pull(loc["feaids"])
+    assert np.array_equal(lg, lo) and np.any(lo > 1)
+    assert_close(vg, vo, rtol=2e-4, what="C2 final model")
     tb.close()
     bt.close()
