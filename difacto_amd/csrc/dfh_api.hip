@@ -354,10 +354,18 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_
   // bound by the latency of its dependent gathers, not by launch size
   int grid = (int)std::max<size_t>(1, std::min<size_t>((b->nrows + 3) / 4, PROG_SLOTS));
   hipStream_t s = b->ctx->stream;
+  static const int fwd_depth = getenv("DFH_FWD_DEPTH") ? atoi(getenv("DFH_FWD_DEPTH")) : 5;
+  static const int fwd_blocks = getenv("DFH_FWD_BLOCKS") ? atoi(getenv("DFH_FWD_BLOCKS")) : 0;
+  if (fwd_blocks > 0) grid = std::min(grid, fwd_blocks);
   TimeScope ts(b->ctx, DFH_K_FORWARD);
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
-    hipLaunchKernelGGL((k_forward<L>), dim3(grid), dim3(256), 0, s, bv, src, k, kp);
+    switch (fwd_depth) {
+      case 4: hipLaunchKernelGGL((k_forward<L, 4>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
+      case 10: hipLaunchKernelGGL((k_forward<L, 10>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
+      case 8: hipLaunchKernelGGL((k_forward<L, 8>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
+      default: hipLaunchKernelGGL((k_forward<L, 5>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
+    }
   });
   if (rc) return rc;
   DFH_HIP(hipGetLastError());

@@ -285,12 +285,11 @@ __global__ void k_refrand_advance(TableView t, const uint32_t* __restrict__ tota
 //
 //   pred_i = sum_j x_ij w_j + 1/2 sum_d [ (sum_j x_ij V_jd)^2 - sum_j x_ij^2 V_jd^2 ]
 // ---------------------------------------------------------------------------
-constexpr int FWD_DEPTH = 8;
 // progress partials: prog[kind * PROG_SLOTS + blockIdx.x], summed on the host
 constexpr int PROG_SLOTS = 16384;
 constexpr int PROG_LOSS = 0, PROG_PENALTY = 1, PROG_AUC = 2;  // [PROG_AUC * PROG_SLOTS] is a single accumulator
 
-template <int L>
+template <int L, int FWD_DEPTH>
 __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k, int kp) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
@@ -469,11 +468,12 @@ __device__ __forceinline__ void finish_key(const BatchView& b, const TableView& 
     return;
   }
   // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
-  if (kr.has_v && sub_ok) pen_acc += 0.5 * (double)t.p.V_l2 * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w);
+  // per-lane partials in fp32 (a handful of terms each), widened when the block flushes
+  if (kr.has_v && sub_ok) pen_acc += (double)(0.5f * t.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
   RowHdr* hp = t.hdr + kr.r;
   if (sub == 0) {
     const float w_old = kr.w_old;
-    pen_acc += (double)t.p.l1 * fabs((double)w_old) + 0.5 * (double)t.p.l2 * (double)w_old * (double)w_old;
+    pen_acc += (double)(t.p.l1 * fabsf(w_old) + 0.5f * t.p.l2 * w_old * w_old);
     // SGDUpdater::Update(kGradient) for this key (sgd_updater.cc:86-95)
     float sqrt_g = kr.sqrt_g, z = kr.z;
     const float w_new = ftrl_update_w(s.gw, w_old, sqrt_g, z, t.p);
