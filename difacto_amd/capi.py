@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
 ]
 K_COUNT = 7
 
@@ -102,6 +102,7 @@ def lib():
     L.dfh_batch_destroy.argtypes = [vp]
     L.dfh_batch_load_host.argtypes = [vp, sz, vp, vp, vp, vp]
     L.dfh_batch_load_device.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.dfh_batch_attach_device.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.dfh_localize.argtypes = [vp, u64]
     L.dfh_batch_load_localized_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz]
     L.dfh_batch_get_localized.argtypes = [vp, PP(sz), vp, vp, vp]
@@ -345,6 +346,10 @@ class Batch:
 
     def load_device(self, nrows, nnz, d_offset, d_index, d_value, d_label):
         _ck(lib().dfh_batch_load_device(self.h, nrows, nnz, _dp(d_offset), _dp(d_index), _dp(d_value), _dp(d_label)))
+
+    def attach_device(self, nrows, nnz, d_offset, d_index, d_value, d_label):
+        """zero-copy: read the caller's device arrays in place"""
+        _ck(lib().dfh_batch_attach_device(self.h, nrows, nnz, _dp(d_offset), _dp(d_index), _dp(d_value), _dp(d_label)))
 
     def localize(self, max_index=U64MAX):
         """Localizer::Compact on device"""

@@ -94,11 +94,15 @@ struct dfh_batch {
   bool has_value = false;
   bool has_cnt = false;
   bool localized = false;
-  // raw input
+  // raw input: own buffers (o_*), or caller-owned device memory attached without a copy
   uint64_t* d_raw = nullptr;
   uint32_t* d_offset = nullptr;
   float* d_value = nullptr;
   float* d_label = nullptr;
+  uint64_t* o_raw = nullptr;
+  uint32_t* o_offset = nullptr;
+  float* o_value = nullptr;
+  float* o_label = nullptr;
   // localizer workspace
   uint64_t *d_keys = nullptr, *d_skeys = nullptr;
   uint32_t *d_pos = nullptr, *d_spos = nullptr, *d_head = nullptr, *d_uid = nullptr;
@@ -1105,10 +1109,14 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
       return DFH_ERR_HIP;                                                                  \
     }                                                                                      \
   } while (0)
-  DFH_ALLOC(b->d_raw, N, uint64_t);
-  DFH_ALLOC(b->d_offset, B + 1, uint32_t);
-  DFH_ALLOC(b->d_value, N, float);
-  DFH_ALLOC(b->d_label, B, float);
+  DFH_ALLOC(b->o_raw, N, uint64_t);
+  DFH_ALLOC(b->o_offset, B + 1, uint32_t);
+  DFH_ALLOC(b->o_value, N, float);
+  DFH_ALLOC(b->o_label, B, float);
+  b->d_raw = b->o_raw;
+  b->d_offset = b->o_offset;
+  b->d_value = b->o_value;
+  b->d_label = b->o_label;
   DFH_ALLOC(b->d_keys, N, uint64_t);
   DFH_ALLOC(b->d_skeys, N, uint64_t);
   DFH_ALLOC(b->d_pos, N, uint32_t);
@@ -1168,7 +1176,7 @@ int dfh_batch_destroy(dfh_batch* b) {
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
   if (b->ev_free) hipEventDestroy(b->ev_free);
-  void* ptrs[] = {b->d_raw,   b->d_offset, b->d_value,   b->d_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
+  void* ptrs[] = {b->o_raw,   b->o_offset, b->o_value,   b->o_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_nnz_row, b->d_pred,  b->d_slope, b->d_xv,
                   b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_smp_rank, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
@@ -1193,6 +1201,7 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   DFH_HIP(hipSetDevice(b->ctx->device));
   rc = prep_begin(b);
   if (rc) return rc;
+  b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, index + base, nnz * 8, hipMemcpyHostToDevice, s));
   if (nnz && value) DFH_HIP(hipMemcpyAsync(b->d_value, value + base, nnz * 4, hipMemcpyHostToDevice, s));
@@ -1216,10 +1225,32 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
     int rc = prep_begin(b);
     if (rc) return rc;
   }
+  b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   DFH_HIP(hipMemcpyAsync(b->d_offset, d_offset, (nrows + 1) * 4, hipMemcpyDeviceToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, d_index, nnz * 8, hipMemcpyDeviceToDevice, s));
   if (nnz && d_value) DFH_HIP(hipMemcpyAsync(b->d_value, d_value, nnz * 4, hipMemcpyDeviceToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_label, d_label, nrows * 4, hipMemcpyDeviceToDevice, s));
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = d_value != nullptr;
+  b->has_cnt = false;
+  b->localized = false;
+  b->looked_up = nullptr;
+  return DFH_OK;
+}
+
+int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t* d_offset, const uint64_t* d_index,
+                            const float* d_value, const float* d_label) {
+  DFH_ARG(b && d_offset && d_label && (nnz == 0 || d_index), "dfh_batch_attach_device: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows && nnz <= b->max_nnz, "dfh_batch_attach_device: shape out of range");
+  {
+    int rc = prep_begin(b);  // a queued step may still read the previously attached memory; nothing of ours is overwritten
+    if (rc) return rc;
+  }
+  b->d_offset = const_cast<uint32_t*>(d_offset);
+  b->d_raw = const_cast<uint64_t*>(d_index);
+  b->d_value = d_value ? const_cast<float*>(d_value) : b->o_value;
+  b->d_label = const_cast<float*>(d_label);
   b->nrows = nrows;
   b->nnz = nnz;
   b->has_value = d_value != nullptr;
@@ -1388,6 +1419,7 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   DFH_HIP(hipSetDevice(b->ctx->device));
   rc = prep_begin(b);
   if (rc) return rc;
+  b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   b->looked_up = nullptr;
   uint32_t U32 = (uint32_t)U;
   DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));

@@ -161,6 +161,11 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
 int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t* d_offset,
                           const uint64_t* d_index, const float* d_value, const float* d_label);
 
+/* same, WITHOUT a copy: the batch reads the caller's device arrays in place; they must stay
+ * valid and unchanged until the work queued on this batch has finished */
+int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t* d_offset,
+                            const uint64_t* d_index, const float* d_value, const float* d_label);
+
 /* Localizer::Compact on device (src/data/localizer.h:41-51, localizer.cc:11-103):
  * keys = ReverseBytes(id % max_index), sorted unique keys + counts + compact
  * index per nnz — bit-exact with the reference — plus the key-ordered view the

@@ -564,3 +564,31 @@ def test_config_c2_rcv1_vdim8(capi, ctx, oracle, rcv1):
     assert_close(vg, vo, rtol=2e-4, what="C2 final model")
     tb.close()
     bt.close()
+
+
+def test_attach_device_zero_copy(capi, ctx, oracle):
+    """dfh_batch_attach_device: same results as the copying loader"""
+    rng = np.random.default_rng(12)
+    b = random_batch(rng, 300, 2 ** 64 - 1, 20, binary=True, empty_rows=False)
+    nnz = int(b["offset"][-1])
+    d_off = capi.DeviceBuffer.from_numpy(ctx, b["offset"].astype(np.uint32))
+    d_idx = capi.DeviceBuffer.from_numpy(ctx, b["index"])
+    d_lab = capi.DeviceBuffer.from_numpy(ctx, b["label"])
+    kw = dict(l1=0.01, l2=0.0, lr=0.2, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.3, seed=1)
+    res = []
+    for mode in ("copy", "attach"):
+        tb = capi.Table(ctx, 1 << 14, V_dim=4, **kw)
+        bt = capi.Batch(ctx, 300, nnz)
+        for it in range(3):
+            if mode == "copy":
+                bt.load_device(300, nnz, d_off.ptr, d_idx.ptr, None, d_lab.ptr)
+            else:
+                bt.attach_device(300, nnz, d_off.ptr, d_idx.ptr, None, d_lab.ptr)
+            bt.localize()
+            bt.sgd_step(tb, is_train=True, push_cnt=(it == 0))
+        res.append((bt.pred(), bt.get_localized()["feaids"].copy()))
+        tb.close()
+        bt.close()
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], oracle.localize(b["offset"], b["index"])["feaids"])
