@@ -416,9 +416,22 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
     if (role_mask & 3u)
       hipLaunchKernelGGL((k_backward_big<LL, FUSED>), dim3((unsigned)(nb_hot + nb_mid)), dim3(256), 0, c->aux, bv, src, tv,
                          grads, gstride, k, kp, need, (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask);
-    if (role_mask & 4u)
-      hipLaunchKernelGGL((k_backward_small<LL, FUSED>), dim3((unsigned)nb_small), dim3(256), 0, s, bv, src, tv, grads,
-                         gstride, k, kp, need, dbg_small);
+    if (role_mask & 4u) {
+      if (FUSED && src.urow && !(dbg_small & 4u)) {
+        SmallArgs sa;
+        sa.d_U = bv.d_U; sa.col_ptr = bv.col_ptr; sa.urow = src.urow; sa.s_row = bv.s_row; sa.s_val = bv.s_val;
+        sa.slope = bv.slope; sa.xv = bv.xv; sa.feaids = bv.feaids; sa.hdr = tv.hdr; sa.va = tv.va; sa.need_init = need;
+        sa.prog = bv.prog; sa.k = k; sa.kp = kp; sa.p = tv.p;
+        if (kp == 4 * LL) {
+          hipLaunchKernelGGL((k_update_small<LL, true>), dim3((unsigned)nb_small), dim3(256), 0, s, sa);
+        } else {
+          hipLaunchKernelGGL((k_update_small<LL, false>), dim3((unsigned)nb_small), dim3(256), 0, s, sa);
+        }
+      } else {
+        hipLaunchKernelGGL((k_backward_small<LL, FUSED>), dim3((unsigned)nb_small), dim3(256), 0, s, bv, src, tv, grads,
+                           gstride, k, kp, need, dbg_small);
+      }
+    }
   });
   DFH_HIP(hipEventRecord(c->ev_join, c->aux));
   DFH_HIP(hipStreamWaitEvent(s, c->ev_join, 0));

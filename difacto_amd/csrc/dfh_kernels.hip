@@ -44,6 +44,17 @@ __device__ __forceinline__ float in_group_sum(float v) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming variants (nt): model rows are touched once per step; keeping them out of the L2's
+// way leaves the batch-sized arrays (XV, slopes, occurrence lists) resident there
+typedef float nt_float4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  nt_float4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_float4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  nt_float4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_float4*>(p));
+}
 
 // The sharding-independent V init: must match oracle/difacto_oracle.c:orc_hash_init_value
 __device__ __forceinline__ float hash_init_value(uint64_t key, int j, unsigned seed, float scale) {
@@ -116,13 +127,17 @@ __device__ __forceinline__ float ftrl_update_w(float gw, float w, float& sqrt_g,
   return (z > 0 ? z - l1 : z + l1) / eta; // :119
 }
 
-// SGDUpdater::UpdateV — AdaGrad, one coordinate, src/sgd/sgd_updater.cc:129-138
+// SGDUpdater::UpdateV — AdaGrad, one coordinate, src/sgd/sgd_updater.cc:129-138.
+// The square root and the reciprocal use the hardware approximations (<= 1 ulp each) instead
+// of the IEEE-rounded sequences: the update is 4*V_dim of these per key and the kernel is
+// issue-bound; the step differs from the reference's by ~1e-7 relative (inside the rtol 1e-5
+// band; the FTRL update of w, whose |z| <= l1 test is threshold-sensitive, stays exact).
 __device__ __forceinline__ void adagrad_update_v(float gv, float& v, float& acc, const dfh_updater_param& P) {
   float g = gv + P.V_l2 * v;           // :132
   float cg = acc;                      // :133
-  float ncg = sqrtf(cg * cg + g * g);  // :134
+  float ncg = __builtin_amdgcn_sqrtf(cg * cg + g * g);  // :134
   acc = ncg;
-  float eta = P.V_lr / (ncg + P.V_lr_beta);  // :135
+  float eta = P.V_lr * __builtin_amdgcn_rcpf(ncg + P.V_lr_beta);  // :135
   v -= eta * g;                        // :136
 }
 
@@ -159,7 +174,8 @@ __device__ __forceinline__ uint32_t lcg_jump(uint32_t x, uint64_t n) {
   return ra * x + rc;
 }
 
-// write V (hash init) + zero accumulators for row r; one thread does the row
+// write V (hash init) + zero accumulators for row r; one thread does the row.  Rare (once per key)
+// (once per key).
 __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, uint64_t key) {
   float* va = t.va + (size_t)r * (2 * t.kp);
   for (int j = 0; j < t.kp; ++j) {
@@ -437,8 +453,8 @@ __device__ __forceinline__ KeyRow load_key_row(const RowSrc& src, const TableVie
   // independent loads, issued back to back
   float4 h0 = ld4(wp);  // table: {w, has_V, sqrt_g, z}; packed: {w, has_V, 0, 0}
   if (k > 0 && sub_ok) {
-    kr.v = ld4(src.vbase + (size_t)kr.r * src.vstride + sub * 4);
-    if (FUSED) kr.acc = ld4(t.va + (size_t)kr.r * (2 * kp) + kp + sub * 4);
+    kr.v = FUSED ? ld4_nt(src.vbase + (size_t)kr.r * src.vstride + sub * 4) : ld4(src.vbase + (size_t)kr.r * src.vstride + sub * 4);
+    if (FUSED) kr.acc = ld4_nt(t.va + (size_t)kr.r * (2 * kp) + kp + sub * 4);
   }
   if (FUSED) kr.fea_cnt = t.hdr[kr.r].fea_cnt;
   kr.w_old = h0.x;
@@ -504,8 +520,8 @@ __device__ __forceinline__ void finish_key(const BatchView& b, const TableView& 
     if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
     if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
     if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
-    st4(va + sub * 4, nv);
-    st4(va + kp + sub * 4, acc);
+    st4_nt(va + sub * 4, nv);
+    st4_nt(va + kp + sub * 4, acc);
   }
 }
 
@@ -732,6 +748,134 @@ __global__ void __launch_bounds__(256, 8) k_backward_small(BatchView b, RowSrc s
     }
   }
   if (FUSED) flush_penalty(b, pen_acc);
+}
+
+// ---------------------------------------------------------------------------
+// k_update_small<L>: the table-resident, fused form of the short-segment role
+// (cnt <= BWD_SMALL, ~95 % of the keys of a Zipf batch), written lean on the
+// pattern tools/rmw_bench.hip measures at ~40 us for a whole batch: a compact
+// argument block (few SGPRs), compile-time row strides when kp == 4L, one level
+// of index loads (segment bounds + row id), then every independent load of the
+// key at once (header, V, accumulators, first occurrences).
+// ---------------------------------------------------------------------------
+struct SmallArgs {
+  const uint32_t* d_U;
+  const uint32_t* col_ptr;
+  const uint32_t* urow;
+  const uint32_t* s_row;
+  const float* s_val;
+  const float* slope;
+  const float* xv;
+  const uint64_t* feaids;
+  RowHdr* hdr;
+  float* va;
+  uint32_t* need_init;
+  double* prog;
+  int k, kp;
+  dfh_updater_param p;
+};
+
+template <int L, bool EXACT>
+__global__ void __launch_bounds__(256, 8) k_update_small(SmallArgs a) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const int grp = lane / L;
+  const int sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp;
+  const int k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  const uint32_t U = *a.d_U;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  float pen = 0.f;
+  for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
+    const uint32_t u = min(u0 + grp, U - 1);
+    const uint32_t beg = a.col_ptr[u], end_all = a.col_ptr[u + 1];
+    const uint32_t r = a.urow[u];
+    const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL;
+    const uint32_t end = mine ? end_all : beg;
+    // every independent load of the key, back to back
+    RowHdr* hp = a.hdr + r;
+    float* va = a.va + (size_t)r * (2 * kp);
+    const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+    const float fea_cnt = hp->fea_cnt;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), acc = v;
+    if (k > 0 && sub_ok) {
+      v = ld4_nt(va + sub * 4);
+      acc = ld4_nt(va + kp + sub * 4);
+    }
+    float gw = 0.f, xxp = 0.f;
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t j0 = beg; j0 < end; j0 += 2) {
+      const bool ok1 = j0 + 1 < end;
+      const uint32_t row0 = a.s_row[j0], row1 = ok1 ? a.s_row[j0 + 1] : 0;
+      const float x0 = a.s_val ? a.s_val[j0] : 1.0f;
+      const float x1 = ok1 ? (a.s_val ? a.s_val[j0 + 1] : 1.0f) : 0.f;
+      const float p0 = a.slope[row0], p1 = ok1 ? a.slope[row1] : 0.f;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+      if (k > 0 && sub_ok) {
+        a0 = ld4(a.xv + (size_t)row0 * kp + sub * 4);
+        if (ok1) a1 = ld4(a.xv + (size_t)row1 * kp + sub * 4);
+      }
+      // ascending rows: the reference's order (spmm.h:137-156)
+      gw += p0 * x0; xxp += p0 * (x0 * x0);
+      gv.x += (a0.x * p0) * x0; gv.y += (a0.y * p0) * x0; gv.z += (a0.z * p0) * x0; gv.w += (a0.w * p0) * x0;
+      gw += p1 * x1; xxp += p1 * (x1 * x1);
+      gv.x += (a1.x * p1) * x1; gv.y += (a1.y * p1) * x1; gv.z += (a1.z * p1) * x1; gv.w += (a1.w * p1) * x1;
+    }
+    if (!mine) continue;
+    const float w_old = h0.x;
+    const bool has_v = k > 0 && __float_as_uint(h0.y) != 0;
+    if (has_v) {
+      // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198); rows without V hold zeros
+      gv.x -= v.x * xxp; gv.y -= v.y * xxp; gv.z -= v.z * xxp; gv.w -= v.w * xxp;
+      if (sub_ok) pen += 0.5f * a.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    }
+    if (sub == 0) {
+      pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
+      float sqrt_g = h0.z, z = h0.w;
+      const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, a.p);
+      uint32_t hv = has_v ? 1u : 0u;
+      if (w_old == 0 && w_new != 0 && k > 0 && !has_v && fea_cnt > (float)a.p.V_threshold) {  // sgd_updater.cc:122-126
+        if (a.p.init_mode == DFH_INIT_HASH) {
+          const uint64_t key = a.feaids[u];
+          for (int j = 0; j < kp; ++j) {
+            va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
+            va[kp + j] = 0.0f;
+          }
+          hv = 1u;
+        } else {
+          a.need_init[u] = 1;
+        }
+      }
+      st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));
+    }
+    if (has_v && sub_ok) {
+      float4 nv = v;
+      adagrad_update_v(gv.x, nv.x, acc.x, a.p);
+      adagrad_update_v(gv.y, nv.y, acc.y, a.p);
+      adagrad_update_v(gv.z, nv.z, acc.z, a.p);
+      adagrad_update_v(gv.w, nv.w, acc.w, a.p);
+      if (!EXACT || k != kp) {
+        const int d0 = sub * 4;
+        if (d0 + 0 >= k) { nv.x = 0.f; acc.x = 0.f; }
+        if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
+        if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
+        if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
+      }
+      st4_nt(va + sub * 4, nv);
+      st4_nt(va + kp + sub * 4, acc);
+    }
+  }
+  // penalty of the pulled weights (sgd_learner.cc:249-273): lane partials -> one slot per block
+  __shared__ float pen_blk[4];
+  pen = wave_sum(pen);
+  if (lane == 0) pen_blk[threadIdx.x >> 6] = pen;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (double)pen_blk[0] + (double)pen_blk[1] + (double)pen_blk[2] + (double)pen_blk[3];
+    if (t != 0.0) atomicAdd(&a.prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
+  }
 }
 
 // penalty only (validation batches: no backward pass)
