@@ -44,7 +44,7 @@ constexpr int SS_MAX_BUCKETS = 1024;   // => the sample sort serves batches up t
 constexpr int SS_AVG_BUCKET = 512;    // target pairs per bucket
 constexpr int SS_LDS_CAP = 2048;      // pairs a bucket may hold to be sorted in LDS (4x the mean)
 constexpr int SS_TILE = 4096;         // pairs per block in count / scatter
-constexpr int SS_TILE_THREADS = 512;
+constexpr int SS_TILE_THREADS = 1024;
 constexpr int SS_PER_THREAD = SS_TILE / SS_TILE_THREADS;
 constexpr int SS_SORT_THREADS = 512;
 constexpr int SS_SCAN_BUCKETS = 64;   // buckets per block in k_ss_scan
