@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-pipeline", action="store_true", help="prepare and train on one stream")
     ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     return ap.parse_args()
 
 
@@ -105,7 +107,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without a launcher: re-launch under torch.distributed.run, one rank per GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd)
+    if args.gpus > 1 or world > 1 or args.force_sharded:
         from difacto_amd import sharded
         return sharded.bench_main(args, rank, world, local_rank, HYPER)
 

@@ -24,6 +24,8 @@ SYMBOLS = [
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
+    "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
+    "dfh_shard_push_grad_resolved", "dfh_table_check",
 ]
 K_COUNT = 7
 
@@ -127,6 +129,12 @@ def lib():
     L.dfh_batch_lookup.argtypes = [vp, vp]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
+    L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp]
+    L.dfh_shard_resolve.argtypes = [vp, vp, sz, vp]
+    L.dfh_shard_pull_resolved.argtypes = [vp, vp, sz, vp]
+    L.dfh_shard_push_count_resolved.argtypes = [vp, vp, vp, sz, vp]
+    L.dfh_shard_push_grad_resolved.argtypes = [vp, vp, vp, sz, vp]
+    L.dfh_table_check.argtypes = [vp]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
@@ -322,6 +330,23 @@ class Table:
     def shard_push_grad(self, d_keys, n, d_grads):
         _ck(lib().dfh_shard_push_grad(self.h, _dp(d_keys), n, _dp(d_grads)))
 
+    # resolved form: probe all received keys once, then work on row ids
+    def shard_resolve(self, d_keys, n, d_rowid):
+        _ck(lib().dfh_shard_resolve(self.h, _dp(d_keys), n, _dp(d_rowid)))
+
+    def shard_pull_resolved(self, d_rowid, n, d_rows):
+        _ck(lib().dfh_shard_pull_resolved(self.h, _dp(d_rowid), n, _dp(d_rows)))
+
+    def shard_push_count_resolved(self, d_rowid, d_keys, n, d_cnt):
+        _ck(lib().dfh_shard_push_count_resolved(self.h, _dp(d_rowid), _dp(d_keys), n, _dp(d_cnt)))
+
+    def shard_push_grad_resolved(self, d_rowid, d_keys, n, d_grads):
+        _ck(lib().dfh_shard_push_grad_resolved(self.h, _dp(d_rowid), _dp(d_keys), n, _dp(d_grads)))
+
+    def check(self):
+        """raise if the device-side error word is set (capacity / duplicate key / V mismatch)"""
+        _ck(lib().dfh_table_check(self.h))
+
 
 class Batch:
     """a device-resident minibatch + workspace (dfh_batch)"""
@@ -416,6 +441,15 @@ class Batch:
         a, b, u = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
         _ck(lib().dfh_batch_device_keys(self.h, C.byref(a), C.byref(b), C.byref(u)))
         return a.value, b.value, u.value
+
+    def device_key_ptrs(self):
+        """device pointers of feaids / feacnt without synchronising (U comes from key_ranges_device)"""
+        a, b = C.c_void_p(), C.c_void_p()
+        _ck(lib().dfh_batch_device_keys(self.h, C.byref(a), C.byref(b), None))
+        return a.value, b.value
+
+    def key_ranges_device(self, nparts, d_bounds):
+        _ck(lib().dfh_batch_key_ranges_device(self.h, nparts, _dp(d_bounds)))
 
 
 class DeviceBuffer:

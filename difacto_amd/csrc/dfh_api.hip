@@ -121,6 +121,7 @@ struct dfh_batch {
   uint32_t* d_U = nullptr;
   // step workspace
   uint32_t* d_nnz_row = nullptr;
+  uint32_t *d_seg_n = nullptr, *d_mid_list = nullptr, *d_hot_list = nullptr;  // long-segment key lists (k_seg_lists)
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
   float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
   size_t xv_floats = 0;
@@ -319,6 +320,9 @@ BatchView batch_view(const dfh_batch* b) {
   v.slope = b->d_slope;
   v.xv = b->d_xv;
   v.prog = b->d_prog;
+  v.seg_n = b->d_seg_n;
+  v.mid_list = b->d_mid_list;
+  v.hot_list = b->d_hot_list;
   return v;
 }
 
@@ -398,43 +402,36 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
   dfh_ctx* c = b->ctx;
-  // U lives on the device; nnz bounds it.  Two launches that touch disjoint keys and run side by side:
-  //   k_backward_big   (aux stream)  256 keys scanned per hot block, 4*BWD_MIDW keys per mid block
-  //   k_backward_small (main stream) 4*(64/L) keys per block and iteration, grid-stride
-  const size_t nb_hot = std::min<size_t>((b->nnz + 255) / 256, 2048);
-  const size_t nb_mid = std::min<size_t>((b->nnz + 4 * BWD_MIDW - 1) / (4 * BWD_MIDW), 8192);
-  static const size_t small_mult = getenv("DFH_BWD_SMALL_BLOCKS_PER_CU") ? (size_t)atoi(getenv("DFH_BWD_SMALL_BLOCKS_PER_CU")) : 16;
-  const size_t nb_small = std::min<size_t>((b->nnz * (size_t)L + 255) / 256, (size_t)c->num_cu * small_mult);
+  // U and the list sizes live on the device; nnz bounds them.  One launch of BWD_THREADS blocks:
+  //   [0, nb_hot)            one hot key (> BWD_MID occurrences) per block and iteration
+  //   [nb_hot, +nb_mid)      one mid key per wave and iteration
+  //   the rest               short segments: (64/L) keys per wave and iteration, grid-stride
+  // the long chains start first; surplus blocks find their list exhausted and leave at once
+  constexpr size_t NWB = BWD_THREADS / 64;
+  const size_t nb_hot = std::max<size_t>(1, std::min<size_t>(b->nnz / (BWD_MID + 1) + 1, 256));
+  const size_t nb_mid = std::max<size_t>(1, std::min<size_t>((b->nnz / (BWD_SMALL + 1)) / NWB + 1, 512));
+  static const size_t small_cap = getenv("DFH_BWD_SMALL_BLOCKS") ? (size_t)atoi(getenv("DFH_BWD_SMALL_BLOCKS")) : 2048;
+  const size_t keys_per_block = NWB * (64 / L);
+  const size_t nb_small = std::max<size_t>(1, std::min<size_t>((b->nnz + keys_per_block - 1) / keys_per_block, small_cap));
   // debugging aid: DFH_BWD_ROLES=<bitmask> runs only some roles (1 hot, 2 mid, 4 small); results are then wrong
   static const uint32_t role_mask = getenv("DFH_BWD_ROLES") ? (uint32_t)atoi(getenv("DFH_BWD_ROLES")) : 7u;
   static const uint32_t dbg_small = getenv("DFH_BWD_DBG") ? (uint32_t)atoi(getenv("DFH_BWD_DBG")) : 0u;
   TimeScope ts(c, DFH_K_BACKWARD);
-  DFH_HIP(hipEventRecord(c->ev_fork, s));
-  DFH_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+  const dim3 grid((unsigned)(nb_hot + nb_mid + nb_small)), block(BWD_THREADS);
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
-    if (role_mask & 3u)
-      hipLaunchKernelGGL((k_backward_big<LL, FUSED>), dim3((unsigned)(nb_hot + nb_mid)), dim3(256), 0, c->aux, bv, src, tv,
-                         grads, gstride, k, kp, need, (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask);
-    if (role_mask & 4u) {
-      if (FUSED && src.urow && !(dbg_small & 4u)) {
-        SmallArgs sa;
-        sa.d_U = bv.d_U; sa.col_ptr = bv.col_ptr; sa.urow = src.urow; sa.s_row = bv.s_row; sa.s_val = bv.s_val;
-        sa.slope = bv.slope; sa.xv = bv.xv; sa.feaids = bv.feaids; sa.hdr = tv.hdr; sa.va = tv.va; sa.need_init = need;
-        sa.prog = bv.prog; sa.k = k; sa.kp = kp; sa.p = tv.p;
-        if (kp == 4 * LL) {
-          hipLaunchKernelGGL((k_update_small<LL, true>), dim3((unsigned)nb_small), dim3(256), 0, s, sa);
-        } else {
-          hipLaunchKernelGGL((k_update_small<LL, false>), dim3((unsigned)nb_small), dim3(256), 0, s, sa);
-        }
-      } else {
-        hipLaunchKernelGGL((k_backward_small<LL, FUSED>), dim3((unsigned)nb_small), dim3(256), 0, s, bv, src, tv, grads,
-                           gstride, k, kp, need, dbg_small);
-      }
+    const bool lean = FUSED && src.urow && !(dbg_small & 4u);
+    if (lean && kp == 4 * LL) {
+      hipLaunchKernelGGL((k_backward_all<LL, FUSED, FUSED, true>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
+                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
+    } else if (lean) {
+      hipLaunchKernelGGL((k_backward_all<LL, FUSED, FUSED, false>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
+                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
+    } else {
+      hipLaunchKernelGGL((k_backward_all<LL, FUSED, false, false>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
+                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
     }
   });
-  DFH_HIP(hipEventRecord(c->ev_join, c->aux));
-  DFH_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   if (rc) return rc;
   DFH_HIP(hipGetLastError());
   return DFH_OK;
@@ -754,6 +751,72 @@ int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const fl
   DFH_HIP(hipGetLastError());
   if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
   return DFH_OK;
+}
+
+// ---- resolved owner-side calls: probe once per step, then work on row ids
+int dfh_shard_resolve(dfh_table* t, const uint64_t* d_keys, size_t n, uint32_t* d_rowid) {
+  DFH_ARG(t && (n == 0 || (d_keys && d_rowid)), "dfh_shard_resolve: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_LOOKUP);
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys, (uint32_t)n,
+                     d_rowid);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_pull_resolved(dfh_table* t, const uint32_t* d_rowid, size_t n, float* d_rows) {
+  DFH_ARG(t && (n == 0 || (d_rowid && d_rows)), "dfh_shard_pull_resolved: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PULL);
+  const size_t stride = dfh_row_stride(t->v.k);
+  int rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);
+    hipLaunchKernelGGL((k_pull_resolved<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, (uint32_t)n,
+                       d_rows, stride);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_cnt) {
+  DFH_ARG(t && (n == 0 || (d_rowid && d_keys && d_cnt)), "dfh_shard_push_count_resolved: NULL argument");
+  if (!(t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0)) {
+    set_error("resolved store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  if (n == 0) return DFH_OK;
+  hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
+                     (const uint32_t*)nullptr, (uint32_t)n, const_cast<uint32_t*>(d_rowid), d_cnt, (const uint32_t*)nullptr, 1,
+                     (uint32_t*)nullptr, 1);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_grads) {
+  DFH_ARG(t && (n == 0 || (d_rowid && d_keys && d_grads)), "dfh_shard_push_grad_resolved: NULL argument");
+  if (!(t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0)) {
+    set_error("resolved store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PUSH);
+  const size_t stride = dfh_row_stride(t->v.k);
+  int rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);
+    hipLaunchKernelGGL((k_push_grad_resolved<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys,
+                       (uint32_t)n, d_grads, stride);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_table_check(dfh_table* t) {
+  DFH_ARG(t, "NULL table");
+  return check_table_err(t);
 }
 
 // ---- literal Store API (host pointers)
@@ -1163,6 +1226,8 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_U, 64, uint32_t);
   DFH_ALLOC(b->d_urow, N, uint32_t);
   DFH_ALLOC(b->d_nnz_row, N, uint32_t);
+  DFH_ALLOC(b->d_mid_list, N / (BWD_SMALL + 1) + 1, uint32_t);
+  DFH_ALLOC(b->d_hot_list, N / (BWD_MID + 1) + 1, uint32_t);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1174,6 +1239,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_slab, B, uint32_t);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
+  b->d_seg_n = b->d_U + SEG_N_WORD;
   DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
   DFH_HIP(hipEventCreateWithFlags(&b->ev_free, hipEventDisableTiming));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
@@ -1193,7 +1259,8 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_nnz_row, b->d_pred,  b->d_slope, b->d_xv,
                   b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_smp_rank, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
-                  b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont};
+                  b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont,
+                  b->d_mid_list, b->d_hot_list};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1286,7 +1353,7 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   b->looked_up = nullptr;
   if (N == 0) {
     // reference would index an empty vector (localizer.cc:35); define: no keys
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, b->d_U, 0u);
+    DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), s));  // U = 0, no long segments
     DFH_HIP(hipMemsetAsync(b->d_col_ptr, 0, 4, s));
     b->localized = true;
     return prep_end(b);
@@ -1350,6 +1417,9 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
                        b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                        b->d_s_row, b->d_s_val, b->d_U);
   }
+  // keys with long segments, for the backward pass (the emit kernels zeroed the two counters)
+  hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
+                     b->d_col_ptr, b->d_U, b->d_seg_n, b->d_mid_list, b->d_hot_list);
   delete tsp;
   DFH_HIP(hipGetLastError());
   b->localized = true;
@@ -1449,6 +1519,12 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemsetAsync(b->d_seg_n, 0, 2 * sizeof(uint32_t), s));
+  if (U) {
+    hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::min<size_t>((U + 1023) / 1024, 256)), dim3(1024), 0, s, b->d_col_ptr,
+                       b->d_U, b->d_seg_n, b->d_mid_list, b->d_hot_list);
+    DFH_HIP(hipGetLastError());
+  }
   DFH_HIP(hipStreamSynchronize(s));
   b->nrows = nrows;
   b->nnz = nnz;
@@ -1499,14 +1575,29 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
   if (d_feaids) *d_feaids = b->d_feaids;
   if (d_feacnt) {
     if (!b->has_cnt) {
-      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, b->ctx)), dim3(256), 0, b->ctx->prep, b->d_col_ptr,
+      // ordered after the batch's preparation, on the stream the consumers of the counts run on
+      int rc = main_begin(b);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, b->ctx)), dim3(256), 0, b->ctx->stream, b->d_col_ptr,
                          b->d_U, b->d_feacnt);
       DFH_HIP(hipGetLastError());
       b->has_cnt = true;
     }
     *d_feacnt = b->d_feacnt;
   }
-  if (U) return dfh_batch_shape(b, nullptr, nullptr, U);
+  if (U) return dfh_batch_shape(b, nullptr, nullptr, U);  // synchronises; pass NULL to stay asynchronous
+  return DFH_OK;
+}
+
+int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, int64_t* d_bounds) {
+  DFH_ARG(b && b->localized && d_bounds && nparts >= 1 && nparts <= 1024, "dfh_batch_key_ranges_device: bad argument");
+  dfh_ctx* c = b->ctx;
+  int rc = main_begin(b);
+  if (rc) return rc;
+  const uint64_t span = nparts == 1 ? ~0ULL : (~0ULL / (uint64_t)nparts) + 1;
+  hipLaunchKernelGGL(k_key_ranges64, dim3((nparts + 256) / 256), dim3(256), 0, c->stream, b->d_feaids, b->d_U, nparts, span,
+                     d_bounds, (uint32_t)(b->nnz == 0));
+  DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
 
@@ -1604,7 +1695,9 @@ int dfh_batch_forward(dfh_batch* b, int V_dim, const float* d_rows) {
   b->nrows_seen += (float)b->nrows;
   rc = main_begin(b);
   if (rc) return rc;
-  return launch_forward(b, packed_src(d_rows, V_dim), V_dim, kp);
+  rc = launch_forward(b, packed_src(d_rows, V_dim), V_dim, kp);
+  if (rc) return rc;
+  return main_end(b);  // a prediction-only step ends here; dfh_batch_backward moves the mark
 }
 
 int dfh_batch_backward(dfh_batch* b, int V_dim, const float* d_rows, float* d_grads) {

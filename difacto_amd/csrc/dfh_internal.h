@@ -56,6 +56,9 @@ struct TableView {
   dfh_updater_param p;
 };
 
+// the batch's device scalar block d_U[64]: [0] = U, [1] = REFRAND total, [SEG_N_WORD..+1] = mid / hot list sizes
+constexpr int SEG_N_WORD = 8;
+
 // "row source" seen by the forward / backward kernels: either the table
 // itself (rows addressed through urow[u]) or a packed [U x stride] buffer of
 // pulled rows (multi-GPU exchange layout, dfh_row_stride()).
@@ -87,6 +90,9 @@ struct BatchView {
   float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
   float* xv;                // [nrows x kp]
   double* prog;             // [2][PROG_SLOTS] per-block partials: logloss, penalty
+  const uint32_t* seg_n;    // [2] number of mid / hot keys (k_seg_lists)
+  const uint32_t* mid_list; // keys with BWD_SMALL < occurrences <= BWD_MID, any order
+  const uint32_t* hot_list; // keys with more than BWD_MID occurrences, any order
 };
 
 // ------------------------------------------------------------- error plumbing

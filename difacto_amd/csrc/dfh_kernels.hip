@@ -187,8 +187,9 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
 constexpr uint32_t BWD_SMALL = 8;
 constexpr uint32_t BWD_MID = 256;
 constexpr int BWD_MIDW = 16;
-constexpr int BWD_DEPTH = 4;
+constexpr int BWD_DEPTH = 2;
 constexpr int BWD_SMALL_DEPTH = 2;
+constexpr int BWD_THREADS = 512;    // threads per block of k_backward_all
 
 // ---------------------------------------------------------------------------
 // k_lookup: one thread per unique key.  urow[u] = row of feaids[u] (inserted as
@@ -534,7 +535,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // block-wide sum of the per-lane penalty partials into one of PROG_SLOTS slots
 // (distinct addresses: no same-address atomic serialisation)
 __device__ __forceinline__ void flush_penalty(const BatchView& b, double pen_acc) {
-  __shared__ double pen_blk[8];
+  __shared__ double pen_blk[16];
   pen_acc = wave_sum_d(pen_acc);
   if (lane_id() == 0) pen_blk[threadIdx.x >> 6] = pen_acc;
   __syncthreads();
@@ -601,92 +602,68 @@ __device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_
   return s;
 }
 
-template <int L, bool FUSED>
-__global__ void __launch_bounds__(256) k_backward_big(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
-                                                      size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
-                                                      uint32_t nb_hot, uint32_t nb_mid, uint32_t role_mask) {
-  constexpr int NW = 4;
-  __shared__ float part[NW][2 + 256];  // hot role, per wave: gw, xxp, gv[kp <= 256]
-  __shared__ uint32_t hot_u[256];
-  __shared__ uint32_t hot_n;
+// ---- long segments (cnt > BWD_SMALL), taken from the two lists k_seg_lists compacts once per
+// minibatch: every wave of the mid blocks takes mid keys (whole wave per key), every hot block
+// takes hot keys one at a time (its NW waves split the segment, partials combined through LDS in
+// wave order).  The lists are in arbitrary order; a key's result does not depend on it.
+template <int L, bool FUSED, int NW>
+__device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
+                                         size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
+                                         uint32_t nwaves, double& pen_acc) {
+  const int lane = lane_id();
+  const int grp = lane / L;
+  const int sub = lane % L;
+  const bool sub_ok = sub * 4 < kp;
+  const uint32_t nm = b.seg_n[0];
+  for (uint32_t q = wave; q < nm; q += nwaves) {
+    const uint32_t u = b.mid_list[q];
+    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+    const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+    KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
+    if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+  }
+}
+
+template <int L, bool FUSED, int NW>
+__device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
+                                         size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t blk,
+                                         uint32_t nblk, double& pen_acc) {
+  __shared__ float part[NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
   const int w = threadIdx.x >> 6;
-  const uint32_t U = *b.d_U;
-  double pen_acc = 0.0;
-
-  if (blockIdx.x < nb_hot) {
-    // ---- hot role: 256 keys scanned per block; keys with cnt > BWD_MID are taken one at a
-    // time by the whole block (4 waves, partials combined in LDS in a fixed order)
-    if (!(role_mask & 1u)) return;
-    for (uint32_t u0 = blockIdx.x * 256; u0 < U; u0 += nb_hot * 256) {
-      if (threadIdx.x == 0) hot_n = 0;
-      __syncthreads();
-      const uint32_t mine = u0 + threadIdx.x;
-      if (mine < U && b.col_ptr[mine + 1] - b.col_ptr[mine] > BWD_MID) hot_u[atomicAdd(&hot_n, 1u)] = mine;
-      __syncthreads();
-      const uint32_t n = hot_n;
-      for (uint32_t q = 0; q < n; ++q) {
-        // LDS slot order is arbitrary but a key's result does not depend on it
-        const uint32_t u = hot_u[q];
-        const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
-        const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-        KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
-        __syncthreads();  // previous key's partials consumed
-        if (grp == 0) {
-          if (sub == 0) { part[w][0] = s.gw; part[w][1] = s.xxp; }
-          if (sub_ok) {
-            part[w][2 + sub * 4 + 0] = s.gv.x; part[w][2 + sub * 4 + 1] = s.gv.y;
-            part[w][2 + sub * 4 + 2] = s.gv.z; part[w][2 + sub * 4 + 3] = s.gv.w;
-          }
-        }
-        __syncthreads();
-        if (w == 0 && grp == 0) {
-          KeySums tot;
-          tot.gw = 0.f; tot.xxp = 0.f; tot.gv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int i = 0; i < NW; ++i) {
-            tot.gw += part[i][0];
-            tot.xxp += part[i][1];
-            if (sub_ok) {
-              tot.gv.x += part[i][2 + sub * 4 + 0]; tot.gv.y += part[i][2 + sub * 4 + 1];
-              tot.gv.z += part[i][2 + sub * 4 + 2]; tot.gv.w += part[i][2 + sub * 4 + 3];
-            }
-          }
-          finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc);
-        }
+  const uint32_t nh = b.seg_n[1];
+  for (uint32_t q = blk; q < nh; q += nblk) {
+    const uint32_t u = b.hot_list[q];
+    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+    const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+    KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
+    __syncthreads();  // previous key's partials consumed
+    if (grp == 0) {
+      if (sub == 0) { part[w][0] = s.gw; part[w][1] = s.xxp; }
+      if (sub_ok) {
+        part[w][2 + sub * 4 + 0] = s.gv.x; part[w][2 + sub * 4 + 1] = s.gv.y;
+        part[w][2 + sub * 4 + 2] = s.gv.z; part[w][2 + sub * 4 + 3] = s.gv.w;
       }
-      __syncthreads();
     }
-  } else {
-    // ---- mid role: each wave scans BWD_MIDW keys and takes those with
-    // BWD_SMALL < cnt <= BWD_MID one after the other, whole wave per key
-    if (!(role_mask & 2u)) return;
-    const uint32_t wave = (blockIdx.x - nb_hot) * NW + w;
-    const uint32_t nwaves = nb_mid * NW;
-    for (uint32_t u0 = wave * BWD_MIDW; u0 < U; u0 += nwaves * BWD_MIDW) {
-      const uint32_t mine = u0 + lane;
-      uint32_t my_beg = 0, my_cnt = 0;
-      if (lane < BWD_MIDW && mine < U) {
-        my_beg = b.col_ptr[mine];
-        my_cnt = b.col_ptr[mine + 1] - my_beg;
+    __syncthreads();
+    if (w == 0 && grp == 0) {
+      KeySums tot;
+      tot.gw = 0.f; tot.xxp = 0.f; tot.gv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        tot.gw += part[i][0];
+        tot.xxp += part[i][1];
+        if (sub_ok) {
+          tot.gv.x += part[i][2 + sub * 4 + 0]; tot.gv.y += part[i][2 + sub * 4 + 1];
+          tot.gv.z += part[i][2 + sub * 4 + 2]; tot.gv.w += part[i][2 + sub * 4 + 3];
+        }
       }
-      unsigned long long todo = __ballot(my_cnt > BWD_SMALL && my_cnt <= BWD_MID);
-      while (todo) {
-        const int src_lane = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t u = u0 + src_lane;
-        const uint32_t beg = __shfl(my_beg, src_lane, 64);
-        const uint32_t end = beg + __shfl(my_cnt, src_lane, 64);
-        const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-        KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
-        if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
-      }
+      finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc);
     }
   }
-  if (FUSED) flush_penalty(b, pen_acc);
 }
 
 // ---- small segments (cnt <= BWD_SMALL): one L-lane group per key, G keys per wave,
@@ -695,20 +672,16 @@ __global__ void __launch_bounds__(256) k_backward_big(BatchView b, RowSrc src, T
 // chain of dependent random accesses and only occupancy hides them.  Runs
 // concurrently with k_backward_big (other stream): the two touch disjoint keys.
 template <int L, bool FUSED>
-__global__ void __launch_bounds__(256, 8) k_backward_small(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
-                                                           size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t dbg) {
+__device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
+                                           size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
+                                           uint32_t nwaves, uint32_t dbg, double& pen_acc) {
   constexpr int G = 64 / L;
-  constexpr int NW = 4;
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
-  const int w = threadIdx.x >> 6;
   const uint32_t U = *b.d_U;
-  double pen_acc = 0.0;
   {
-    const uint32_t wave = blockIdx.x * NW + w;
-    const uint32_t nwaves = gridDim.x * NW;
     for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
       // no branch before the loads: the segment bounds, the row id and then the row itself are
       // requested for every lane group (keys left to the mid / hot roles waste one speculative read)
@@ -747,7 +720,6 @@ __global__ void __launch_bounds__(256, 8) k_backward_small(BatchView b, RowSrc s
       }
     }
   }
-  if (FUSED) flush_penalty(b, pen_acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -776,7 +748,7 @@ struct SmallArgs {
 };
 
 template <int L, bool EXACT>
-__global__ void __launch_bounds__(256, 8) k_update_small(SmallArgs a) {
+__device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wave, uint32_t nwaves, double& pen_acc) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
@@ -785,8 +757,6 @@ __global__ void __launch_bounds__(256, 8) k_update_small(SmallArgs a) {
   const int k = a.k;
   const bool sub_ok = EXACT ? true : (sub * 4 < kp);
   const uint32_t U = *a.d_U;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   float pen = 0.f;
   for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
     const uint32_t u = min(u0 + grp, U - 1);
@@ -867,14 +837,65 @@ __global__ void __launch_bounds__(256, 8) k_update_small(SmallArgs a) {
       st4_nt(va + kp + sub * 4, acc);
     }
   }
-  // penalty of the pulled weights (sgd_learner.cc:249-273): lane partials -> one slot per block
-  __shared__ float pen_blk[4];
-  pen = wave_sum(pen);
-  if (lane == 0) pen_blk[threadIdx.x >> 6] = pen;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t = (double)pen_blk[0] + (double)pen_blk[1] + (double)pen_blk[2] + (double)pen_blk[3];
-    if (t != 0.0) atomicAdd(&a.prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
+  pen_acc += (double)pen;  // penalty of the pulled weights (sgd_learner.cc:249-273); flushed once per block
+}
+
+// ---------------------------------------------------------------------------
+// k_backward_all: ONE launch for the whole backward/update of a minibatch.  Blocks
+// [0, nb_big) run the long-segment roles (they start first: their chains are the
+// longest), the others the short-segment role.  LEAN selects the table-specialised
+// short-segment code (fused update on the resident table).
+// ---------------------------------------------------------------------------
+template <int L, bool FUSED, bool LEAN, bool EXACT>
+__global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
+                                                                size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
+                                                                uint32_t nb_hot, uint32_t nb_mid, uint32_t role_mask, uint32_t dbg) {
+  constexpr int NW = BWD_THREADS / 64;
+  double pen_acc = 0.0;
+  if (blockIdx.x < nb_hot) {
+    if (role_mask & 1u) hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, blockIdx.x, nb_hot, pen_acc);
+  } else if (blockIdx.x < nb_hot + nb_mid) {
+    if (role_mask & 2u)
+      mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (blockIdx.x - nb_hot) * NW + (threadIdx.x >> 6),
+                             nb_mid * NW, pen_acc);
+  } else if (role_mask & 4u) {
+    const uint32_t nb_big = nb_hot + nb_mid;
+    const uint32_t wave = (blockIdx.x - nb_big) * NW + (threadIdx.x >> 6);
+    const uint32_t nwaves = (gridDim.x - nb_big) * NW;
+    if (LEAN) {
+      SmallArgs sa;
+      sa.d_U = b.d_U; sa.col_ptr = b.col_ptr; sa.urow = src.urow; sa.s_row = b.s_row; sa.s_val = b.s_val;
+      sa.slope = b.slope; sa.xv = b.xv; sa.feaids = b.feaids; sa.hdr = t.hdr; sa.va = t.va; sa.need_init = need_init;
+      sa.prog = b.prog; sa.k = k; sa.kp = kp; sa.p = t.p;
+      small_role_lean<L, EXACT>(sa, wave, nwaves, pen_acc);
+    } else {
+      small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, dbg, pen_acc);
+    }
+  }
+  if (FUSED) flush_penalty(b, pen_acc);
+}
+
+// k_seg_lists: one pass over the unique keys of a localized minibatch, compacting the keys with
+// long segments into the mid / hot lists (one atomic per block and list; seg_n zeroed before)
+__global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U,
+                                                    uint32_t* __restrict__ seg_n, uint32_t* __restrict__ mid_list,
+                                                    uint32_t* __restrict__ hot_list) {
+  __shared__ uint32_t cnt[2], base[2];
+  const uint32_t U = *d_U;
+  for (uint32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += gridDim.x * blockDim.x) {
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t u = u0 + threadIdx.x;
+    uint32_t len = 0, slot = 0;
+    if (u < U) len = col_ptr[u + 1] - col_ptr[u];
+    const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : -1);
+    if (which >= 0) slot = atomicAdd(&cnt[which], 1u);
+    __syncthreads();
+    if (threadIdx.x < 2 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&seg_n[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (which == 0) mid_list[base[0] + slot] = u;
+    if (which == 1) hot_list[base[1] + slot] = u;
+    __syncthreads();
   }
 }
 
@@ -970,6 +991,118 @@ __global__ void __launch_bounds__(256) k_push_grad(TableView t, const uint64_t* 
         adagrad_update_v(g[4 + d], vv, acc, t.p);
         va[d] = vv;
         va[t.kp + d] = acc;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Owner side, resolved form: the keys an owner receives from G source ranks are
+// resolved to table rows ONCE per step (k_resolve, duplicates across sources
+// allowed), then Pull is one gather over all of them and the two Push kinds run
+// per source rank on known rows (no probing, sequential in source order).
+// ---------------------------------------------------------------------------
+// like find_or_insert, but several threads of the launch may carry the same key:
+// the thread that wins the slot publishes the row id, the others wait for it
+__device__ __forceinline__ uint32_t find_or_insert_shared(const TableView& t, uint64_t key) {
+  uint64_t h = splitmix64(key) & t.hmask;
+  for (;;) {
+    uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
+                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == kEmptyKey) {
+        uint32_t r = atomicAdd(t.nrows, 1u);
+        if (r >= t.capacity) {
+          atomicOr(t.err, 1u);
+          r = t.capacity - 1;
+        }
+        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return r;
+      }
+      k = old;
+    }
+    if (k == key) {
+      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (r != 0xFFFFFFFFu) return r;
+      continue;  // the winner of this slot is between its CAS and its store
+    }
+    h = (h + 1) & t.hmask;
+  }
+}
+
+__global__ void k_resolve(TableView t, const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ rowid) {
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    rowid[u] = find_or_insert_shared(t, keys[u]);
+}
+
+// Pull on resolved rows: L lanes per key copy [w, has_V, 0, 0 | V] (float4 per lane)
+template <int L>
+__global__ void __launch_bounds__(256) k_pull_resolved(TableView t, const uint32_t* __restrict__ rowid, uint32_t n,
+                                                       float* __restrict__ rows, size_t stride) {
+  constexpr int GPW = 64 / L;
+  const int lane = lane_id();
+  const int sub = lane % L;
+  const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
+  const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
+  for (uint32_t u = group; u < n; u += ngroups) {
+    const uint32_t r = rowid[u];
+    const float4 h0 = ld4(reinterpret_cast<const float*>(t.hdr + r));  // {w, has_V, sqrt_g, z}
+    const bool hv = __float_as_uint(h0.y) != 0u;
+    float* out = rows + (size_t)u * stride;
+    if (sub == 0) st4(out, make_float4(h0.x, hv ? 1.0f : 0.0f, 0.f, 0.f));
+    const float* va = t.va + (size_t)r * (2 * t.kp);
+    for (int d = sub * 4; d < t.kp; d += 4 * L) st4(out + 4 + d, hv ? ld4(va + d) : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
+// Push(kGradient) on resolved rows of ONE source rank (unique inside the launch): L lanes per key
+template <int L>
+__global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const uint32_t* __restrict__ rowid,
+                                                            const uint64_t* __restrict__ keys, uint32_t n,
+                                                            const float* __restrict__ grads, size_t stride) {
+  constexpr int GPW = 64 / L;
+  const int lane = lane_id();
+  const int sub = lane % L;
+  const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
+  const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
+  for (uint32_t u = group; u < n; u += ngroups) {
+    const uint32_t r = rowid[u];
+    const float* g = grads + (size_t)u * stride;
+    const float4 g0 = ld4(g);
+    const bool had_v = g0.y != 0.0f;
+    RowHdr* hp = t.hdr + r;
+    const uint32_t has_v = hp->has_V;
+    if (had_v && !has_v) {  // CHECK(e.V != nullptr), sgd_updater.cc:92
+      if (sub == 0) atomicOr(t.err, 4u);
+    } else if (had_v) {
+      float* va = t.va + (size_t)r * (2 * t.kp);
+      for (int d = sub * 4; d < t.kp; d += 4 * L) {
+        const float4 gv = ld4(g + 4 + d);
+        float4 v = ld4(va + d), acc = ld4(va + t.kp + d);
+        adagrad_update_v(gv.x, v.x, acc.x, t.p);
+        adagrad_update_v(gv.y, v.y, acc.y, t.p);
+        adagrad_update_v(gv.z, v.z, acc.z, t.p);
+        adagrad_update_v(gv.w, v.w, acc.w, t.p);
+        if (d + 0 >= t.k) { v.x = 0.f; acc.x = 0.f; }
+        if (d + 1 >= t.k) { v.y = 0.f; acc.y = 0.f; }
+        if (d + 2 >= t.k) { v.z = 0.f; acc.z = 0.f; }
+        if (d + 3 >= t.k) { v.w = 0.f; acc.w = 0.f; }
+        st4(va + d, v);
+        st4(va + t.kp + d, acc);
+      }
+    }
+    if (sub == 0) {
+      const float w_old = hp->w;
+      float sqrt_g = hp->sqrt_g, z = hp->z;
+      const float w_new = ftrl_update_w(g0.x, w_old, sqrt_g, z, t.p);
+      hp->w = w_new;
+      hp->sqrt_g = sqrt_g;
+      hp->z = z;
+      // lazy InitV when w leaves zero (sgd_updater.cc:122-126); HASH init only on this path
+      if (w_old == 0 && w_new != 0 && t.k > 0 && has_v == 0 && hp->fea_cnt > (float)t.p.V_threshold) {
+        init_v_hash_row(t, r, keys[u]);
+        hp->has_V = 1;
       }
     }
   }
@@ -1129,6 +1262,7 @@ __global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* _
                            uint32_t nrows, const uint32_t* __restrict__ offset, const float* __restrict__ value,
                            uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
                            uint32_t* __restrict__ s_row, float* __restrict__ s_val, uint32_t* __restrict__ d_U) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d_U[SEG_N_WORD] = 0; d_U[SEG_N_WORD + 1] = 0; }  // for k_seg_lists
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
     const uint32_t uid = uid_incl[i] - 1;
     const uint32_t pos = spos[i];
@@ -1211,6 +1345,25 @@ __global__ void __launch_bounds__(256) k_warm_start(TableView t, const uint64_t*
 }
 
 // feacnt[u] = segment length (float), for reading the localizer's output back
+// the same bounds as int64 in caller-owned device memory (asynchronous sharded step)
+__global__ void k_key_ranges64(const uint64_t* __restrict__ feaids, const uint32_t* __restrict__ d_U, int nparts,
+                               uint64_t span, int64_t* __restrict__ bounds, uint32_t empty) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d > nparts) return;
+  const uint32_t U = empty ? 0u : *d_U;
+  if (d == nparts) {
+    bounds[d] = U;
+    return;
+  }
+  const uint64_t first = (uint64_t)d * span;
+  uint32_t lo = 0, hi = U;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (feaids[mid] < first) lo = mid + 1; else hi = mid;
+  }
+  bounds[d] = lo;
+}
+
 __global__ void k_loc_counts(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U, float* __restrict__ cnt) {
   const uint32_t U = *d_U;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {

@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(256) k_ss_emit(SSView v, const uint32_t* __res
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t sh_cont;
   const uint32_t b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) { d_U[SEG_N_WORD] = 0; d_U[SEG_N_WORD + 1] = 0; }  // for k_seg_lists
   const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
   if (beg == end) return;
   // uniq(b') = nheads[b'] - cont[b'] summed over b' < b; cont[b'] compares first_key[b'] with the

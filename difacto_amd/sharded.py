@@ -30,6 +30,7 @@ exercised on CPU (gloo, world_size 2) with a test double; the product backend is
 HipBackend (HIP kernels through the C ABI).  No CPU fallback is selected
 implicitly: ShardedWorker requires an explicit backend.
 """
+import collections
 import json
 import os
 import time
@@ -62,75 +63,118 @@ def torch_view(ptr, n, dtype, device):
     return torch.as_tensor(_DevPtr(ptr, (n,), typestr), device=device)
 
 
+NSLOTS = 2  # minibatches in flight per rank: one stepping, one being localized
+
+
 class HipBackend:
     """the product backend: HIP kernels through include/difacto_hip.h"""
 
-    def __init__(self, device_index, V_dim, capacity, hyper, max_rows, max_nnz):
+    def __init__(self, device_index, V_dim, capacity, hyper, max_rows, max_nnz, pipeline=True):
         from . import capi
         self.capi = capi
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        # share torch's current stream so that kernels, copies and RCCL collectives are stream-ordered
-        self.ctx = capi.Context(device_index, stream=torch.cuda.current_stream().cuda_stream)
+        # one torch stream carries the step; the library's kernels, torch's copies and the RCCL
+        # collectives are all ordered on it.  The Localizer of the NEXT minibatch runs on the
+        # library's own preparation stream (dfh_ctx_set_pipeline) and is joined with events.
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
+        self.ctx = capi.Context(device_index, stream=self.stream.cuda_stream)
+        if pipeline:
+            self.ctx.set_pipeline(True)
         self.table = capi.Table(self.ctx, capacity, V_dim=V_dim, init_mode=capi.INIT_HASH, **hyper)
-        self.batch = capi.Batch(self.ctx, max_rows, max_nnz)
+        self.batches = [capi.Batch(self.ctx, max_rows, max_nnz) for _ in range(NSLOTS)]
+        self._keep = [None] * NSLOTS
         self.V_dim = V_dim
         self.stride = capi.row_stride(V_dim)
 
     # ---- worker side
-    def load_and_localize(self, b):
-        """b: dict(offset u64, index u64 raw ids, value f32|None, label f32) on the host"""
-        self.batch.load_host(b["offset"], b["index"], b["value"], b["label"])
-        self.batch.localize()
+    def submit(self, slot, data):
+        """enqueue load + Localizer for a minibatch: either the reader's host arrays
+        dict(offset u64, index u64 raw ids, value f32|None, label f32), or arrays already in
+        HBM as dict(device=True, nrows, nnz, offset i32, index i64, value|None, label)"""
+        b = self.batches[slot]
+        if data.get("device"):
+            self._keep[slot] = data  # the batch reads the caller's tensors in place
+            b.attach_device(data["nrows"], data["nnz"], data["offset"], data["index"], data.get("value"), data["label"])
+        else:
+            b.load_host(data["offset"], data["index"], data["value"], data["label"])
+        b.localize()
 
-    def load_and_localize_device(self, nrows, nnz, d_offset, d_index, d_value, d_label):
-        self.batch.load_device(nrows, nnz, d_offset, d_index, d_value, d_label)
-        self.batch.localize()
+    def bounds(self, slot, world, out):
+        """out[world+1] (int64, device): keys of shard d are feaids[out[d]:out[d+1]]; asynchronous"""
+        self.batches[slot].key_ranges_device(world, out)
 
-    def unique_keys(self):
+    def unique_keys(self, slot, U):
         """-> (keys int64 tensor [U] (bit pattern of the u64 keys), counts float32 [U])"""
-        pk, pc, U = self.batch.device_keys()
+        pk, pc = self.batches[slot].device_key_ptrs()
         return torch_view(pk, U, torch.int64, self.device), torch_view(pc, U, torch.float32, self.device)
 
-    def key_ranges(self, world):
-        return self.batch.key_ranges(world).astype(np.int64)
+    def forward(self, slot, rows):
+        self.batches[slot].forward(self.V_dim, rows.data_ptr())
 
-    def forward(self, rows):
-        self.batch.forward(self.V_dim, rows.data_ptr())
-
-    def backward(self, rows, grads):
-        self.batch.backward(self.V_dim, rows.data_ptr(), grads.data_ptr())
+    def backward(self, slot, rows, grads):
+        self.batches[slot].backward(self.V_dim, rows.data_ptr(), grads.data_ptr())
 
     def progress(self):
-        return self.batch.progress(reset=True)
+        tot = None
+        for b in self.batches:
+            p = b.progress(reset=True)
+            if tot is None:
+                tot = p
+            else:
+                for f, _ in p._fields_:
+                    setattr(tot, f, getattr(tot, f) + getattr(p, f))
+        return tot
 
-    def pred(self):
-        return self.batch.pred()
+    def pred(self, slot):
+        return self.batches[slot].pred()
 
-    # ---- owner side (n unique keys per call)
-    def owner_push_count(self, keys, cnt):
+    # ---- owner side: all keys received in a step are resolved to rows once
+    def owner_resolve(self, keys):
+        rowid = torch.empty(keys.numel(), dtype=torch.int32, device=self.device)
+        self.table.shard_resolve(keys, keys.numel(), rowid)
+        return rowid
+
+    def owner_pull(self, rowid, keys, rows, seg):
+        self.table.shard_pull_resolved(rowid, rowid.numel(), rows)
+
+    def owner_push_count(self, rowid, keys, cnt):
         if keys.numel():
-            self.table.shard_push_count(keys.data_ptr(), keys.numel(), cnt.data_ptr())
+            self.table.shard_push_count_resolved(rowid, keys, keys.numel(), cnt)
 
-    def owner_pull(self, keys, rows):
+    def owner_push_grad(self, rowid, keys, grads):
         if keys.numel():
-            self.table.shard_pull(keys.data_ptr(), keys.numel(), rows.data_ptr())
-
-    def owner_push_grad(self, keys, grads):
-        if keys.numel():
-            self.table.shard_push_grad(keys.data_ptr(), keys.numel(), grads.data_ptr())
+            self.table.shard_push_grad_resolved(rowid, keys, keys.numel(), grads)
 
     def sync(self):
         self.ctx.sync()
 
+    def check(self):
+        self.table.check()
+
     def close(self):
-        self.batch.close()
+        self.ctx.sync()
+        for b in self.batches:
+            b.close()
         self.table.close()
         self.ctx.close()
 
 
+class _Pending:
+    __slots__ = ("slot", "counted")
+
+    def __init__(self, slot):
+        self.slot, self.counted = slot, False
+
+
 class ShardedWorker:
-    """one rank of the sharded SGD loop (worker + owner of one key range)"""
+    """one rank of the sharded SGD loop (worker + owner of one key range).
+
+    submit(batch) enqueues the Localizer of a minibatch (up to NSLOTS in flight);
+    step() runs the oldest submitted one.  Submitting batch t+1 before step(t) lets its
+    Localizer and the exchange of its per-destination key counts overlap step t, so a
+    step waits on the host only for an event that was recorded long before."""
 
     def __init__(self, backend, group=None):
         self.be = backend
@@ -139,49 +183,89 @@ class ShardedWorker:
         self.world = dist.get_world_size(group)
         self.device = backend.device
         self.stride = backend.stride
+        self.cuda = self.device.type == "cuda"
+        G = self.world
+        self.queue = collections.deque()
+        self.next_slot = 0
+        self._bounds = [torch.zeros(G + 1, dtype=torch.int64, device=self.device) for _ in range(NSLOTS)]
+        self._hcnt = [torch.zeros((2, G), dtype=torch.int64, pin_memory=self.cuda) for _ in range(NSLOTS)]
+        self._ev = [torch.cuda.Event() for _ in range(NSLOTS)] if self.cuda else None
 
     def _a2a(self, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
-    def step(self, is_train=True, push_cnt=False):
-        """one synchronous step over the batch the backend has localized"""
-        be, G = self.be, self.world
-        keys, cnt = be.unique_keys()
-        bounds = be.key_ranges(G)                       # feaids[bounds[d]:bounds[d+1]] -> owner d
-        send = [int(bounds[d + 1] - bounds[d]) for d in range(G)]
-        # how many keys does every rank send me?
-        send_t = torch.tensor(send, dtype=torch.int64, device=self.device)
-        recv_t = torch.empty(G, dtype=torch.int64, device=self.device)
-        dist.all_to_all_single(recv_t, send_t, group=self.group)
-        recv = [int(x) for x in recv_t.cpu().tolist()]
-        nrecv, U = sum(recv), int(keys.numel())
+    def submit(self, data):
+        if len(self.queue) >= NSLOTS:
+            raise RuntimeError("at most %d minibatches in flight" % NSLOTS)
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % NSLOTS
+        self.be.submit(slot, data)
+        self.queue.append(_Pending(slot))
 
-        # 1. keys (and epoch-0 counts) to their owners
+    def _exchange_counts(self, p):
+        """how many keys does every rank send me?  (device -> pinned host, no host wait here)"""
+        b = self._bounds[p.slot]
+        self.be.bounds(p.slot, self.world, b)
+        send_t = b[1:] - b[:-1]
+        recv_t = torch.empty_like(send_t)
+        dist.all_to_all_single(recv_t, send_t, group=self.group)
+        h = self._hcnt[p.slot]
+        h[0].copy_(send_t, non_blocking=True)
+        h[1].copy_(recv_t, non_blocking=True)
+        if self.cuda:
+            self._ev[p.slot].record()
+        p.counted = True
+
+    def step(self, is_train=True, push_cnt=False):
+        """one synchronous step over the oldest submitted minibatch"""
+        be, G = self.be, self.world
+        p = self.queue.popleft()
+        slot = p.slot
+        if not p.counted:
+            self._exchange_counts(p)
+        if self.cuda:
+            self._ev[slot].synchronize()
+        send = self._hcnt[slot][0].tolist()
+        recv = self._hcnt[slot][1].tolist()
+        nrecv, U = sum(recv), sum(send)
+        keys, cnt = be.unique_keys(slot, U)
+
+        # 1. keys (and epoch-0 counts) to their owners; owners resolve them to table rows once
         rkeys = torch.empty(nrecv, dtype=torch.int64, device=self.device)
         self._a2a(rkeys, keys, recv, send)
-        roff = np.concatenate([[0], np.cumsum(recv)]).astype(np.int64)
+        roff = [0]
+        for n in recv:
+            roff.append(roff[-1] + n)
+        rowid = be.owner_resolve(rkeys)
         if push_cnt:
             rcnt = torch.empty(nrecv, dtype=torch.float32, device=self.device)
             self._a2a(rcnt, cnt, recv, send)
             for s in range(G):  # Push(kFeaCount), source rank after source rank
-                be.owner_push_count(rkeys[roff[s]:roff[s + 1]], rcnt[roff[s]:roff[s + 1]])
-        # 2. owners pull rows and send them back
+                if recv[s]:
+                    be.owner_push_count(rowid[roff[s]:roff[s + 1]], rkeys[roff[s]:roff[s + 1]], rcnt[roff[s]:roff[s + 1]])
+        # 2. owners pull rows (every source reads the same model version) and send them back
         rrows = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
-        for s in range(G):
-            be.owner_pull(rkeys[roff[s]:roff[s + 1]], rrows[roff[s]:roff[s + 1]])
+        if nrecv:
+            be.owner_pull(rowid, rkeys, rrows, roff)
         rows = torch.empty((U, self.stride), dtype=torch.float32, device=self.device)
         self._a2a(rows, rrows, send, recv)
         # 3. worker math on the pulled rows
-        be.forward(rows)
+        be.forward(slot, rows)
         if is_train:
             grads = torch.empty((U, self.stride), dtype=torch.float32, device=self.device)
-            be.backward(rows, grads)
+            be.backward(slot, rows, grads)
+        # the next minibatch's Localizer has been running beside this step: exchange its counts now,
+        # ahead of the gradient exchange, so that the next step() finds them on the host
+        if self.queue and not self.queue[0].counted:
+            self._exchange_counts(self.queue[0])
+        if is_train:
             # 4. gradients to the owners, applied in source-rank order
             rgrads = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
             self._a2a(rgrads, grads, recv, send)
             for s in range(G):
-                be.owner_push_grad(rkeys[roff[s]:roff[s + 1]], rgrads[roff[s]:roff[s + 1]])
-        return dict(unique=U, sent=send, received=recv)
+                if recv[s]:
+                    be.owner_push_grad(rowid[roff[s]:roff[s + 1]], rkeys[roff[s]:roff[s + 1]], rgrads[roff[s]:roff[s + 1]])
+        return dict(unique=U, sent=send, received=recv, slot=slot)
 
 
 # --------------------------------------------------------------------------- bench (N > 1)
@@ -193,14 +277,16 @@ def bench_main(args, rank, world, local_rank, hyper):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         build_hip()
     dist.barrier()
     B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
     span = key_span(world)
     # owned share of the id space (+ slack for imbalance and insert-on-miss)
-    cap = int(args.ids / world * 1.15) + 8 * B * S
+    cap = int(args.ids / world * 1.3) + 8 * B * S
     be = HipBackend(local_rank, k, cap, hyper, B, B * S)
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
@@ -220,21 +306,27 @@ def bench_main(args, rank, world, local_rank, hyper):
     dev = []
     for _ in range(nd):
         hb = gen.batch(B)
-        dev.append((torch.from_numpy(hb["offset"].astype(np.uint32).view(np.int32)).to(be.device),
-                    torch.from_numpy(hb["index"].view(np.int64)).to(be.device),
-                    torch.from_numpy(hb["label"]).to(be.device)))
+        dev.append(dict(device=True, nrows=B, nnz=B * S, value=None,
+                        offset=torch.from_numpy(hb["offset"].astype(np.uint32).view(np.int32)).to(be.device),
+                        index=torch.from_numpy(hb["index"].view(np.int64)).to(be.device),
+                        label=torch.from_numpy(hb["label"]).to(be.device)))
     worker = ShardedWorker(be)
+    total = args.warmup + args.steps
 
     def step(i):
-        o, x, l = dev[i % nd]
-        be.load_and_localize_device(B, B * S, o.data_ptr(), x.data_ptr(), None, l.data_ptr())
+        # the reader's overlap (sgd_learner.cc:196-224): minibatch i+1 is localized while i steps
+        if i + 1 < total:
+            worker.submit(dev[(i + 1) % nd])
         return worker.step(is_train=True, push_cnt=True)
 
+    worker.submit(dev[0])
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     dist.barrier()
     be.progress()
+    if not args.no_timing:
+        be.ctx.set_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         info = step(args.warmup + i)
@@ -243,6 +335,11 @@ def bench_main(args, rank, world, local_rank, hyper):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    timing = {}
+    if not args.no_timing:
+        timing = {n: round(ms / args.steps, 4) for n, (ms, calls) in be.ctx.get_timing(reset=True).items() if calls}
+        be.ctx.set_timing(False)
+    be.check()
     prog = be.progress()
     stats = torch.tensor([prog.loss, prog.nrows, float(info["unique"]), float(sum(info["sent"]) - info["sent"][rank])],
                          dtype=torch.float64, device=be.device)
@@ -266,6 +363,7 @@ def bench_main(args, rank, world, local_rank, hyper):
             "train_logloss_per_example": stats[0].item() / max(stats[1].item(), 1.0),
             "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
             "prefill_seconds": t_prefill,
+            "kernel_ms_per_step_rank0": timing,
         }
         print(json.dumps(out))
     be.close()

@@ -222,6 +222,23 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
  * partitioning ReverseBytes exists for (include/difacto/base.h:29-38).  HOST output
  * bounds[nparts+1]: shard d gets feaids[bounds[d] .. bounds[d+1]).  Synchronises. */
 int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds);
+/* the same bounds as int64 into DEVICE memory d_bounds[nparts+1], enqueued on the main
+ * stream after the batch's preparation; does not synchronise (d_bounds[nparts] = U) */
+int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, int64_t* d_bounds);
+
+/* Owner side in resolved form, for keys arriving from several source ranks in one step
+ * (StoreLocal::Push/Pull per source, src/store/store_local.h:24-44; SGDUpdater::Get/Update,
+ * src/sgd/sgd_updater.cc:32-102).  dfh_shard_resolve probes/inserts ALL received keys once
+ * (the same key may appear under several sources) and writes their row ids; Pull is then one
+ * gather over all of them; the two Push kinds take one source's slice at a time (keys unique
+ * inside a call) and are applied in call order.  V_init must be "hash". */
+int dfh_shard_resolve(dfh_table* t, const uint64_t* d_keys, size_t n, uint32_t* d_rowid);
+int dfh_shard_pull_resolved(dfh_table* t, const uint32_t* d_rowid, size_t n, float* d_rows);
+int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_cnt);
+int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_grads);
+/* fetch and report the table's sticky device-side error word (capacity, duplicate key,
+ * gradient with V for a row without V); synchronises */
+int dfh_table_check(dfh_table* t);
 
 /* raw device memory for hosts without a HIP runtime of their own */
 int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);

@@ -23,21 +23,26 @@ class OracleBackend:
         self.device = torch.device("cpu")
         self.loss = 0.0
         self.nrows = 0.0
+        self.slots = {}
 
-    # worker side
-    def load_and_localize(self, b):
-        self.b = b
-        self.loc = self.o.localize(b["offset"], b["index"])
+    # worker side (two minibatches may be in flight, like the HIP backend)
+    def submit(self, slot, b):
+        self.slots[slot] = dict(b=b, loc=self.o.localize(b["offset"], b["index"]))
 
-    def unique_keys(self):
-        return (torch.from_numpy(self.loc["feaids"].view(np.int64).copy()),
-                torch.from_numpy(self.loc["feacnt"].copy()))
+    def _use(self, slot):
+        self.b, self.loc = self.slots[slot]["b"], self.slots[slot]["loc"]
 
-    def key_ranges(self, world):
+    def unique_keys(self, slot, U):
+        loc = self.slots[slot]["loc"]
+        assert U == loc["U"]
+        return (torch.from_numpy(loc["feaids"].view(np.int64).copy()), torch.from_numpy(loc["feacnt"].copy()))
+
+    def bounds(self, slot, world, out):
+        loc = self.slots[slot]["loc"]
         span = U64MAX if world == 1 else U64MAX // world + 1
         firsts = np.array([min(d * span, U64MAX) for d in range(world)], dtype=np.uint64)
-        b = np.searchsorted(self.loc["feaids"], firsts, side="left").astype(np.int64)
-        return np.concatenate([b, [self.loc["U"]]])
+        b = np.searchsorted(loc["feaids"], firsts, side="left").astype(np.int64)
+        out.copy_(torch.from_numpy(np.concatenate([b, [loc["U"]]]).astype(np.int64)))
 
     def _ragged(self, rows):
         rows = rows.numpy()
@@ -52,7 +57,8 @@ class OracleBackend:
         W = np.concatenate(vals).astype(np.float32) if len(vals) else np.zeros(0, np.float32)
         return W, lens
 
-    def forward(self, rows):
+    def forward(self, slot, rows):
+        self._use(slot)
         W, lens = self._ragged(rows)
         self._W, self._lens = W, lens
         if self.V_dim:
@@ -63,7 +69,8 @@ class OracleBackend:
         self.loss += self.o.loss_evaluate(self.b["label"], self._pred)
         self.nrows += len(self._pred)
 
-    def backward(self, rows, grads):
+    def backward(self, slot, rows, grads):
+        self._use(slot)
         g = self.o.fm_calcgrad(self.V_dim, self.loc["offset"], self.loc["index"], self.b["value"], self.b["label"],
                                self._W, self._pred, self._wp, self._vp)
         out = grads.numpy()
@@ -78,17 +85,24 @@ class OracleBackend:
                 out[u, 4:4 + k] = g[p:p + k]
                 p += k
 
-    def pred(self):
+    def pred(self, slot=None):
         return self._pred
 
-    # owner side
-    def owner_push_count(self, keys, cnt):
+    # owner side ("resolved" interface of the HIP backend; the double keeps using keys)
+    def owner_resolve(self, keys):
+        return torch.zeros(keys.numel(), dtype=torch.int32)
+
+    def owner_push_count(self, rowid, keys, cnt):
         if keys.numel():
             self.store.push(keys.numpy().view(np.uint64), ob.FEA_COUNT, cnt.numpy())
 
-    def owner_pull(self, keys, rows):
-        if not keys.numel():
-            return
+    def owner_pull(self, rowid, keys, rows, seg):
+        # one Store::Pull per source rank (keys are unique only within a source)
+        for s in range(len(seg) - 1):
+            if seg[s + 1] > seg[s]:
+                self._pull(keys[seg[s]:seg[s + 1]], rows[seg[s]:seg[s + 1]])
+
+    def _pull(self, keys, rows):
         vals, lens = self.store.pull(keys.numpy().view(np.uint64))
         out = rows.numpy()
         out[:] = 0
@@ -102,7 +116,7 @@ class OracleBackend:
                 out[u, 4:4 + k] = vals[p:p + k]
                 p += k
 
-    def owner_push_grad(self, keys, grads):
+    def owner_push_grad(self, rowid, keys, grads):
         if not keys.numel():
             return
         g = grads.numpy()

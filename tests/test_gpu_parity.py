@@ -413,6 +413,71 @@ def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
         o.close()
 
 
+@pytest.mark.parametrize("V_dim", [0, 6, 64])
+def test_owner_resolved_calls_match_per_source_calls(capi, ctx, V_dim):
+    """keys arriving from several source ranks in one step (the same key under more than one
+    source): resolve-once + pull-all + per-source pushes on row ids == the per-source
+    dfh_shard_* calls (parity-tested above) applied in the same order"""
+    import torch
+    rng = np.random.default_rng(77 + V_dim)
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=2, V_init_scale=0.2, seed=9)
+    stride = capi.row_stride(V_dim)
+    dev = torch.device("cuda", 0)
+    ta = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # resolved calls
+    tb = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # per-source calls
+    universe = np.unique(rng.integers(0, 2 ** 64 - 1, 3000, dtype=np.uint64))
+    G = 4
+    for step in range(6):
+        srcs = [np.sort(rng.choice(universe, size=int(rng.integers(0 if step == 3 else 200, 900)), replace=False))
+                for _ in range(G)]
+        if step == 3:
+            srcs[1] = srcs[1][:0]  # a source with nothing for this owner
+        seg = np.concatenate([[0], np.cumsum([len(x) for x in srcs])]).astype(np.int64)
+        n = int(seg[-1])
+        keys = torch.from_numpy(np.concatenate(srcs).view(np.int64)).to(dev)
+        cnt = torch.from_numpy(rng.integers(1, 5, n).astype(np.float32)).to(dev)
+        rowid = torch.empty(n, dtype=torch.int32, device=dev)
+        rows_a = torch.zeros((n, stride), dtype=torch.float32, device=dev)
+        rows_b = torch.zeros((n, stride), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # the fixture's context runs on its own (non-blocking) stream
+        ta.shard_resolve(keys, n, rowid)
+        for s in range(G):
+            a, b = int(seg[s]), int(seg[s + 1])
+            if b > a and step < 3:
+                ta.shard_push_count_resolved(rowid[a:b], keys[a:b], b - a, cnt[a:b])
+                tb.shard_push_count(keys[a:b], b - a, cnt[a:b])
+        ta.shard_pull_resolved(rowid, n, rows_a)
+        for s in range(G):
+            a, b = int(seg[s]), int(seg[s + 1])
+            if b > a:
+                tb.shard_pull(keys[a:b], b - a, rows_b[a:b])
+        ctx.sync()
+        torch.cuda.synchronize()
+        assert torch.equal(rows_a, rows_b)
+        # gradient rows: [gw, has_V as pulled, 0, 0 | gV]
+        g = rng.normal(size=(n, stride)).astype(np.float32) * 0.5
+        g[rng.random(n) < 0.2, 0] = 0.0
+        g[:, 1] = rows_a[:, 1].cpu().numpy()
+        g[:, 2:4] = 0
+        grads = torch.from_numpy(g).to(dev)
+        torch.cuda.synchronize()
+        for s in range(G):
+            a, b = int(seg[s]), int(seg[s + 1])
+            if b > a:
+                ta.shard_push_grad_resolved(rowid[a:b], keys[a:b], b - a, grads[a:b])
+                tb.shard_push_grad(keys[a:b], b - a, grads[a:b])
+        ta.check()
+        tb.check()
+    va, la = ta.pull(universe)
+    vb, lb = tb.pull(universe)
+    assert np.array_equal(la, lb)
+    assert (la > 1).any() or V_dim == 0
+    assert_close(va, vb, rtol=1e-6, what="weights")
+    assert ta.size() == tb.size()
+    for o in (ta, tb):
+        o.close()
+
+
 def test_pipelined_prep_matches_serial(capi, oracle):
     """preparing batch t+1 on the second stream while batch t trains gives the
     same predictions and the same model as the serial order"""
@@ -476,15 +541,18 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
         ctx = capi.Context(0)
         tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
         bt = capi.Batch(ctx, 150, max_nnz)
-        for epoch in range(3):
-            for b in batches:
-                be.load_and_localize(b)
-                info = w.step(is_train=True, push_cnt=(epoch == 0))
-                bt.load_host(b["offset"], b["index"], b["value"], b["label"])
-                bt.localize()
-                bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
-                assert info["sent"] == info["received"] == [info["unique"]]
-                assert_close(be.pred(), bt.pred(), what="pred")
+        seq = [(epoch, b) for epoch in range(3) for b in batches]
+        w.submit(seq[0][1])
+        for i, (epoch, b) in enumerate(seq):
+            if i + 1 < len(seq):  # the next minibatch is localized on the preparation stream meanwhile
+                w.submit(seq[i + 1][1])
+            info = w.step(is_train=True, push_cnt=(epoch == 0))
+            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bt.localize()
+            bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+            assert info["sent"] == info["received"] == [info["unique"]]
+            assert_close(be.pred(info["slot"]), bt.pred(), what="pred")
+        be.check()
         keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
         va, la = tb.pull(keys)
         vb, lb = be.table.pull(keys)

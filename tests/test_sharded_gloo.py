@@ -36,8 +36,11 @@ def _worker(rank, world, port, out_dir):
     be = OracleBackend(V_DIM, HYPER)
     w = ShardedWorker(be)
     preds, infos = [], []
-    for i, b in enumerate(make_batches(rank)):
-        be.load_and_localize(b)
+    batches = make_batches(rank)
+    w.submit(batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):  # the next minibatch is localized (and its counts exchanged) during this step
+            w.submit(batches[i + 1])
         infos.append(w.step(is_train=True, push_cnt=(i < 2)))
         preds.append(be.pred().copy())
     # every rank owns a disjoint key range
