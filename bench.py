@@ -37,11 +37,16 @@ def parse_args():
     ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-pipeline", action="store_true", help="prepare and train on one stream")
+    ap.add_argument("--prep-streams", type=int, default=2,
+                    help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
+                         "keeps 2 in flight)")
     ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     return ap.parse_args()
 
+
+TIMING_EVERY = 4  # the forward kernel is timed with HIP events on every 4th step of the timed region
 
 HYPER = dict(l1=0.0, l2=0.0, V_l2=0.01, lr=0.01, lr_beta=1.0, V_lr=0.01, V_lr_beta=1.0, V_init_scale=0.01,
              V_threshold=0, seed=0)
@@ -157,37 +162,48 @@ def main():
         off32 = hb["offset"].astype(np.uint32)
         dev.append((capi.DeviceBuffer.from_numpy(ctx, off32), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
                     capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
-    # two batch objects: batch t+1 is copied in, localized and looked up on the
-    # preparation stream while batch t trains on the main stream
-    ctx.set_pipeline(not args.no_pipeline)
-    bts = [capi.Batch(ctx, B, B * S), capi.Batch(ctx, B, B * S)]
+    # depth+1 batch objects: batches t+1 .. t+depth are localized on the preparation streams while
+    # batch t trains on the main stream (updates are still applied strictly in batch order)
+    depth = 0 if args.no_pipeline else max(1, min(args.prep_streams, 4))
+    ctx.set_pipeline(depth)
+    ahead = max(depth, 1)
+    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + 1)]
     bt = bts[0]
 
     def prep(i):
         o, x, l = dev[i % nd]
-        b = bts[i % 2]
+        b = bts[i % len(bts)]
         b.attach_device(B, B * S, o.ptr, x.ptr, None, l.ptr)  # inputs are resident in HBM: no copy
         b.localize()
         if args.prep_lookup:
             b.lookup(table)
 
     def step(i):
-        prep(i + 1)
-        bts[i % 2].sgd_step(table, is_train=True, push_cnt=True)
+        prep(i + ahead)
+        bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=True)
 
-    prep(0)
+    for i in range(ahead - 1):
+        prep(i)
+    prep(ahead - 1)
     for i in range(args.warmup):
         step(i)
     ctx.sync()
     torch.cuda.synchronize()
     for b in bts:
         b.progress(reset=True)
-    if not args.no_timing:
-        ctx.set_timing(True)
-        ctx.get_timing(reset=True)
+    # live timing of the dominant kernel inside the timed region: HIP events around k_forward on
+    # every TIMING_EVERY-th step only (an event pair drains the stream, ~10 us; bracketing every kernel of
+    # every step would cost the job ~15 %)
+    fwd_mask = 0 if args.no_timing else (1 << capi.K_FORWARD)
+    ctx.get_timing(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        if fwd_mask and i % TIMING_EVERY == 0:
+            ctx.set_timing_mask(fwd_mask)
+            step(args.warmup + i)
+            ctx.set_timing_mask(0)
+        else:
+            step(args.warmup + i)
     ctx.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -196,7 +212,17 @@ def main():
     prog.loss = sum(p.loss for p in progs)
     prog.nrows = sum(p.nrows for p in progs)
     timing = {} if args.no_timing else ctx.get_timing(reset=True)
-    ctx.set_timing(False)
+    # per-kernel breakdown from a separate, fully instrumented pass (NOT part of the timed region)
+    breakdown = {}
+    if not args.no_timing:
+        nb_steps = min(args.steps, 50)
+        ctx.set_timing(True)
+        for i in range(nb_steps):
+            step(args.warmup + args.steps + i)
+        breakdown = {n: v[0] / nb_steps for n, v in ctx.get_timing(reset=True).items() if v[1] > 0}
+        ctx.set_timing(False)
+        for b in bts:
+            b.progress(reset=True)
     _, _, U_last = bt.shape()
 
     ex_per_s = args.steps * B / dt
@@ -207,7 +233,8 @@ def main():
         achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", kernel="k_forward", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<"),
-                        algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms)
+                        algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms,
+                        launches_timed=int(timing["forward"][1]))
     nb = args.cpu_batches
     cpu = None
     if nb != 0:
@@ -225,10 +252,11 @@ def main():
                    "rows_per_step": B, "nnz_per_row": S, "unique_keys_last_batch": int(U_last),
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
                    "model_keys": int(nkeys), "prefilled": not args.no_prefill, "hyper": HYPER,
-                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline},
+                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "kernel_ms_per_step": {n: (v[0] / max(args.steps, 1)) for n, v in timing.items() if v[1] > 0},
+        "kernel_ms_per_step": breakdown,
+        "kernel_ms_per_step_note": "separate instrumented pass after the timed region (HIP events around every kernel group)",
         "train_logloss_per_example": prog.loss / max(prog.nrows, 1),
         "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
         "prefill_seconds": t_prefill,

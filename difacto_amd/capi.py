@@ -25,9 +25,10 @@ SYMBOLS = [
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
-    "dfh_shard_push_grad_resolved", "dfh_table_check",
+    "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask",
 ]
 K_COUNT = 7
+K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
 
 
 class UpdaterParam(C.Structure):
@@ -136,6 +137,7 @@ def lib():
     L.dfh_shard_push_grad_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_table_check.argtypes = [vp]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
+    L.dfh_ctx_set_timing_mask.argtypes = [vp, C.c_uint32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
     L.dfh_kernel_name.argtypes = [i32]
@@ -187,11 +189,16 @@ class Context:
         _ck(lib().dfh_ctx_sync(self.h))
 
     def set_pipeline(self, on=True):
-        """prepare batch t+1 (copy, localize, lookup) on a second stream while batch t trains"""
-        _ck(lib().dfh_ctx_set_pipeline(self.h, 1 if on else 0))
+        """prepare later batches (copy, localize, lookup) on `on` preparation streams (True = 1)
+        while an earlier batch trains on the main stream"""
+        _ck(lib().dfh_ctx_set_pipeline(self.h, int(on)))
 
     def set_timing(self, on=True):
         _ck(lib().dfh_ctx_set_timing(self.h, 1 if on else 0))
+
+    def set_timing_mask(self, mask):
+        """time only the kernels whose bit (1 << K_*) is set"""
+        _ck(lib().dfh_ctx_set_timing_mask(self.h, mask))
 
     def get_timing(self, reset=True):
         """{kernel name: (total_ms, calls)} from HIP events on this context's stream"""

@@ -22,20 +22,18 @@ struct dfh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  // second stream for batch preparation (copies, Localizer, key lookup) so that
-  // batch t+1 is prepared while batch t trains; == stream unless pipelining is on
-  hipStream_t prep = nullptr;
-  hipStream_t prep_own = nullptr;
-  // auxiliary stream: the long-segment half of the backward pass runs beside the short-segment half
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // preparation streams (copies, Localizer, key lookup): with pipelining on, the batches being
+  // prepared take them round-robin while an earlier batch trains on `stream`
+  std::vector<hipStream_t> preps;
+  unsigned nprep = 0;       // streams in use (0: pipelining off, everything on `stream`)
+  unsigned next_prep = 0;
   bool pipeline = false;
   // monotonic scratch for the literal (host-pointer) calls
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int num_cu = 256;
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
-  bool timing = false;
+  uint32_t timing = 0;  // bit i: time kernel id i
   struct Span { int id; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
@@ -61,13 +59,13 @@ struct TimeScope {
     return e;
   }
   TimeScope(dfh_ctx* ctx, int kid, hipStream_t s = nullptr) : c(ctx), id(kid), st(s ? s : ctx->stream) {
-    if (!c->timing) return;
+    if (!((c->timing >> kid) & 1u)) return;
     a = get(c);
     b = get(c);
     if (a && b) (void)hipEventRecord(a, st);
   }
   ~TimeScope() {
-    if (!c->timing || !a || !b) return;
+    if (!a || !b) return;
     (void)hipEventRecord(b, st);
     c->spans.push_back({id, a, b});
   }
@@ -130,6 +128,7 @@ struct dfh_batch {
   // pipelining: prep-stream work -> ev_ready -> main-stream step -> ev_free -> next prep
   hipEvent_t ev_ready = nullptr, ev_free = nullptr;
   bool ready_pending = false, free_pending = false;
+  hipStream_t prep = nullptr;      // stream of the current preparation phase (load .. localize .. lookup)
   bool compute_auc = false;        // dfh_sgd_step also accumulates BinClassMetric::AUC per batch
   uint32_t *d_auc_keys = nullptr, *d_auc_skeys = nullptr, *d_auc_lab = nullptr, *d_auc_slab = nullptr;
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
@@ -138,19 +137,35 @@ struct dfh_batch {
 };
 
 namespace {
+// stream of the batch's current preparation phase
+inline hipStream_t prep_of(const dfh_batch* b) {
+  const dfh_ctx* c = b->ctx;
+  return (c->pipeline && b->prep) ? b->prep : c->stream;
+}
+// a new phase (a load / attach call) takes the next preparation stream
+void phase_begin(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  hipStream_t next = c->pipeline ? c->preps[c->next_prep++ % c->nprep] : nullptr;
+  if (next && b->prep && next != b->prep && b->ready_pending) {
+    // the previous phase's output was never consumed by a step: keep the two phases ordered
+    (void)hipStreamWaitEvent(next, b->ev_ready, 0);
+  }
+  b->prep = next;
+}
 // prep-stream work on a batch must not overwrite buffers a queued step still reads
 int prep_begin(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
-  if (c->prep != c->stream && b->free_pending) {
-    DFH_HIP(hipStreamWaitEvent(c->prep, b->ev_free, 0));
+  if (c->pipeline && !b->prep) phase_begin(b);
+  if (c->pipeline && b->free_pending) {
+    DFH_HIP(hipStreamWaitEvent(prep_of(b), b->ev_free, 0));
     b->free_pending = false;
   }
   return DFH_OK;
 }
 int prep_end(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
-  if (c->prep != c->stream) {
-    DFH_HIP(hipEventRecord(b->ev_ready, c->prep));
+  if (c->pipeline) {
+    DFH_HIP(hipEventRecord(b->ev_ready, prep_of(b)));
     b->ready_pending = true;
   }
   return DFH_OK;
@@ -165,15 +180,14 @@ int main_begin(dfh_batch* b) {
 }
 int main_end(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
-  if (c->prep != c->stream) {
+  if (c->pipeline) {
     DFH_HIP(hipEventRecord(b->ev_free, c->stream));
     b->free_pending = true;
   }
   return DFH_OK;
 }
 int sync_all(dfh_ctx* c) {
-  if (c->prep != c->stream) DFH_HIP(hipStreamSynchronize(c->prep));
-  DFH_HIP(hipStreamSynchronize(c->aux));
+  for (hipStream_t p : c->preps) DFH_HIP(hipStreamSynchronize(p));
   DFH_HIP(hipStreamSynchronize(c->stream));
   return DFH_OK;
 }
@@ -488,14 +502,6 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
     }
     c->own_stream = true;
   }
-  c->prep = c->stream;
-  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-    set_error("dfh_ctx_create: cannot create auxiliary stream/events");
-    delete c;
-    return DFH_ERR_HIP;
-  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   *out = c;
@@ -512,15 +518,9 @@ int dfh_ctx_destroy(dfh_ctx* c) {
     hipEventDestroy(sp.b);
   }
   for (auto e : c->pool) hipEventDestroy(e);
-  if (c->aux) {
-    hipStreamSynchronize(c->aux);
-    hipStreamDestroy(c->aux);
-    hipEventDestroy(c->ev_fork);
-    hipEventDestroy(c->ev_join);
-  }
-  if (c->prep_own) {
-    hipStreamSynchronize(c->prep_own);
-    hipStreamDestroy(c->prep_own);
+  for (hipStream_t p : c->preps) {
+    hipStreamSynchronize(p);
+    hipStreamDestroy(p);
   }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -534,22 +534,22 @@ int dfh_ctx_sync(dfh_ctx* c) {
 
 int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
   DFH_ARG(c, "ctx is NULL");
+  DFH_ARG(enable >= 0 && enable <= 4, "dfh_ctx_set_pipeline: 0 (off) .. 4 preparation streams");
   int rc = sync_all(c);
   if (rc) return rc;
-  if (enable) {
-    if (!c->prep_own) {
-      // highest priority: the preparation kernels are small and latency-bound; behind the wide
-      // forward/backward launches of the main stream their blocks would wait for free slots
-      int lo = 0, hi = 0;
-      DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const char* pr = getenv("DFH_PREP_PRIORITY");
-      int prio = pr ? atoi(pr) : hi;
-      DFH_HIP(hipStreamCreateWithPriority(&c->prep_own, hipStreamNonBlocking, prio));
-    }
-    c->prep = c->prep_own;
-  } else {
-    c->prep = c->stream;
+  while ((int)c->preps.size() < enable) {
+    // highest priority: the preparation kernels are small and latency-bound; behind the wide
+    // forward/backward launches of the main stream their blocks would wait for free slots
+    int lo = 0, hi = 0;
+    DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* pr = getenv("DFH_PREP_PRIORITY");
+    int prio = pr ? atoi(pr) : hi;
+    hipStream_t p = nullptr;
+    DFH_HIP(hipStreamCreateWithPriority(&p, hipStreamNonBlocking, prio));
+    c->preps.push_back(p);
   }
+  c->nprep = (unsigned)enable;
+  c->next_prep = 0;
   c->pipeline = enable != 0;
   return DFH_OK;
 }
@@ -558,7 +558,13 @@ int dfh_ctx_device(dfh_ctx* c) { return c ? c->device : -1; }
 
 int dfh_ctx_set_timing(dfh_ctx* c, int enable) {
   DFH_ARG(c, "ctx is NULL");
-  c->timing = enable != 0;
+  c->timing = enable ? ~0u : 0u;
+  return DFH_OK;
+}
+
+int dfh_ctx_set_timing_mask(dfh_ctx* c, uint32_t mask) {
+  DFH_ARG(c, "ctx is NULL");
+  c->timing = mask;
   return DFH_OK;
 }
 
@@ -1277,10 +1283,11 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   const size_t base = offset[0], nnz = off32[nrows];
   DFH_ARG(nnz <= b->max_nnz, "dfh_batch_load_host: nnz exceeds max_nnz");
   DFH_ARG(nnz == 0 || index, "index is NULL");
-  hipStream_t s = b->ctx->prep;
   DFH_HIP(hipSetDevice(b->ctx->device));
+  phase_begin(b);
   rc = prep_begin(b);
   if (rc) return rc;
+  hipStream_t s = prep_of(b);
   b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, index + base, nnz * 8, hipMemcpyHostToDevice, s));
@@ -1300,11 +1307,12 @@ int dfh_batch_load_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32_t
                           const float* d_value, const float* d_label) {
   DFH_ARG(b && d_offset && d_label && (nnz == 0 || d_index), "dfh_batch_load_device: NULL argument");
   DFH_ARG(nrows >= 1 && nrows <= b->max_rows && nnz <= b->max_nnz, "dfh_batch_load_device: shape out of range");
-  hipStream_t s = b->ctx->prep;
+  phase_begin(b);
   {
     int rc = prep_begin(b);
     if (rc) return rc;
   }
+  hipStream_t s = prep_of(b);
   b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   DFH_HIP(hipMemcpyAsync(b->d_offset, d_offset, (nrows + 1) * 4, hipMemcpyDeviceToDevice, s));
   if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, d_index, nnz * 8, hipMemcpyDeviceToDevice, s));
@@ -1323,6 +1331,7 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
                             const float* d_value, const float* d_label) {
   DFH_ARG(b && d_offset && d_label && (nnz == 0 || d_index), "dfh_batch_attach_device: NULL argument");
   DFH_ARG(nrows >= 1 && nrows <= b->max_rows && nnz <= b->max_nnz, "dfh_batch_attach_device: shape out of range");
+  phase_begin(b);
   {
     int rc = prep_begin(b);  // a queued step may still read the previously attached memory; nothing of ours is overwritten
     if (rc) return rc;
@@ -1344,12 +1353,12 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
   DFH_ARG(max_index != 0, "max_index must be nonzero");
   dfh_ctx* c = b->ctx;
-  hipStream_t s = c->prep;
   const uint32_t N = (uint32_t)b->nnz;
   {
     int rc = prep_begin(b);
     if (rc) return rc;
   }
+  hipStream_t s = prep_of(b);
   b->looked_up = nullptr;
   if (N == 0) {
     // reference would index an empty vector (localizer.cc:35); define: no keys
@@ -1456,10 +1465,11 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   int rc = prep_begin(b);
   if (rc) return rc;
   {
-    TimeScope ts(c, DFH_K_LOOKUP, c->prep);
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, c->prep, t->v, b->d_feaids, b->d_U, 0u,
+    hipStream_t ps = prep_of(b);
+    TimeScope ts(c, DFH_K_LOOKUP, ps);
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, t->v, b->d_feaids, b->d_U, 0u,
                        b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0);
-    hipLaunchKernelGGL(k_nnz_rows, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, c->prep, b->d_index, b->d_urow,
+    hipLaunchKernelGGL(k_nnz_rows, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, b->d_index, b->d_urow,
                        (uint32_t)b->nnz, b->d_nnz_row);
   }
   DFH_HIP(hipGetLastError());
@@ -1498,10 +1508,11 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
         if (value) s_val[q] = value[base + j];
       }
   }
-  hipStream_t s = b->ctx->prep;
   DFH_HIP(hipSetDevice(b->ctx->device));
+  phase_begin(b);
   rc = prep_begin(b);
   if (rc) return rc;
+  hipStream_t s = prep_of(b);
   b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
   b->looked_up = nullptr;
   uint32_t U32 = (uint32_t)U;
@@ -1609,7 +1620,7 @@ int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds) {
   uint32_t* d_bounds = static_cast<uint32_t*>(c->scratch);
   // span = ceil(2^64 / nparts): shard d owns keys in [d*span, (d+1)*span)
   const uint64_t span = nparts == 1 ? ~0ULL : (~0ULL / (uint64_t)nparts) + 1;
-  hipStream_t s = c->prep;
+  hipStream_t s = prep_of(b);
   if (b->nnz == 0) {
     for (int d = 0; d <= nparts; ++d) bounds[d] = 0;
     return DFH_OK;

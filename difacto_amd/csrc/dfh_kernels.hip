@@ -1017,13 +1017,13 @@ __device__ __forceinline__ uint32_t find_or_insert_shared(const TableView& t, ui
           atomicOr(t.err, 1u);
           r = t.capacity - 1;
         }
-        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the id is the whole message
         return r;
       }
       k = old;
     }
     if (k == key) {
-      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (r != 0xFFFFFFFFu) return r;
       continue;  // the winner of this slot is between its CAS and its store
     }
