@@ -167,7 +167,8 @@ def main():
     depth = 0 if args.no_pipeline else max(1, min(args.prep_streams, 4))
     ctx.set_pipeline(depth)
     ahead = max(depth, 1)
-    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + 1)]
+    # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
+    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + (2 if depth else 1))]
     bt = bts[0]
 
     def prep(i):
