@@ -177,9 +177,13 @@ class ShardedWorker:
     Localizer and the exchange of its per-destination key counts overlap step t, so a
     step waits on the host only for an event that was recorded long before."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, stage_through_host=False):
+        """stage_through_host: exchange through host copies (for process groups whose backend
+        cannot move device tensors, e.g. gloo when several ranks share one GPU in a test);
+        the product path exchanges device buffers over RCCL directly"""
         self.be = backend
         self.group = group
+        self.stage = bool(stage_through_host)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = backend.device
@@ -192,7 +196,15 @@ class ShardedWorker:
         self._hcnt = [torch.zeros((2, G), dtype=torch.int64, pin_memory=self.cuda) for _ in range(NSLOTS)]
         self._ev = [torch.cuda.Event() for _ in range(NSLOTS)] if self.cuda else None
 
-    def _a2a(self, out, inp, out_splits, in_splits):
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        if self.stage and inp.device.type != "cpu":
+            if self.cuda:
+                torch.cuda.current_stream().synchronize()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                   group=self.group)
+            out.copy_(h_out)
+            return
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
     def submit(self, data):
@@ -209,7 +221,7 @@ class ShardedWorker:
         self.be.bounds(p.slot, self.world, b)
         send_t = b[1:] - b[:-1]
         recv_t = torch.empty_like(send_t)
-        dist.all_to_all_single(recv_t, send_t, group=self.group)
+        self._a2a(recv_t, send_t)
         h = self._hcnt[p.slot]
         h[0].copy_(send_t, non_blocking=True)
         h[1].copy_(recv_t, non_blocking=True)

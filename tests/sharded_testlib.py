@@ -130,3 +130,31 @@ class OracleBackend:
             else:
                 lens.append(1)
         self.store.push(keys.numpy().view(np.uint64), ob.GRADIENT, np.concatenate(vals), np.array(lens, np.int32) if k else None)
+
+
+def emulate_single_store(oracle, batches, V_dim, hyper, push_cnt_steps):
+    """what the sharded step must equal: ONE store receiving, per step, all count pushes (source
+    rank order), then all pulls (same model version), then all gradient pushes (source rank order).
+    batches[r][i] = minibatch of rank r at step i.  Returns (store, preds[r][i], loss[r])."""
+    world, steps = len(batches), len(batches[0])
+    store = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
+    preds = [[] for _ in range(world)]
+    loss = [0.0] * world
+    for i in range(steps):
+        locs = [oracle.localize(batches[r][i]["offset"], batches[r][i]["index"]) for r in range(world)]
+        if i < push_cnt_steps:
+            for r in range(world):
+                store.push(locs[r]["feaids"], ob.FEA_COUNT, locs[r]["feacnt"])
+        pulled = [store.pull(locs[r]["feaids"]) for r in range(world)]
+        grads = []
+        for r in range(world):
+            b, loc = batches[r][i], locs[r]
+            vals, lens = pulled[r]
+            wp, vp = oracle.get_pos(lens)
+            p = oracle.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], vals, wp, vp)
+            preds[r].append(p)
+            loss[r] += oracle.loss_evaluate(b["label"], p)
+            grads.append(oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp))
+        for r in range(world):
+            store.push(locs[r]["feaids"], ob.GRADIENT, grads[r], pulled[r][1])
+    return store, preds, loss

@@ -62,28 +62,9 @@ def test_sharded_world2_matches_single_store(tmp_path, oracle):
     port = 29600 + (os.getpid() % 300)
     mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
 
-    # single-store emulation: per step all count pushes (rank order), all pulls, all gradient pushes (rank order)
-    store = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=V_DIM, **HYPER)
+    from sharded_testlib import emulate_single_store
     batches = [make_batches(r) for r in range(WORLD)]
-    preds = [[] for _ in range(WORLD)]
-    loss = [0.0] * WORLD
-    for i in range(STEPS):
-        locs = [oracle.localize(batches[r][i]["offset"], batches[r][i]["index"]) for r in range(WORLD)]
-        if i < 2:
-            for r in range(WORLD):
-                store.push(locs[r]["feaids"], ob.FEA_COUNT, locs[r]["feacnt"])
-        pulled = [store.pull(locs[r]["feaids"]) for r in range(WORLD)]
-        grads = []
-        for r in range(WORLD):
-            b, loc = batches[r][i], locs[r]
-            vals, lens = pulled[r]
-            wp, vp = oracle.get_pos(lens)
-            p = oracle.fm_predict(V_DIM, loc["offset"], loc["index"], b["value"], vals, wp, vp)
-            preds[r].append(p)
-            loss[r] += oracle.loss_evaluate(b["label"], p)
-            grads.append(oracle.fm_calcgrad(V_DIM, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp))
-        for r in range(WORLD):
-            store.push(locs[r]["feaids"], ob.GRADIENT, grads[r], pulled[r][1])
+    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2)
 
     total_keys = 0
     for r in range(WORLD):

@@ -1,0 +1,86 @@
+"""The N>1 path with the PRODUCT backend (HIP kernels through the C ABI) and two ranks that
+share the one GPU of the test box: the exchange runs over gloo with host staging (RCCL cannot
+put two ranks on one device), everything else — Localizer, key-range split, resolve / pull /
+push on the owner side, forward / backward on packed rows — is the code the 8-GPU job runs.
+Checked against a single oracle store that receives the same pushes in the same order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HYPER = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=5)
+V_DIM = 8
+STEPS = 5
+ROWS = 300
+
+
+def make_batches(rank):
+    from conftest import random_batch
+    rng = np.random.default_rng(700 + rank)
+    return [random_batch(rng, ROWS, 2 ** 64 - 1 if i % 2 else 3000, 30, binary=(i % 2 == 0)) for i in range(STEPS)]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from difacto_amd import sharded
+    batches = make_batches(rank)
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    be = sharded.HipBackend(0, V_DIM, 1 << 16, HYPER, ROWS, max_nnz)
+    w = sharded.ShardedWorker(be, stage_through_host=True)
+    preds, infos = [], []
+    w.submit(batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            w.submit(batches[i + 1])
+        info = w.step(is_train=True, push_cnt=(i < 2))
+        infos.append(info)
+        preds.append(be.pred(info["slot"]).copy())
+    be.check()
+    prog = be.progress()
+    from oracle import bindings as ob
+    o = ob.Oracle()
+    allkeys = np.unique(np.concatenate([o.localize(b["offset"], b["index"])["feaids"]
+                                        for r in range(world) for b in make_batches(r)]))
+    span = (2 ** 64 - 1) // world + 1
+    mine = allkeys[(allkeys // np.uint64(span)) == np.uint64(rank)]
+    nkeys = be.table.size()
+    vals, lens = be.table.pull(mine)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=prog.loss, nkeys=nkeys,
+             sent=np.array([x["sent"] for x in infos]), recv=np.array([x["received"] for x in infos]),
+             keys=mine, vals=vals, lens=lens)
+    dist.barrier()
+    be.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("WORLD", [2, 4])
+def test_sharded_hip_ranks_share_one_gpu(tmp_path, oracle, WORLD):
+    from sharded_testlib import emulate_single_store
+    port = 29900 + (os.getpid() % 90) + WORLD
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    batches = [make_batches(r) for r in range(WORLD)]
+    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2)
+    total = 0
+    for r in range(WORLD):
+        got = np.load(os.path.join(tmp_path, "rank%d.npz" % r))
+        np.testing.assert_allclose(got["preds"], np.concatenate(preds[r]), rtol=1e-5, atol=1e-6, err_msg="rank %d preds" % r)
+        assert float(got["loss"]) == pytest.approx(loss[r], rel=1e-5)
+        other = (r + 1) % WORLD
+        assert got["sent"][:, other].sum() > 0 and got["recv"][:, other].sum() > 0  # the exchange crossed ranks
+        vals, lens = store.pull(got["keys"])
+        assert np.array_equal(got["lens"], lens)
+        np.testing.assert_allclose(got["vals"], vals, rtol=2e-5, atol=1e-6, err_msg="rank %d owned model" % r)
+        assert np.any(lens > 1)
+        total += int(got["nkeys"])
+    assert total == store.size()
