@@ -41,6 +41,8 @@ def parse_args():
                     help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
                          "keeps 2 in flight)")
     ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
+    ap.add_argument("--uniform-ranges", action="store_true",
+                    help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     return ap.parse_args()

@@ -130,7 +130,7 @@ def lib():
     L.dfh_batch_lookup.argtypes = [vp, vp]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
-    L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp]
+    L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp, vp]
     L.dfh_shard_resolve.argtypes = [vp, vp, sz, vp]
     L.dfh_shard_pull_resolved.argtypes = [vp, vp, sz, vp]
     L.dfh_shard_push_count_resolved.argtypes = [vp, vp, vp, sz, vp]
@@ -455,8 +455,8 @@ class Batch:
         _ck(lib().dfh_batch_device_keys(self.h, C.byref(a), C.byref(b), None))
         return a.value, b.value
 
-    def key_ranges_device(self, nparts, d_bounds):
-        _ck(lib().dfh_batch_key_ranges_device(self.h, nparts, _dp(d_bounds)))
+    def key_ranges_device(self, nparts, d_bounds, d_splits=None):
+        _ck(lib().dfh_batch_key_ranges_device(self.h, nparts, _dp(d_splits), _dp(d_bounds)))
 
 
 class DeviceBuffer:

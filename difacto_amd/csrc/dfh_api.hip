@@ -1600,14 +1600,14 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
   return DFH_OK;
 }
 
-int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, int64_t* d_bounds) {
+int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, const uint64_t* d_splits, int64_t* d_bounds) {
   DFH_ARG(b && b->localized && d_bounds && nparts >= 1 && nparts <= 1024, "dfh_batch_key_ranges_device: bad argument");
   dfh_ctx* c = b->ctx;
   int rc = main_begin(b);
   if (rc) return rc;
   const uint64_t span = nparts == 1 ? ~0ULL : (~0ULL / (uint64_t)nparts) + 1;
   hipLaunchKernelGGL(k_key_ranges64, dim3((nparts + 256) / 256), dim3(256), 0, c->stream, b->d_feaids, b->d_U, nparts, span,
-                     d_bounds, (uint32_t)(b->nnz == 0));
+                     d_splits, d_bounds, (uint32_t)(b->nnz == 0));
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }

@@ -1346,8 +1346,10 @@ __global__ void __launch_bounds__(256) k_warm_start(TableView t, const uint64_t*
 
 // feacnt[u] = segment length (float), for reading the localizer's output back
 // the same bounds as int64 in caller-owned device memory (asynchronous sharded step)
+// splits != NULL: shard d (d >= 1) starts at key splits[d-1] (ascending) instead of d*span
 __global__ void k_key_ranges64(const uint64_t* __restrict__ feaids, const uint32_t* __restrict__ d_U, int nparts,
-                               uint64_t span, int64_t* __restrict__ bounds, uint32_t empty) {
+                               uint64_t span, const uint64_t* __restrict__ splits, int64_t* __restrict__ bounds,
+                               uint32_t empty) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d > nparts) return;
   const uint32_t U = empty ? 0u : *d_U;
@@ -1355,7 +1357,7 @@ __global__ void k_key_ranges64(const uint64_t* __restrict__ feaids, const uint32
     bounds[d] = U;
     return;
   }
-  const uint64_t first = (uint64_t)d * span;
+  const uint64_t first = d == 0 ? 0ULL : (splits ? splits[d - 1] : (uint64_t)d * span);
   uint32_t lo = 0, hi = U;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;

@@ -48,6 +48,28 @@ def key_span(world):
     return U64MAX if world == 1 else U64MAX // world + 1
 
 
+def uniform_splits(world):
+    """first keys of shards 1 .. world-1 under the uniform partition"""
+    return np.array([d * key_span(world) for d in range(1, world)], dtype=np.uint64)
+
+
+def balanced_splits(sample_keys, world):
+    """first keys of shards 1 .. world-1 such that every shard owns the same share of
+    `sample_keys` (a sample of the id space, identical on every rank).  Feature-group ids
+    live in the top bits of a reversed key (EncodeFeaGrpID + ReverseBytes, base.h:39-63), so
+    the uniform partition of a 39-group id space gives one shard 2.3x the average at world 8."""
+    s = np.sort(np.asarray(sample_keys, dtype=np.uint64))
+    if world == 1 or len(s) == 0:
+        return np.zeros(0, np.uint64)
+    q = [(len(s) * d) // world for d in range(1, world)]
+    return s[q].astype(np.uint64)
+
+
+def owner_of(keys, splits):
+    """shard index of every (reversed) key"""
+    return np.searchsorted(np.asarray(splits, dtype=np.uint64), np.asarray(keys, dtype=np.uint64), side="right")
+
+
 class _DevPtr:
     """expose a raw device pointer to torch through __cuda_array_interface__"""
 
@@ -102,9 +124,10 @@ class HipBackend:
             b.load_host(data["offset"], data["index"], data["value"], data["label"])
         b.localize()
 
-    def bounds(self, slot, world, out):
-        """out[world+1] (int64, device): keys of shard d are feaids[out[d]:out[d+1]]; asynchronous"""
-        self.batches[slot].key_ranges_device(world, out)
+    def bounds(self, slot, world, out, splits=None):
+        """out[world+1] (int64, device): keys of shard d are feaids[out[d]:out[d+1]]; asynchronous.
+        splits: device int64 tensor with the bit patterns of the world-1 first keys, or None (uniform)"""
+        self.batches[slot].key_ranges_device(world, out, splits)
 
     def unique_keys(self, slot, U):
         """-> (keys int64 tensor [U] (bit pattern of the u64 keys), counts float32 [U])"""
@@ -177,8 +200,9 @@ class ShardedWorker:
     Localizer and the exchange of its per-destination key counts overlap step t, so a
     step waits on the host only for an event that was recorded long before."""
 
-    def __init__(self, backend, group=None, stage_through_host=False):
-        """stage_through_host: exchange through host copies (for process groups whose backend
+    def __init__(self, backend, group=None, stage_through_host=False, splits=None):
+        """splits: np.uint64[world-1] first keys of shards 1.. (identical on all ranks); None =
+        the uniform partition.  stage_through_host: exchange through host copies (for process groups whose backend
         cannot move device tensors, e.g. gloo when several ranks share one GPU in a test);
         the product path exchanges device buffers over RCCL directly"""
         self.be = backend
@@ -195,6 +219,12 @@ class ShardedWorker:
         self._bounds = [torch.zeros(G + 1, dtype=torch.int64, device=self.device) for _ in range(NSLOTS)]
         self._hcnt = [torch.zeros((2, G), dtype=torch.int64, pin_memory=self.cuda) for _ in range(NSLOTS)]
         self._ev = [torch.cuda.Event() for _ in range(NSLOTS)] if self.cuda else None
+        self.splits = None
+        if splits is not None and G > 1:
+            sp = np.ascontiguousarray(np.asarray(splits, dtype=np.uint64))
+            if len(sp) != G - 1 or np.any(sp[1:] < sp[:-1]):
+                raise ValueError("splits must be world-1 ascending keys")
+            self.splits = torch.from_numpy(sp.view(np.int64).copy()).to(self.device)
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         if self.stage and inp.device.type != "cpu":
@@ -218,7 +248,7 @@ class ShardedWorker:
     def _exchange_counts(self, p):
         """how many keys does every rank send me?  (device -> pinned host, no host wait here)"""
         b = self._bounds[p.slot]
-        self.be.bounds(p.slot, self.world, b)
+        self.be.bounds(p.slot, self.world, b, self.splits)
         send_t = b[1:] - b[:-1]
         recv_t = torch.empty_like(send_t)
         self._a2a(recv_t, send_t)
@@ -300,29 +330,47 @@ def bench_main(args, rank, world, local_rank, hyper):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # DFH_BENCH_BACKEND=gloo: functional dry run of this very code on a box with fewer GPUs than ranks
+    # (ranks share devices, the exchange is staged through the host); numbers from it mean nothing
+    dry = os.environ.get("DFH_BENCH_BACKEND", "nccl") == "gloo"
+    if dry:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if dry:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         build_hip()
     dist.barrier()
     B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
-    span = key_span(world)
-    # owned share of the id space (+ slack for imbalance and insert-on-miss)
-    cap = int(args.ids / world * 1.3) + 8 * B * S
-    be = HipBackend(local_rank, k, cap, hyper, B, B * S)
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
+    # key ranges balanced on the id space (every rank derives the same split keys): the feature-group id
+    # sits in the top bits of a reversed key, so uniform ranges would give one shard 2.3x the average
+    splits = None
+    if world > 1 and not args.uniform_ranges:
+        splits = balanced_splits(np.concatenate([synth.reverse_bytes_np(gen.all_ids(g))[::61] for g in range(S)]), world)
+    elif world > 1:
+        splits = uniform_splits(world)
+    mine = []
+    for g in range(S):
+        keys = synth.reverse_bytes_np(gen.all_ids(g))
+        mine.append(keys[owner_of(keys, splits) == rank] if world > 1 else keys)
+    owned = sum(len(m) for m in mine)
+    # owned share of the id space + slack for insert-on-miss
+    cap = int(owned * 1.05) + 8 * B * S
+    be = HipBackend(local_rank, k, cap, hyper, B, B * S)
     if not args.no_prefill:
-        for g in range(S):
-            keys = synth.reverse_bytes_np(gen.all_ids(g))
-            mine = keys[(keys // np.uint64(span)) == np.uint64(rank)] if world > 1 else keys
-            chunk = 1 << 22
-            for o in range(0, len(mine), chunk):
-                part = torch.from_numpy(np.ascontiguousarray(mine[o:o + chunk]).view(np.int64)).to(be.device)
+        chunk = 1 << 22
+        for m in mine:
+            for o in range(0, len(m), chunk):
+                part = torch.from_numpy(np.ascontiguousarray(m[o:o + chunk]).view(np.int64)).to(be.device)
                 be.table.warm_start(part.data_ptr(), part.numel(), w0=0.01, cnt0=100.0)
                 be.sync()
+    del mine
     t_prefill = time.time() - t0
     # every rank draws its own stream of minibatches (different data parts, sgd_learner.cc:78-89)
     gen.rng = np.random.default_rng(1000 + rank)
@@ -334,7 +382,7 @@ def bench_main(args, rank, world, local_rank, hyper):
                         offset=torch.from_numpy(hb["offset"].astype(np.uint32).view(np.int32)).to(be.device),
                         index=torch.from_numpy(hb["index"].view(np.int64)).to(be.device),
                         label=torch.from_numpy(hb["label"]).to(be.device)))
-    worker = ShardedWorker(be)
+    worker = ShardedWorker(be, stage_through_host=dry, splits=splits)
     extra = 0 if args.no_timing else min(args.steps, 30)  # instrumented pass after the timed region
     total = args.warmup + args.steps + extra
 
@@ -385,7 +433,9 @@ def bench_main(args, rank, world, local_rank, hyper):
                        "step": "device localize + key/row/gradient all_to_all_v + predict + calcgrad + in-place update",
                        "avg_unique_keys_per_batch": stats[2].item() / world,
                        "avg_remote_keys_per_batch": stats[3].item() / world,
-                       "prefilled": not args.no_prefill, "hyper": hyper},
+                       "prefilled": not args.no_prefill, "hyper": hyper, "dry_run_shared_gpu": dry,
+                       "key_ranges": "uniform" if args.uniform_ranges else "balanced on the id space",
+                       "owned_keys_rank0": int(owned)},
             "roofline": None, "cpu_baseline": None,
             "train_logloss_per_example": stats[0].item() / max(stats[1].item(), 1.0),
             "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,

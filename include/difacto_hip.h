@@ -227,8 +227,12 @@ int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float**
  * bounds[nparts+1]: shard d gets feaids[bounds[d] .. bounds[d+1]).  Synchronises. */
 int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds);
 /* the same bounds as int64 into DEVICE memory d_bounds[nparts+1], enqueued on the main
- * stream after the batch's preparation; does not synchronise (d_bounds[nparts] = U) */
-int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, int64_t* d_bounds);
+ * stream after the batch's preparation; does not synchronise (d_bounds[nparts] = U).
+ * d_splits == NULL: the uniform partition above.  Otherwise d_splits[nparts-1] (device,
+ * ascending): shard d >= 1 owns keys in [d_splits[d-1], d_splits[d]) — still contiguous key
+ * ranges, with boundaries the caller balanced for its id space (feature-group ids sit in the
+ * top bits of a reversed key, base.h:60-63, so uniform ranges can be badly skewed). */
+int dfh_batch_key_ranges_device(dfh_batch* b, int nparts, const uint64_t* d_splits, int64_t* d_bounds);
 
 /* Owner side in resolved form, for keys arriving from several source ranks in one step
  * (StoreLocal::Push/Pull per source, src/store/store_local.h:24-44; SGDUpdater::Get/Update,

@@ -37,10 +37,12 @@ class OracleBackend:
         assert U == loc["U"]
         return (torch.from_numpy(loc["feaids"].view(np.int64).copy()), torch.from_numpy(loc["feacnt"].copy()))
 
-    def bounds(self, slot, world, out):
+    def bounds(self, slot, world, out, splits=None):
         loc = self.slots[slot]["loc"]
         span = U64MAX if world == 1 else U64MAX // world + 1
         firsts = np.array([min(d * span, U64MAX) for d in range(world)], dtype=np.uint64)
+        if splits is not None:
+            firsts[1:] = splits.numpy().view(np.uint64)
         b = np.searchsorted(loc["feaids"], firsts, side="left").astype(np.int64)
         out.copy_(torch.from_numpy(np.concatenate([b, [loc["U"]]]).astype(np.int64)))
 

@@ -27,14 +27,25 @@ def make_batches(rank):
     return [random_batch(rng, 60, 2 ** 64 - 1 if i % 2 else 400, 12, binary=(i % 2 == 0)) for i in range(STEPS)]
 
 
-def _worker(rank, world, port, out_dir):
+def _splits(kind):
+    """None = uniform ranges; "balanced" = split keys balanced on the keys the batches hold"""
+    if kind != "balanced":
+        return None
+    from difacto_amd.sharded import balanced_splits
+    from difacto_amd.synth import reverse_bytes_np
+    ids = np.concatenate([b["index"] for r in range(WORLD) for b in make_batches(r)])
+    return balanced_splits(reverse_bytes_np(ids), WORLD)
+
+
+def _worker(rank, world, port, out_dir, kind):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from difacto_amd.sharded import ShardedWorker
     from sharded_testlib import OracleBackend
     be = OracleBackend(V_DIM, HYPER)
-    w = ShardedWorker(be)
+    splits = _splits(kind)
+    w = ShardedWorker(be, splits=splits)
     preds, infos = [], []
     batches = make_batches(rank)
     w.submit(batches[0])
@@ -49,18 +60,19 @@ def _worker(rank, world, port, out_dir):
     # final owned model, key by key
     allkeys = np.unique(np.concatenate([be.o.localize(b["offset"], b["index"])["feaids"]
                                         for r in range(world) for b in make_batches(r)]))
-    span = (2 ** 64 - 1) // world + 1
-    mine = allkeys[(allkeys // np.uint64(span)) == np.uint64(rank)]
+    from difacto_amd.sharded import owner_of, uniform_splits
+    mine = allkeys[owner_of(allkeys, uniform_splits(world) if splits is None else splits) == rank]
     vals, lens = be.store.pull(mine)
     np.savez(os.path.join(out_dir, "model%d.npz" % rank), keys=mine, vals=vals, lens=lens)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_world2_matches_single_store(tmp_path, oracle):
+@pytest.mark.parametrize("kind", ["uniform", "balanced"])
+def test_sharded_world2_matches_single_store(tmp_path, oracle, kind):
     from oracle import bindings as ob
-    port = 29600 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    port = 29600 + (os.getpid() % 300) + (7 if kind == "balanced" else 0)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), kind), nprocs=WORLD, join=True)
 
     from sharded_testlib import emulate_single_store
     batches = [make_batches(r) for r in range(WORLD)]
@@ -91,3 +103,21 @@ def test_key_span_partition_is_contiguous_and_total():
         owner = (keys // np.uint64(span)).astype(np.int64) if world > 1 else np.zeros(len(keys), np.int64)
         assert owner.min() >= 0 and owner.max() < world
         assert np.all(np.diff(owner) >= 0)  # ascending keys -> contiguous slices per owner
+
+
+def test_balanced_splits_even_out_a_grouped_id_space():
+    """ids carrying a feature-group id in their low bits (EncodeFeaGrpID, base.h:60-63): after
+    ReverseBytes the group sits in the top bits and uniform ranges are skewed; balanced splits are not"""
+    from difacto_amd.sharded import balanced_splits, owner_of, uniform_splits
+    from difacto_amd.synth import reverse_bytes_np
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(1000, 60000, size=39)
+    ids = np.concatenate([(rng.integers(0, 2 ** 52, size=n, dtype=np.uint64) << np.uint64(12)) | np.uint64(g)
+                          for g, n in enumerate(sizes)])
+    keys = reverse_bytes_np(ids)
+    for world in (2, 4, 8):
+        uni = np.bincount(owner_of(keys, uniform_splits(world)), minlength=world)
+        bal = np.bincount(owner_of(keys, balanced_splits(keys[::7], world)), minlength=world)
+        assert bal.sum() == uni.sum() == len(keys)
+        assert bal.max() / bal.mean() < 1.05
+        assert uni.max() / uni.mean() > bal.max() / bal.mean()

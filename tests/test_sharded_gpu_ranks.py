@@ -36,7 +36,12 @@ def _worker(rank, world, port, out_dir):
     batches = make_batches(rank)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     be = sharded.HipBackend(0, V_DIM, 1 << 16, HYPER, ROWS, max_nnz)
-    w = sharded.ShardedWorker(be, stage_through_host=True)
+    from difacto_amd.synth import reverse_bytes_np
+    splits = None
+    if world == 4:  # one of the two cases runs with split keys balanced on the data instead of uniform ranges
+        ids = np.concatenate([b["index"] for r in range(world) for b in make_batches(r)])
+        splits = sharded.balanced_splits(reverse_bytes_np(ids), world)
+    w = sharded.ShardedWorker(be, stage_through_host=True, splits=splits)
     preds, infos = [], []
     w.submit(batches[0])
     for i in range(len(batches)):
@@ -51,8 +56,7 @@ def _worker(rank, world, port, out_dir):
     o = ob.Oracle()
     allkeys = np.unique(np.concatenate([o.localize(b["offset"], b["index"])["feaids"]
                                         for r in range(world) for b in make_batches(r)]))
-    span = (2 ** 64 - 1) // world + 1
-    mine = allkeys[(allkeys // np.uint64(span)) == np.uint64(rank)]
+    mine = allkeys[sharded.owner_of(allkeys, sharded.uniform_splits(world) if splits is None else splits) == rank]
     nkeys = be.table.size()
     vals, lens = be.table.pull(mine)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=prog.loss, nkeys=nkeys,
