@@ -260,12 +260,12 @@ def test_table_export_import_roundtrip(capi, ctx, oracle):
 
 
 # ------------------------------------------------------------------ the fused step
-def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True):
+def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True, capacity=1 << 16):
     from oracle import bindings as ob
     om = ob.INIT_HASH if mode == "hash" else ob.INIT_REFRAND
     dm = capi.INIT_HASH if mode == "hash" else capi.INIT_REFRAND
     so = oracle.store_create(init_mode=om, V_dim=V_dim, **kw)
-    tb = capi.Table(ctx, 1 << 16, V_dim=V_dim, init_mode=dm, **kw)
+    tb = capi.Table(ctx, capacity, V_dim=V_dim, init_mode=dm, **kw)
     max_rows = max(len(b["label"]) for b in batches)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     bt = capi.Batch(ctx, max_rows, max(max_nnz, 1))
@@ -281,11 +281,32 @@ def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, de
             bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
             pg = bt.pred()
             prog_g = bt.progress(reset=True)
+            if epoch == 0:  # the step's own count push precedes its pull (sgd_learner.cc:214-217)
+                so.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
+            pv, pl = so.pull(loc["feaids"])  # the weights this step will see, for an fp64 penalty
             po, prog_o = so.sgd_step(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"],
-                                     feacnt=loc["feacnt"] if epoch == 0 else None, is_train=True)
+                                     feacnt=None, is_train=True)
             assert_close(pg, po, rtol=5e-5, what="pred epoch %d" % epoch)
-            assert prog_g.loss == pytest.approx(prog_o.loss, rel=2e-5)
-            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=1e-4, abs=1e-6)
+            # Loss::Evaluate sums n terms in fp32 (loss.h:57-66), the device in fp64: allow the
+            # reference its own rounding, ~n * eps / 6 (observed 2.6e-5 at n = 10 000)
+            assert prog_g.loss == pytest.approx(prog_o.loss, rel=2e-5 + 1e-8 * len(b["label"]))
+            # EvaluatePenalty (sgd_learner.cc:249-273) adds U*(1+V_dim) small terms into one fp32
+            # scalar; at 9.5 M terms whole addends fall below half an ulp of the running sum and the
+            # reference comes out 1 % low.  The device keeps fp64 partials: check it against the
+            # exact value, and the reference within its own rounding.
+            if V_dim == 0:  # lens is empty: one value per key
+                w64, v64 = pv.astype(np.float64), np.zeros(0)
+            else:
+                starts = np.concatenate([[0], np.cumsum(pl)[:-1]]).astype(np.int64)
+                w64 = pv[starts].astype(np.float64)
+                is_w = np.zeros(len(pv), bool)
+                is_w[starts] = True
+                v64 = pv[~is_w].astype(np.float64)
+            exact = kw.get("l1", 0.0) * np.abs(w64).sum() + 0.5 * kw.get("l2", 0.0) * (w64 ** 2).sum() \
+                + 0.5 * kw.get("V_l2", 0.0) * (v64 ** 2).sum()
+            assert prog_g.penalty == pytest.approx(exact, rel=2e-5, abs=1e-6)
+            nterms = loc["U"] * (1 + V_dim)
+            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=1e-4 if nterms < 1e5 else 0.05, abs=1e-6)
             assert prog_g.nrows == prog_o.nrows
     # final model state, key by key
     allkeys = np.unique(np.concatenate([l["feaids"] for l in locs]))
@@ -307,6 +328,39 @@ def test_fused_step_vs_oracle(capi, ctx, oracle, V_dim, mode):
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=1, V_init_scale=0.2, seed=9)
     n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, 3, kw)
     assert (n_with_v > 0) == (V_dim > 0)
+
+
+def test_full_size_c3_minibatches(capi, ctx, oracle):
+    """BASELINE.json's C3 shape at full size: 10 000 rows x 39 slots drawn from the 33 M id space,
+    V_dim = 64.  The Localizer is compared bit for bit with the oracle AND through properties that
+    need no oracle (sortedness, inverse mapping, count checksum, idempotence); then two epochs of the
+    fused step (FTRL + AdaGrad + lazy InitV, hot keys with ~1000 occurrences) against the oracle."""
+    from difacto_amd import synth
+    gen = synth.CriteoSynth(total_ids=33_000_000, seed=42)
+    batches = [gen.batch(10000) for _ in range(2)]
+    nnz = int(batches[0]["offset"][-1])
+    assert nnz == 10000 * synth.NUM_SLOTS
+    bt = capi.Batch(ctx, 10000, nnz)
+    for b in batches:
+        bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+        bt.localize()
+        got = bt.get_localized()
+        want = oracle.localize(b["offset"], b["index"])
+        assert got["U"] == want["U"] and got["U"] > 100000
+        assert np.array_equal(got["feaids"], want["feaids"])
+        assert np.array_equal(got["feacnt"], want["feacnt"])
+        assert np.array_equal(got["index"], want["index"])
+        # oracle-free properties
+        assert np.all(got["feaids"][1:] > got["feaids"][:-1])                               # ascending, unique
+        assert np.array_equal(got["feaids"][got["index"]], synth.reverse_bytes_np(b["index"]))  # index inverts the map
+        assert float(got["feacnt"].sum()) == nnz and got["feacnt"].max() > 256                # checksum; a hot key exists
+        bt.localize()                                                                        # idempotent
+        again = bt.get_localized()
+        assert all(np.array_equal(again[k], got[k]) for k in ("feaids", "feacnt", "index"))
+    bt.close()
+    kw = dict(l1=0.001, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 64, "hash", batches, 2, kw, capacity=1 << 19)
+    assert n_with_v > 1000
 
 
 def test_fused_step_host_localized(capi, ctx, oracle):
