@@ -5,6 +5,7 @@
 #include <mutex>
 #include <new>
 
+#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 
 #include "dfh_kernels.hip"
@@ -379,16 +380,29 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_
   static const int fwd_depth = getenv("DFH_FWD_DEPTH") ? atoi(getenv("DFH_FWD_DEPTH")) : 5;
   static const int fwd_blocks = getenv("DFH_FWD_BLOCKS") ? atoi(getenv("DFH_FWD_BLOCKS")) : 0;
   if (fwd_blocks > 0) grid = std::min(grid, fwd_blocks);
-  TimeScope ts(b->ctx, DFH_K_FORWARD);
+  // timing: the dispatch itself carries the two events (hipExtLaunchKernelGGL), so the span is the
+  // kernel's own begin/end as the command processor stamps them — what a profiler reports — and no
+  // marker packet drains the stream around it
+  dfh_ctx* c = b->ctx;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if ((c->timing >> DFH_K_FORWARD) & 1u) {
+    ea = TimeScope::get(c);
+    eb = TimeScope::get(c);
+  }
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
+#define DFH_FWD(D)                                                                                             \
+  if (ea && eb) hipExtLaunchKernelGGL((k_forward<L, D>), dim3(grid), dim3(256), 0, s, ea, eb, 0, bv, src, k, kp); \
+  else hipLaunchKernelGGL((k_forward<L, D>), dim3(grid), dim3(256), 0, s, bv, src, k, kp)
     switch (fwd_depth) {
-      case 4: hipLaunchKernelGGL((k_forward<L, 4>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
-      case 10: hipLaunchKernelGGL((k_forward<L, 10>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
-      case 8: hipLaunchKernelGGL((k_forward<L, 8>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
-      default: hipLaunchKernelGGL((k_forward<L, 5>), dim3(grid), dim3(256), 0, s, bv, src, k, kp); break;
+      case 4: DFH_FWD(4); break;
+      case 10: DFH_FWD(10); break;
+      case 8: DFH_FWD(8); break;
+      default: DFH_FWD(5); break;
     }
+#undef DFH_FWD
   });
+  if (ea && eb) c->spans.push_back({DFH_K_FORWARD, ea, eb});
   if (rc) return rc;
   DFH_HIP(hipGetLastError());
   return DFH_OK;
@@ -430,22 +444,33 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   // debugging aid: DFH_BWD_ROLES=<bitmask> runs only some roles (1 hot, 2 mid, 4 small); results are then wrong
   static const uint32_t role_mask = getenv("DFH_BWD_ROLES") ? (uint32_t)atoi(getenv("DFH_BWD_ROLES")) : 7u;
   static const uint32_t dbg_small = getenv("DFH_BWD_DBG") ? (uint32_t)atoi(getenv("DFH_BWD_DBG")) : 0u;
-  TimeScope ts(c, DFH_K_BACKWARD);
+  hipEvent_t ea = nullptr, eb = nullptr;  // timing rides on the dispatch, like the forward's
+  if ((c->timing >> DFH_K_BACKWARD) & 1u) {
+    ea = TimeScope::get(c);
+    eb = TimeScope::get(c);
+  }
   const dim3 grid((unsigned)(nb_hot + nb_mid + nb_small)), block(BWD_THREADS);
+  const uint32_t nh = (uint32_t)nb_hot, nm = (uint32_t)nb_mid;
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
     const bool lean = FUSED && src.urow && !(dbg_small & 4u);
+#define DFH_BWD(LEAN, EXACT)                                                                                          \
+  if (ea && eb)                                                                                                       \
+    hipExtLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, ea, eb, 0, bv, src, tv, grads, \
+                          gstride, k, kp, need, nh, nm, role_mask, dbg_small);                                        \
+  else                                                                                                                \
+    hipLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, \
+                       need, nh, nm, role_mask, dbg_small)
     if (lean && kp == 4 * LL) {
-      hipLaunchKernelGGL((k_backward_all<LL, FUSED, FUSED, true>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
-                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
+      DFH_BWD(FUSED, true);
     } else if (lean) {
-      hipLaunchKernelGGL((k_backward_all<LL, FUSED, FUSED, false>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
-                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
+      DFH_BWD(FUSED, false);
     } else {
-      hipLaunchKernelGGL((k_backward_all<LL, FUSED, false, false>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, need,
-                         (uint32_t)nb_hot, (uint32_t)nb_mid, role_mask, dbg_small);
+      DFH_BWD(false, false);
     }
+#undef DFH_BWD
   });
+  if (ea && eb) c->spans.push_back({DFH_K_BACKWARD, ea, eb});
   if (rc) return rc;
   DFH_HIP(hipGetLastError());
   return DFH_OK;

@@ -88,9 +88,11 @@ enum {
   DFH_K_LOCALIZE = 0, DFH_K_LOOKUP, DFH_K_FORWARD, DFH_K_BACKWARD, DFH_K_PULL, DFH_K_PUSH, DFH_K_MISC, DFH_K_COUNT
 };
 int dfh_ctx_set_timing(dfh_ctx* ctx, int enable);
-/* time only the kernels whose bit (1u << DFH_K_*) is set.  An event pair costs the stream a
- * pipeline drain (~10 us on MI355X), so production loops leave this off and a benchmark
- * samples: one kernel, every n-th step */
+/* time only the kernels whose bit (1u << DFH_K_*) is set.  Single-launch kernels (forward,
+ * backward) carry their event pair on the dispatch itself (hipExtLaunchKernelGGL: the kernel's own
+ * begin/end, as a profiler reports it); multi-launch groups (Localizer, lookup) are bracketed by
+ * recorded events, each of which drains the stream (~10 us on MI355X) — so production loops
+ * leave timing off and a benchmark samples: one kernel, every n-th step */
 int dfh_ctx_set_timing_mask(dfh_ctx* ctx, uint32_t mask);
 int dfh_ctx_get_timing(dfh_ctx* ctx, int reset, double* total_ms, uint64_t* calls); /* synchronises */
 const char* dfh_kernel_name(int id);

@@ -4,7 +4,8 @@
 TAG=${1:-r01}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_final -o kt -- python $R/bench.py --steps 100 --warmup 20 --cpu-batches 0 > $R/gpurun_out/prof_${TAG}_final.log 2>&1
+# the default bench command itself (what the driver runs), under the kernel trace
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_final -o kt -- python $R/bench.py > $R/gpurun_out/prof_${TAG}_final.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_final_np -o kt -- python $R/bench.py --steps 100 --warmup 20 --cpu-batches 0 --no-pipeline > $R/gpurun_out/prof_${TAG}_final_np.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_${TAG}_$c -o pmc -- python $R/bench.py --steps 20 --warmup 5 --cpu-batches 0 --no-pipeline --no-timing > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
