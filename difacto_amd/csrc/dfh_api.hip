@@ -121,6 +121,7 @@ struct dfh_batch {
   // step workspace
   uint32_t* d_nnz_row = nullptr;
   uint32_t *d_seg_n = nullptr, *d_mid_list = nullptr, *d_hot_list = nullptr;  // long-segment key lists (k_seg_lists)
+  uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
   float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
   size_t xv_floats = 0;
@@ -331,6 +332,7 @@ BatchView batch_view(const dfh_batch* b) {
   v.s_val = b->has_value ? b->d_s_val : nullptr;
   v.urow = b->d_urow;
   v.nnz_row = nullptr;
+  v.uw = nullptr;
   v.pred = b->d_pred;
   v.slope = b->d_slope;
   v.xv = b->d_xv;
@@ -370,9 +372,10 @@ int dispatch_L(int kp, F&& f) {
   return DFH_OK;
 }
 
-int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_rows = false) {
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_rows = false, const uint2* uw = nullptr) {
   BatchView bv = batch_view(b);
   if (use_nnz_rows) bv.nnz_row = b->d_nnz_row;
+  bv.uw = uw;
   // one wave per example, all resident at once where possible: the kernel is
   // bound by the latency of its dependent gathers, not by launch size
   int grid = (int)std::max<size_t>(1, std::min<size_t>((b->nrows + 3) / 4, PROG_SLOTS));
@@ -760,7 +763,7 @@ int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const f
   }
   hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (const uint32_t*)nullptr, (uint32_t)n, refrand ? t->d_urow : (uint32_t*)nullptr, d_cnt,
-                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr, 0);
+                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr, 0, (uint2*)nullptr);
   DFH_HIP(hipGetLastError());
   if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
   return DFH_OK;
@@ -820,7 +823,7 @@ int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const u
   if (n == 0) return DFH_OK;
   hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (const uint32_t*)nullptr, (uint32_t)n, const_cast<uint32_t*>(d_rowid), d_cnt, (const uint32_t*)nullptr, 1,
-                     (uint32_t*)nullptr, 1);
+                     (uint32_t*)nullptr, 1, (uint2*)nullptr);
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
@@ -1257,6 +1260,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_U, 64, uint32_t);
   DFH_ALLOC(b->d_urow, N, uint32_t);
   DFH_ALLOC(b->d_nnz_row, N, uint32_t);
+  DFH_ALLOC(b->d_uw, N, uint2);
   DFH_ALLOC(b->d_mid_list, N / (BWD_SMALL + 1) + 1, uint32_t);
   DFH_ALLOC(b->d_hot_list, N / (BWD_MID + 1) + 1, uint32_t);
   DFH_ALLOC(b->d_need, N, uint32_t);
@@ -1291,7 +1295,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_nnz_row, b->d_pred,  b->d_slope, b->d_xv,
                   b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_smp_rank, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
                   b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont,
-                  b->d_mid_list, b->d_hot_list};
+                  b->d_mid_list, b->d_hot_list, b->d_uw};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1493,7 +1497,7 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
     hipStream_t ps = prep_of(b);
     TimeScope ts(c, DFH_K_LOOKUP, ps);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, t->v, b->d_feaids, b->d_U, 0u,
-                       b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0);
+                       b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr);
     hipLaunchKernelGGL(k_nnz_rows, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, b->d_index, b->d_urow,
                        (uint32_t)b->nnz, b->d_nnz_row);
   }
@@ -1689,11 +1693,14 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   // dfh_batch_lookup already resolved the rows on the prep stream only the count
   // push remains (it must stay ordered with the previous step's update).
   const bool pre = b->looked_up == t;
+  // the lookup on THIS stream also leaves {row, w} per key for the forward (w is current: the
+  // previous step's update precedes it here); without it the forward reads the headers itself
+  uint2* uw = (!pre || push_cnt) ? b->d_uw : nullptr;
   if (!pre || push_cnt) {
     TimeScope ts(c, DFH_K_LOOKUP);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? 1 : 0,
-                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0);
+                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw);
   }
   DFH_HIP(hipGetLastError());
   if (push_cnt && refrand) {
@@ -1701,7 +1708,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     if (rc) return rc;
   }
   RowSrc src = table_src(t, b->d_urow);
-  rc = launch_forward(b, src, k, kp, pre);
+  rc = launch_forward(b, src, k, kp, pre, uw);
   if (rc) return rc;
   if (b->compute_auc) {
     rc = launch_auc(b);

@@ -86,6 +86,7 @@ struct BatchView {
   const float* s_val;       // [nnz] value of each occurrence, key order, or NULL
   uint32_t* urow;           // [U] table row of each unique key (filled by lookup)
   const uint32_t* nnz_row;  // [nnz] urow[index[j]] when precomposed (dfh_batch_lookup), else NULL
+  const uint2* uw;          // [U] {table row, w} per unique key as of this step's k_lookup, else NULL
   float* pred;              // [nrows]
   float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
   float* xv;                // [nrows x kp]

@@ -200,19 +200,21 @@ constexpr int BWD_THREADS = 512;    // threads per block of k_backward_all
 __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
-                         int rows_known) {
+                         int rows_known, uint2* __restrict__ uw) {
   uint32_t n = d_n ? *d_n : n_static;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
     uint64_t key = keys[u];
     // rows_known: urow was filled by an earlier (prep-stream) lookup of the same keys
     uint32_t r = rows_known ? urow[u] : find_or_insert(t, key);
     if (urow && !rows_known) urow[u] = r;
+    float w = 0.f;
     if (push_cnt) {
       float c = cnt ? cnt[u] : (float)(col_ptr[u + 1] - col_ptr[u]);
       RowHdr& h = t.hdr[r];
       float fc = h.fea_cnt + c;
       h.fea_cnt = fc;
-      bool init = t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold;
+      w = h.w;
+      bool init = t.k > 0 && h.has_V == 0 && w != 0 && fc > (float)t.p.V_threshold;
       if (t.p.init_mode == DFH_INIT_HASH) {
         if (init) {
           init_v_hash_row(t, r, key);
@@ -221,7 +223,12 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
       } else if (need_init) {
         need_init[u] = init ? 1u : 0u;
       }
+    } else if (uw) {
+      w = t.hdr[r].w;
     }
+    // {row, w} per unique key, batch-local and L2-resident: the forward then touches nothing of a
+    // row but its V lines (the weight is read here once per KEY instead of once per nonzero)
+    if (uw) uw[u] = make_uint2(r, __float_as_uint(w));
   }
 }
 
@@ -330,17 +337,26 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
       uint32_t hv = 0;
       if (valid) {
         x = b.value ? b.value[j] : 1.0f;
-        if (b.nnz_row) {
-          r = b.nnz_row[j];  // urow[index[j]] composed ahead of time on the preparation stream
+        if (b.uw) {
+          // {row, w} of the key from the batch-local table k_lookup left in L2: no header access;
+          // a row without V holds zeros, so its flag is not needed either
+          const uint2 e = b.uw[b.index[j]];
+          r = e.x;
+          hv = 1u;
+          wsum += __uint_as_float(e.y) * x;
         } else {
-          const uint32_t u = b.index[j];
-          r = src.urow ? src.urow[u] : u;
+          if (b.nnz_row) {
+            r = b.nnz_row[j];  // urow[index[j]] composed ahead of time on the preparation stream
+          } else {
+            const uint32_t u = b.index[j];
+            r = src.urow ? src.urow[u] : u;
+          }
+          const float* wp = src.wbase + (size_t)r * src.wstride;
+          // {w, has_V} are adjacent: one 8 B load
+          float2 wf = *reinterpret_cast<const float2*>(wp);
+          hv = __float_as_uint(wf.y);
+          wsum += wf.x * x;
         }
-        const float* wp = src.wbase + (size_t)r * src.wstride;
-        // {w, has_V} are adjacent: one 8 B load
-        float2 wf = *reinterpret_cast<const float2*>(wp);
-        hv = __float_as_uint(wf.y);
-        wsum += wf.x * x;
       }
       const int cnt = min(64u, end - base);
       if (k > 0) {
