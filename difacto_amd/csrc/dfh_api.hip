@@ -566,12 +566,13 @@ int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
   int rc = sync_all(c);
   if (rc) return rc;
   while ((int)c->preps.size() < enable) {
-    // highest priority: the preparation kernels are small and latency-bound; behind the wide
-    // forward/backward launches of the main stream their blocks would wait for free slots
+    // lowest priority: the main stream (lookup -> forward -> backward) is the critical path of a
+    // step; the preparation of later batches has a whole step (or two) of slack and fills the gaps
+    // (measured: highest 72.9, normal 72.7, lowest 75.8 M examples/sec)
     int lo = 0, hi = 0;
     DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     const char* pr = getenv("DFH_PREP_PRIORITY");
-    int prio = pr ? atoi(pr) : hi;
+    int prio = pr ? atoi(pr) : lo;
     hipStream_t p = nullptr;
     DFH_HIP(hipStreamCreateWithPriority(&p, hipStreamNonBlocking, prio));
     c->preps.push_back(p);
