@@ -260,12 +260,13 @@ def test_table_export_import_roundtrip(capi, ctx, oracle):
 
 
 # ------------------------------------------------------------------ the fused step
-def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True, capacity=1 << 16):
+def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True, capacity=1 << 16,
+                         table=None):
     from oracle import bindings as ob
     om = ob.INIT_HASH if mode == "hash" else ob.INIT_REFRAND
     dm = capi.INIT_HASH if mode == "hash" else capi.INIT_REFRAND
     so = oracle.store_create(init_mode=om, V_dim=V_dim, **kw)
-    tb = capi.Table(ctx, capacity, V_dim=V_dim, init_mode=dm, **kw)
+    tb = table if table is not None else capi.Table(ctx, capacity, V_dim=V_dim, init_mode=dm, **kw)
     max_rows = max(len(b["label"]) for b in batches)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     bt = capi.Batch(ctx, max_rows, max(max_nnz, 1))
@@ -315,7 +316,8 @@ def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, de
     assert np.array_equal(lg, lo)
     assert_close(vg, vo, rtol=2e-4, what="final weights")
     n_with_v = int(np.sum(lo > 1)) if V_dim else 0
-    tb.close()
+    if table is None:
+        tb.close()
     bt.close()
     return n_with_v
 
@@ -361,6 +363,34 @@ def test_full_size_c3_minibatches(capi, ctx, oracle):
     kw = dict(l1=0.001, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
     n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 64, "hash", batches, 2, kw, capacity=1 << 19)
     assert n_with_v > 1000
+
+
+def test_rows_beyond_32bit_float_offsets(capi, ctx, oracle):
+    """One aspect of BASELINE's C5 (1 B ids, V_dim = 128) that C3 never reaches: a row's float offset
+    row * 2*kp passes 2^32 from row 16.8 M on.  18 M filler keys are warm-started (reversed keys with
+    the top bit set), then minibatches whose keys have it clear land in rows beyond that and must
+    train exactly as in an empty oracle store."""
+    V_dim, filler = 128, 18_000_000
+    kw = dict(l1=0.001, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
+    tb = capi.Table(ctx, filler + (1 << 17), V_dim=V_dim, **kw)
+    chunk = 1 << 22
+    for o in range(0, filler, chunk):
+        keys = (np.arange(o, min(o + chunk, filler), dtype=np.uint64) | np.uint64(1 << 63))
+        db = capi.DeviceBuffer.from_numpy(ctx, keys)
+        tb.warm_start(db.ptr, len(keys), w0=0.5, cnt0=3.0)
+        ctx.sync()
+        db.close()
+    assert tb.size() == filler
+    rng = np.random.default_rng(1234)
+    batches = [random_batch(rng, 200, 2 ** 64 - 1, 30, binary=(i == 0)) for i in range(2)]
+    for b in batches:  # low nibble < 8  <=>  top bit of the reversed key clear: disjoint from the filler
+        b["index"] &= ~np.uint64(8)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, V_dim, "hash", batches, 3, kw, table=tb)
+    assert n_with_v > 0
+    nb = len(np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches])))
+    assert tb.size() == filler + nb           # every batch key got a fresh row behind the filler ...
+    assert (filler * 2 * 128) > 2 ** 32       # ... whose float offset does not fit 32 bits
+    tb.close()
 
 
 def test_fused_step_host_localized(capi, ctx, oracle):
