@@ -1,14 +1,20 @@
 // HIP kernels of the FM/SGD worker path for gfx950 (MI355X, CDNA4).
 //
 // Kernel inventory (DESIGN.md has the roofline of each):
-//   k_lookup          keys -> table rows (insert-on-miss) [+ Push(kFeaCount)]
-//   k_forward<L>      fused gather + FMLoss::Predict + logistic slope + logloss
-//   k_backward<L,F>   segmented sum over duplicate keys = FMLoss::CalcGrad,
-//                     F=1: fused in-place FTRL/AdaGrad (SGDUpdater::Update)
-//   k_pull_rows / k_push_grad / k_push_count   owner side of the sharded store
-//   k_refrand_*       rand_r-compatible lazy InitV (parity mode)
-//   k_predict_generic / k_xv_slope_generic / k_calcgrad_generic   literal Loss API
-//   k_loc_*           device Localizer::Compact around a radix sort
+//   k_lookup              keys -> table rows (insert-on-miss) [+ Push(kFeaCount)], leaves {row, w}
+//                         per key for the forward
+//   k_forward<L,D>        fused gather + FMLoss::Predict + logistic slope + logloss
+//   k_seg_lists           compacts the keys with long segments into the mid / hot lists
+//   k_backward_all<L,F,LEAN,EXACT>   segmented sum over duplicate keys = FMLoss::CalcGrad in ONE
+//                         launch (hot / mid / short-segment roles by block range);
+//                         F=1: fused in-place FTRL/AdaGrad (SGDUpdater::Update)
+//   k_resolve / k_pull_resolved / k_push_grad_resolved (+ k_pull_rows / k_push_grad)
+//                         owner side of the sharded store
+//   k_refrand_*           rand_r-compatible lazy InitV (parity mode)
+//   k_predict_generic / k_calcgrad_generic / k_logloss   literal Loss API
+//   k_auc_keys / k_auc_area   BinClassMetric::AUC
+//   k_loc_*               Localizer::Compact around a library radix sort (very large batches);
+//                         the sample-sort Localizer lives in dfh_localize.hip
 //
 // All kernels assume 64-lane wavefronts and are launched with 256-thread
 // blocks (4 waves) unless noted.
@@ -418,7 +424,7 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
 }
 
 // ---------------------------------------------------------------------------
-// k_backward<L, FUSED>: FMLoss::CalcGrad (src/loss/fm_loss.h:148-199) as a
+// Backward / update: FMLoss::CalcGrad (src/loss/fm_loss.h:148-199) as a
 // segmented sum over the key-ordered occurrence list the Localizer's sort
 // leaves behind (runs of equal key, src/data/localizer.cc:28):
 //   gw_u   = sum_occ x p_i
@@ -427,21 +433,18 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
 // V, lazy InitV) — no gradient ever reaches HBM.
 // !FUSED: write [gw, has_V, 0, 0 | gV] rows of `gstride` floats (exchange layout).
 //
-// Segment lengths are Zipf-distributed (1 .. ~B/8), so ONE launch runs three
-// roles, chosen by blockIdx (long tasks first so they start early):
-//   hot   blocks [0, nb_hot):   256 keys scanned per block; keys with
-//                               cnt > BWD_MID are taken one at a time by the
-//                               whole block (4 waves, partials combined in LDS)
-//   mid   next nb_mid blocks:   each wave scans BWD_MIDW keys and takes those
-//                               with BWD_SMALL < cnt <= BWD_MID, whole wave per key
-//   small the rest:             one L-lane group per key (G keys per wave),
-//                               occurrences summed serially in row order — the
-//                               reference's own order
-// Every key is handled by exactly one role; nothing is communicated between
-// blocks.  The kernel is bound by the latency of dependent random accesses, so
-// each role issues all of a key's independent loads (header, V row, AdaGrad
-// row, occurrence list) before consuming any; V rows are read speculatively
-// (a row without V holds zeros, in the table and in packed rows alike).
+// Segment lengths are Zipf-distributed (1 .. ~B/8), so ONE launch (k_backward_all)
+// runs three roles, chosen by block range (long chains first so they start early):
+//   hot    one key of the hot list (cnt > BWD_MID) per block and iteration: the
+//          block's waves split the segment, partials combined in LDS in wave order
+//   mid    one key of the mid list (BWD_SMALL < cnt <= BWD_MID) per wave
+//   short  one L-lane group per key (G keys per wave), occurrences summed serially
+//          in row order — the reference's own order
+// The two lists are compacted once per minibatch by k_seg_lists.  Every key is
+// handled by exactly one role; nothing is communicated between blocks.  Each role
+// issues all of a key's independent loads (header, V row, AdaGrad row, occurrence
+// list) before consuming any; V rows are read speculatively (a row without V holds
+// zeros, in the table and in packed rows alike).
 // ---------------------------------------------------------------------------
 
 struct KeySums {
