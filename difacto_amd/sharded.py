@@ -3,16 +3,19 @@ range across the ranks, one exchange each way per step.
 
 This is the parameter-server pattern the reference's interfaces were designed
 for — workers own data parts, servers own key ranges (Store::Push/Pull,
-include/difacto/store.h:53-73) — with every rank being both: rank g owns the
-reversed keys in [g*span, (g+1)*span), span = ceil(2^64/G).  ReverseBytes exists
-to make exactly this range partition uniform (include/difacto/base.h:29-38), and
-because the Localizer emits keys in ascending order (src/data/localizer.cc:28-48)
-each destination's keys are one contiguous slice: send buffers need no permutation.
+include/difacto/store.h:53-73) — with every rank being both.  Rank g owns a
+contiguous range of the reversed keys: ReverseBytes exists to make range
+partitioning work (include/difacto/base.h:29-38), and because the Localizer emits
+keys in ascending order (src/data/localizer.cc:28-48) each destination's keys are
+one contiguous slice: send buffers need no permutation.  The ranges are either the
+uniform ones (owner = key / ceil(2^64/G)) or given by explicit split keys balanced
+on the id space (balanced_splits): with feature-group ids in the low bits of an id
+(EncodeFeaGrpID, base.h:60-63) the uniform split is badly skewed.
 
 Per step and rank (torch.distributed all_to_all_single = RCCL over xGMI):
-    localize own minibatch                      (device, dfh_localize)
-    keys  --all_to_all_v-->  owners             [+ counts in epoch 0]
-    owners: Push(kFeaCount), Pull -> rows       (dfh_shard_push_count / dfh_shard_pull)
+    localize own minibatch                      (device, dfh_localize; one step ahead)
+    keys  --all_to_all_v-->  owners             [+ counts in epoch 0, same message]
+    owners: resolve keys -> rows once; Push(kFeaCount) per source; Pull -> rows
     rows  --all_to_all_v-->  workers            ((1+V_dim) floats per key, fixed stride)
     worker: Predict / Evaluate / CalcGrad       (dfh_batch_forward / dfh_batch_backward)
     grads --all_to_all_v-->  owners
