@@ -25,7 +25,8 @@ SYMBOLS = [
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
-    "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask",
+    "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
+    "dfh_shard_push_grad_multi", "dfh_shard_release",
 ]
 K_COUNT = 7
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
@@ -136,6 +137,10 @@ def lib():
     L.dfh_shard_push_count_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_shard_push_grad_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_table_check.argtypes = [vp]
+    L.dfh_shard_resolve_multi.argtypes = [vp, vp, vp, i32, vp]
+    L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.dfh_shard_release.argtypes = [vp, vp, sz]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_set_timing_mask.argtypes = [vp, C.c_uint32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
@@ -349,6 +354,27 @@ class Table:
 
     def shard_push_grad_resolved(self, d_rowid, d_keys, n, d_grads):
         _ck(lib().dfh_shard_push_grad_resolved(self.h, _dp(d_rowid), _dp(d_keys), n, _dp(d_grads)))
+
+    # all source ranks of a step in one launch (seg: nsrc+1 host offsets into the concatenated lists)
+    @staticmethod
+    def _seg(seg):
+        a = np.ascontiguousarray(seg, dtype=np.uint64)
+        return a, len(a) - 1
+
+    def shard_resolve_multi(self, d_keys, seg, d_rowid):
+        a, n = self._seg(seg)
+        _ck(lib().dfh_shard_resolve_multi(self.h, _dp(d_keys), _p(a), n, _dp(d_rowid)))
+
+    def shard_push_count_multi(self, d_rowid, d_keys, seg, d_cnt):
+        a, n = self._seg(seg)
+        _ck(lib().dfh_shard_push_count_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, _dp(d_cnt)))
+
+    def shard_push_grad_multi(self, d_rowid, d_keys, seg, d_grads):
+        a, n = self._seg(seg)
+        _ck(lib().dfh_shard_push_grad_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, _dp(d_grads)))
+
+    def shard_release(self, d_rowid, n):
+        _ck(lib().dfh_shard_release(self.h, _dp(d_rowid), n))
 
     def check(self):
         """raise if the device-side error word is set (capacity / duplicate key / V mismatch)"""

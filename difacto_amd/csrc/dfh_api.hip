@@ -849,6 +849,89 @@ int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const ui
   return DFH_OK;
 }
 
+// ---- all source ranks of a step in one launch per operation
+namespace {
+int make_segoff(const size_t* seg, int nsrc, SegOff* out) {
+  DFH_ARG(seg && nsrc >= 1 && nsrc <= 32, "seg must hold nsrc+1 offsets, 1 <= nsrc <= 32");
+  DFH_ARG(seg[0] == 0, "seg[0] must be 0");
+  for (int s = 0; s <= nsrc; ++s) {
+    DFH_ARG(seg[s] < 0xFFFFFFF0ULL && (s == 0 || seg[s] >= seg[s - 1]), "seg must be ascending 32-bit offsets");
+    out->off[s] = (uint32_t)seg[s];
+  }
+  out->nsrc = nsrc;
+  return DFH_OK;
+}
+bool hash_init_only(const dfh_table* t) { return t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0; }
+}  // namespace
+
+int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, uint32_t* d_rowid) {
+  DFH_ARG(t, "NULL table");
+  SegOff g;
+  int rc = make_segoff(seg, nsrc, &g);
+  if (rc) return rc;
+  const size_t n = g.off[nsrc];
+  DFH_ARG(n == 0 || (d_keys && d_rowid), "dfh_shard_resolve_multi: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_LOOKUP);
+  hipLaunchKernelGGL(k_resolve_multi, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys, g, d_rowid);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                               const float* d_cnt) {
+  DFH_ARG(t, "NULL table");
+  if (!hash_init_only(t)) {
+    set_error("multi-source store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  SegOff g;
+  int rc = make_segoff(seg, nsrc, &g);
+  if (rc) return rc;
+  const size_t n = g.off[nsrc];
+  DFH_ARG(n == 0 || (d_rowid && d_keys && d_cnt), "dfh_shard_push_count_multi: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_LOOKUP);
+  hipLaunchKernelGGL(k_push_count_multi, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g,
+                     d_cnt);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                              const float* d_grads) {
+  DFH_ARG(t, "NULL table");
+  if (!hash_init_only(t)) {
+    set_error("multi-source store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  SegOff g;
+  int rc = make_segoff(seg, nsrc, &g);
+  if (rc) return rc;
+  const size_t n = g.off[nsrc];
+  DFH_ARG(n == 0 || (d_rowid && d_keys && d_grads), "dfh_shard_push_grad_multi: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PUSH);
+  const size_t stride = dfh_row_stride(t->v.k);
+  rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);
+    hipLaunchKernelGGL((k_push_grad_multi<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g,
+                       d_grads, stride);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n) {
+  DFH_ARG(t && (n == 0 || d_rowid), "dfh_shard_release: NULL argument");
+  if (n == 0) return DFH_OK;
+  hipLaunchKernelGGL(k_release_rows, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_rowid, (uint32_t)n);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
 int dfh_table_check(dfh_table* t) {
   DFH_ARG(t, "NULL table");
   return check_table_err(t);

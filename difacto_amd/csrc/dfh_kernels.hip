@@ -1128,6 +1128,155 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
 }
 
 // ---------------------------------------------------------------------------
+// Owner side, one launch for ALL source ranks of a step.  The received keys are the
+// concatenation of nsrc ascending lists (SegOff).  k_resolve_multi resolves every entry to
+// its row and ORs the entry's source into a per-row mask (RowHdr::pad[0]).  In the Push
+// kernels the entry of the LOWEST source carrying a key is the key's leader: it finds the
+// key in the later sources (binary search in their ascending lists), applies their values
+// one after the other in source order — exactly what per-source launches would do — and
+// stores the row once.  The last Push of a step (or k_release_rows) clears the mask.
+// ---------------------------------------------------------------------------
+struct SegOff {
+  uint32_t off[33];  // entries of source s are [off[s], off[s+1])
+  int nsrc;
+};
+
+__device__ __forceinline__ int seg_source(const SegOff& g, uint32_t e) {
+  int s = 0;
+  while (s + 1 < g.nsrc && e >= g.off[s + 1]) ++s;
+  return s;
+}
+
+// position of `key` in keys[lo, hi) (ascending, present by construction)
+__device__ __forceinline__ uint32_t seg_find(const uint64_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint64_t key) {
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, SegOff g, uint32_t* __restrict__ rowid) {
+  const uint32_t n = g.off[g.nsrc];
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const uint32_t r = find_or_insert_shared(t, keys[e]);
+    rowid[e] = r;
+    atomicOr(&t.hdr[r].pad[0], 1u << seg_source(g, e));
+  }
+}
+
+__global__ void k_release_rows(TableView t, const uint32_t* __restrict__ rowid, uint32_t n) {
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) t.hdr[rowid[e]].pad[0] = 0;
+}
+
+// Push(kFeaCount) of all sources: one thread per entry, the leader adds every source's count
+// (small integers: the sum is exact in any order) and then takes the InitV decision once —
+// w does not change during count pushes and fea_cnt only grows, so the outcome equals the
+// sequential one (sgd_updater.cc:62-73)
+__global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ rowid, const uint64_t* __restrict__ keys,
+                                   SegOff g, const float* __restrict__ cnt) {
+  const uint32_t n = g.off[g.nsrc];
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const uint32_t r = rowid[e];
+    RowHdr& h = t.hdr[r];
+    const uint32_t mask = h.pad[0];
+    const int s = seg_source(g, e);
+    if ((mask & (0u - mask)) != (1u << s)) continue;  // an earlier source carries this key: its entry leads
+    const uint64_t key = keys[e];
+    float fc = h.fea_cnt + cnt[e];
+    for (uint32_t m = mask & ~(1u << s); m; m &= m - 1) {
+      const int s2 = __ffs((int)m) - 1;
+      fc += cnt[seg_find(keys, g.off[s2], g.off[s2 + 1], key)];
+    }
+    h.fea_cnt = fc;
+    if (t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold) {
+      init_v_hash_row(t, r, key);
+      h.has_V = 1;
+    }
+  }
+}
+
+// Push(kGradient) of all sources: L lanes per entry; the leader applies the sources' gradient rows
+// one after the other (FTRL on w with lazy InitV, AdaGrad on V iff the rows were pulled with V) on
+// registers and stores the row once; clears the row's source mask
+template <int L>
+__global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
+                                                         const uint64_t* __restrict__ keys, SegOff g,
+                                                         const float* __restrict__ grads, size_t stride) {
+  constexpr int GPW = 64 / L;
+  const int lane = lane_id();
+  const int sub = lane % L;
+  const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
+  const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
+  const uint32_t n = g.off[g.nsrc];
+  for (uint32_t e = group; e < n; e += ngroups) {
+    const uint32_t r = rowid[e];
+    RowHdr* hp = t.hdr + r;
+    const uint32_t mask = hp->pad[0];
+    const int s = seg_source(g, e);
+    if ((mask & (0u - mask)) != (1u << s)) continue;
+    const uint64_t key = keys[e];
+    const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+    float w = h0.x, sqrt_g = h0.z, z = h0.w;
+    uint32_t has_v = __float_as_uint(h0.y);
+    const float fea_cnt = hp->fea_cnt;
+    const float* g_own = grads + (size_t)e * stride;
+    const bool had_v = ld4(g_own).y != 0.0f;  // every source pulled the same model version: one answer
+    if (had_v && !has_v) {                    // CHECK(e.V != nullptr), sgd_updater.cc:92
+      if (sub == 0) atomicOr(t.err, 4u);
+      if (sub == 0) hp->pad[0] = 0;
+      continue;
+    }
+    float* va = t.va + (size_t)r * (2 * t.kp);
+    // this lane's V slice (4 * L >= kp by dispatch: one float4 per lane covers the row)
+    const int d = sub * 4;
+    const bool d_ok = d < t.kp;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), acc = v;
+    if (had_v && d_ok) {
+      v = ld4(va + d);
+      acc = ld4(va + t.kp + d);
+    }
+    for (uint32_t m = mask; m; m &= m - 1) {
+      const int s2 = __ffs((int)m) - 1;
+      uint32_t p = e;
+      if (s2 != s) {
+        if (sub == 0) p = seg_find(keys, g.off[s2], g.off[s2 + 1], key);
+        p = __shfl(p, (lane / L) * L, 64);
+      }
+      const float* gp = grads + (size_t)p * stride;
+      const float gw = ld4(gp).x;
+      const float w_old = w;
+      w = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
+      // lazy InitV when w leaves zero (sgd_updater.cc:122-126); the pulled rows had no V, so no
+      // gradient of this step touches the fresh values
+      if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
+        if (sub == 0) init_v_hash_row(t, r, key);
+        has_v = 1;
+      }
+      if (had_v && d_ok) {
+        const float4 gv = ld4(gp + 4 + d);
+        adagrad_update_v(gv.x, v.x, acc.x, t.p);
+        adagrad_update_v(gv.y, v.y, acc.y, t.p);
+        adagrad_update_v(gv.z, v.z, acc.z, t.p);
+        adagrad_update_v(gv.w, v.w, acc.w, t.p);
+      }
+    }
+    if (sub == 0) {
+      st4(reinterpret_cast<float*>(hp), make_float4(w, __uint_as_float(has_v), sqrt_g, z));
+      hp->pad[0] = 0;
+    }
+    if (had_v && d_ok) {
+      if (d + 0 >= t.k) { v.x = 0.f; acc.x = 0.f; }
+      if (d + 1 >= t.k) { v.y = 0.f; acc.y = 0.f; }
+      if (d + 2 >= t.k) { v.z = 0.f; acc.z = 0.f; }
+      if (d + 3 >= t.k) { v.w = 0.f; acc.w = 0.f; }
+      st4(va + d, v);
+      st4(va + t.kp + d, acc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Literal Loss API kernels: arbitrary V_dim, arbitrary w_pos/V_pos into a
 // ragged weights array (host SArray semantics).  Sums run serially in the
 // reference's order per output element, so these agree with the CPU path to

@@ -157,22 +157,32 @@ class HipBackend:
     def pred(self, slot):
         return self.batches[slot].pred()
 
-    # ---- owner side: all keys received in a step are resolved to rows once
-    def owner_resolve(self, keys):
+    # ---- owner side: the keys received in a step (concatenated ascending lists, source s in
+    # [seg[s], seg[s+1])) are resolved to rows once; every operation is one launch for all sources
+    def owner_resolve(self, keys, seg):
         rowid = torch.empty(keys.numel(), dtype=torch.int32, device=self.device)
-        self.table.shard_resolve(keys, keys.numel(), rowid)
+        if keys.numel():
+            self.table.shard_resolve_multi(keys, seg, rowid)
         return rowid
 
     def owner_pull(self, rowid, keys, rows, seg):
-        self.table.shard_pull_resolved(rowid, rowid.numel(), rows)
-
-    def owner_push_count(self, rowid, keys, cnt):
         if keys.numel():
-            self.table.shard_push_count_resolved(rowid, keys, keys.numel(), cnt)
+            self.table.shard_pull_resolved(rowid, rowid.numel(), rows)
 
-    def owner_push_grad(self, rowid, keys, grads):
+    def owner_push_count(self, rowid, keys, cnt, seg):
+        """Push(kFeaCount) of every source, applied in source order"""
         if keys.numel():
-            self.table.shard_push_grad_resolved(rowid, keys, keys.numel(), grads)
+            self.table.shard_push_count_multi(rowid, keys, seg, cnt)
+
+    def owner_push_grad(self, rowid, keys, grads, seg):
+        """Push(kGradient) of every source, applied in source order; ends the step for these rows"""
+        if keys.numel():
+            self.table.shard_push_grad_multi(rowid, keys, seg, grads)
+
+    def owner_release(self, rowid):
+        """ends a step that pushes no gradients (validation)"""
+        if rowid.numel():
+            self.table.shard_release(rowid, rowid.numel())
 
     def sync(self):
         self.ctx.sync()
@@ -290,11 +300,9 @@ class ShardedWorker:
         else:
             rkeys = torch.empty(nrecv, dtype=torch.int64, device=self.device)
             self._a2a(rkeys, keys, recv, send)
-        rowid = be.owner_resolve(rkeys)
+        rowid = be.owner_resolve(rkeys, roff)
         if push_cnt:
-            for s in range(G):  # Push(kFeaCount), source rank after source rank
-                if recv[s]:
-                    be.owner_push_count(rowid[roff[s]:roff[s + 1]], rkeys[roff[s]:roff[s + 1]], rcnt[roff[s]:roff[s + 1]])
+            be.owner_push_count(rowid, rkeys, rcnt, roff)  # Push(kFeaCount), source rank after source rank
         # 2. owners pull rows (every source reads the same model version) and send them back
         rrows = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
         if nrecv:
@@ -314,9 +322,9 @@ class ShardedWorker:
             # 4. gradients to the owners, applied in source-rank order
             rgrads = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
             self._a2a(rgrads, grads, recv, send)
-            for s in range(G):
-                if recv[s]:
-                    be.owner_push_grad(rowid[roff[s]:roff[s + 1]], rkeys[roff[s]:roff[s + 1]], rgrads[roff[s]:roff[s + 1]])
+            be.owner_push_grad(rowid, rkeys, rgrads, roff)
+        else:
+            be.owner_release(rowid)
         return dict(unique=U, sent=send, received=recv, slot=slot)
 
 

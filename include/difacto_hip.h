@@ -246,6 +246,20 @@ int dfh_shard_resolve(dfh_table* t, const uint64_t* d_keys, size_t n, uint32_t* 
 int dfh_shard_pull_resolved(dfh_table* t, const uint32_t* d_rowid, size_t n, float* d_rows);
 int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_cnt);
 int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_grads);
+/* The same for ALL source ranks of a step in one launch per operation.  d_keys is the
+ * concatenation of nsrc ascending key lists, source s holding entries [seg[s], seg[s+1]) (seg:
+ * HOST array of nsrc+1 offsets, nsrc <= 32).  resolve_multi also marks, per row, which sources
+ * carry its key; in the two Push calls the entry of the lowest such source applies every
+ * source's value in ascending source order (the result of nsrc per-source calls) and stores the
+ * row once.  push_grad_multi ends the step for these rows; a step without it (validation) ends
+ * with dfh_shard_release.  Between resolve_multi and that end no other store call may touch
+ * the table. */
+int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, uint32_t* d_rowid);
+int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                               const float* d_cnt);
+int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                              const float* d_grads);
+int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n);
 /* fetch and report the table's sticky device-side error word (capacity, duplicate key,
  * gradient with V for a row without V); synchronises */
 int dfh_table_check(dfh_table* t);

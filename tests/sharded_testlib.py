@@ -90,19 +90,29 @@ class OracleBackend:
     def pred(self, slot=None):
         return self._pred
 
-    # owner side ("resolved" interface of the HIP backend; the double keeps using keys)
-    def owner_resolve(self, keys):
+    # owner side (the HIP backend's interface: all sources of a step per call; the double
+    # walks the sources one Store call at a time, which is what those calls must equal)
+    def owner_resolve(self, keys, seg):
         return torch.zeros(keys.numel(), dtype=torch.int32)
 
-    def owner_push_count(self, rowid, keys, cnt):
-        if keys.numel():
-            self.store.push(keys.numpy().view(np.uint64), ob.FEA_COUNT, cnt.numpy())
+    def owner_push_count(self, rowid, keys, cnt, seg):
+        for s in range(len(seg) - 1):
+            if seg[s + 1] > seg[s]:
+                self.store.push(keys[seg[s]:seg[s + 1]].numpy().view(np.uint64), ob.FEA_COUNT, cnt[seg[s]:seg[s + 1]].numpy())
 
     def owner_pull(self, rowid, keys, rows, seg):
         # one Store::Pull per source rank (keys are unique only within a source)
         for s in range(len(seg) - 1):
             if seg[s + 1] > seg[s]:
                 self._pull(keys[seg[s]:seg[s + 1]], rows[seg[s]:seg[s + 1]])
+
+    def owner_push_grad(self, rowid, keys, grads, seg):
+        for s in range(len(seg) - 1):
+            if seg[s + 1] > seg[s]:
+                self._push_grad(keys[seg[s]:seg[s + 1]], grads[seg[s]:seg[s + 1]])
+
+    def owner_release(self, rowid):
+        pass
 
     def _pull(self, keys, rows):
         vals, lens = self.store.pull(keys.numpy().view(np.uint64))
@@ -118,9 +128,7 @@ class OracleBackend:
                 out[u, 4:4 + k] = vals[p:p + k]
                 p += k
 
-    def owner_push_grad(self, rowid, keys, grads):
-        if not keys.numel():
-            return
+    def _push_grad(self, keys, grads):
         g = grads.numpy()
         k = self.V_dim
         vals, lens = [], []

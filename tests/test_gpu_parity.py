@@ -498,37 +498,50 @@ def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
 
 
 @pytest.mark.parametrize("V_dim", [0, 6, 64])
-def test_owner_resolved_calls_match_per_source_calls(capi, ctx, V_dim):
+@pytest.mark.parametrize("form", ["resolved", "multi"])
+def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
     """keys arriving from several source ranks in one step (the same key under more than one
-    source): resolve-once + pull-all + per-source pushes on row ids == the per-source
-    dfh_shard_* calls (parity-tested above) applied in the same order"""
+    source).  Two forms of the owner side must equal the per-source dfh_shard_* calls
+    (parity-tested above) applied in source order:
+      resolved  resolve once + pull all + per-source pushes on row ids
+      multi     one launch per operation for all sources (leader entry per key applies every
+                source's value in order) - what difacto_amd.sharded runs"""
     import torch
     rng = np.random.default_rng(77 + V_dim)
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=2, V_init_scale=0.2, seed=9)
     stride = capi.row_stride(V_dim)
     dev = torch.device("cuda", 0)
-    ta = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # resolved calls
+    ta = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # form under test
     tb = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # per-source calls
     universe = np.unique(rng.integers(0, 2 ** 64 - 1, 3000, dtype=np.uint64))
     G = 4
-    for step in range(6):
+    for step in range(7):
         srcs = [np.sort(rng.choice(universe, size=int(rng.integers(0 if step == 3 else 200, 900)), replace=False))
                 for _ in range(G)]
         if step == 3:
             srcs[1] = srcs[1][:0]  # a source with nothing for this owner
+        if step == 5:
+            srcs[0] = srcs[0][:0]  # ... and the first one empty
         seg = np.concatenate([[0], np.cumsum([len(x) for x in srcs])]).astype(np.int64)
         n = int(seg[-1])
+        train = step != 6          # the last step pushes no gradients (validation): release instead
         keys = torch.from_numpy(np.concatenate(srcs).view(np.int64)).to(dev)
         cnt = torch.from_numpy(rng.integers(1, 5, n).astype(np.float32)).to(dev)
         rowid = torch.empty(n, dtype=torch.int32, device=dev)
         rows_a = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         rows_b = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()  # the fixture's context runs on its own (non-blocking) stream
-        ta.shard_resolve(keys, n, rowid)
+        if form == "multi":
+            ta.shard_resolve_multi(keys, seg, rowid)
+            if step < 3:
+                ta.shard_push_count_multi(rowid, keys, seg, cnt)
+        else:
+            ta.shard_resolve(keys, n, rowid)
         for s in range(G):
             a, b = int(seg[s]), int(seg[s + 1])
             if b > a and step < 3:
-                ta.shard_push_count_resolved(rowid[a:b], keys[a:b], b - a, cnt[a:b])
+                if form == "resolved":
+                    ta.shard_push_count_resolved(rowid[a:b], keys[a:b], b - a, cnt[a:b])
                 tb.shard_push_count(keys[a:b], b - a, cnt[a:b])
         ta.shard_pull_resolved(rowid, n, rows_a)
         for s in range(G):
@@ -538,6 +551,10 @@ def test_owner_resolved_calls_match_per_source_calls(capi, ctx, V_dim):
         ctx.sync()
         torch.cuda.synchronize()
         assert torch.equal(rows_a, rows_b)
+        if not train:
+            if form == "multi":
+                ta.shard_release(rowid, n)
+            continue
         # gradient rows: [gw, has_V as pulled, 0, 0 | gV]
         g = rng.normal(size=(n, stride)).astype(np.float32) * 0.5
         g[rng.random(n) < 0.2, 0] = 0.0
@@ -545,10 +562,13 @@ def test_owner_resolved_calls_match_per_source_calls(capi, ctx, V_dim):
         g[:, 2:4] = 0
         grads = torch.from_numpy(g).to(dev)
         torch.cuda.synchronize()
+        if form == "multi":
+            ta.shard_push_grad_multi(rowid, keys, seg, grads)
         for s in range(G):
             a, b = int(seg[s]), int(seg[s + 1])
             if b > a:
-                ta.shard_push_grad_resolved(rowid[a:b], keys[a:b], b - a, grads[a:b])
+                if form == "resolved":
+                    ta.shard_push_grad_resolved(rowid[a:b], keys[a:b], b - a, grads[a:b])
                 tb.shard_push_grad(keys[a:b], b - a, grads[a:b])
         ta.check()
         tb.check()
@@ -558,6 +578,26 @@ def test_owner_resolved_calls_match_per_source_calls(capi, ctx, V_dim):
     assert (la > 1).any() or V_dim == 0
     assert_close(va, vb, rtol=1e-6, what="weights")
     assert ta.size() == tb.size()
+    if form == "multi":  # every source mask was cleared: a fresh multi step must see clean rows
+        keys = torch.from_numpy(universe[:100].view(np.int64).copy()).to(dev)
+        rowid = torch.empty(100, dtype=torch.int32, device=dev)
+        rows = torch.zeros((100, stride), dtype=torch.float32, device=dev)
+        zeros = torch.zeros((100, stride), dtype=torch.float32, device=dev)
+        zeros[:, 1] = 0
+        torch.cuda.synchronize()
+        ta.shard_resolve_multi(keys, np.array([0, 0, 100]), rowid)   # source 0 empty, source 1 carries all
+        ta.shard_pull_resolved(rowid, 100, rows)
+        ctx.sync()
+        g = np.zeros((100, stride), np.float32)
+        g[:, 1] = rows[:, 1].cpu().numpy()
+        grads = torch.from_numpy(g).to(dev)
+        torch.cuda.synchronize()
+        ta.shard_push_grad_multi(rowid, keys, np.array([0, 0, 100]), grads)   # applied iff the masks were clean
+        ta.check()
+        tb.shard_push_grad(keys, 100, grads)
+        v2a, _ = ta.pull(universe[:100])
+        v2b, _ = tb.pull(universe[:100])
+        assert_close(v2a, v2b, rtol=1e-6, what="weights after a clean multi step")
     for o in (ta, tb):
         o.close()
 
