@@ -393,6 +393,41 @@ def test_rows_beyond_32bit_float_offsets(capi, ctx, oracle):
     tb.close()
 
 
+def test_edge_batches(capi, ctx, oracle):
+    """edge inputs of the path: a minibatch without a single nonzero (pred = 0, loss = n ln 2,
+    nothing pulled or pushed); the largest id (2^64-1, which id % max_index folds onto key 0,
+    localizer.cc:24) next to id 0; one row holding one feature many times"""
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=3)
+    tb = capi.Table(ctx, 1 << 12, V_dim=4, **kw)
+    bt = capi.Batch(ctx, 64, 256)
+    # (1) no nonzeros at all
+    n = 37
+    lab = np.where(np.arange(n) % 3 == 0, 1.0, -1.0).astype(np.float32)
+    bt.load_host(np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64), None, lab)
+    bt.localize()
+    assert bt.get_localized()["U"] == 0
+    bt.sgd_step(tb, is_train=True, push_cnt=True)
+    assert np.array_equal(bt.pred(), np.zeros(n, np.float32))
+    p = bt.progress()
+    assert p.loss == pytest.approx(n * np.log(2.0), rel=1e-6) and p.nrows == n and tb.size() == 0
+    # (2) extreme ids + a feature repeated inside one row, against the oracle
+    off = np.array([0, 3, 3, 40, 42], np.uint64)
+    idx = np.concatenate([np.array([2 ** 64 - 1, 0, 5], np.uint64), np.full(37, 5, np.uint64),
+                          np.array([2 ** 64 - 2, 7], np.uint64)])
+    val = np.linspace(-1, 1, 42).astype(np.float32)
+    b = dict(offset=off, index=idx, value=val, label=np.array([1, -1, 1, -1], np.float32))
+    loc = oracle.localize(b["offset"], b["index"])
+    assert loc["U"] == 4  # ids 2^64-1 and 0 share key 0
+    bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+    bt.localize()
+    got = bt.get_localized()
+    assert np.array_equal(got["feaids"], loc["feaids"]) and np.array_equal(got["index"], loc["index"])
+    assert np.array_equal(got["feacnt"], loc["feacnt"])
+    bt.close()
+    tb.close()
+    _run_fused_vs_oracle(capi, ctx, oracle, 4, "refrand", [b], 4, kw)
+
+
 def test_fused_step_host_localized(capi, ctx, oracle):
     rng = np.random.default_rng(77)
     batches = [random_batch(rng, 64, 200, 20) for _ in range(2)]
