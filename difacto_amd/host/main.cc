@@ -1,7 +1,7 @@
 /**
  * main.cc — the `difacto` command line: key=value arguments, `argfile=x.conf`
  * pulls in a config file (same "k = v" / '#' comment format as the reference's
- * example/*.conf), `task=train learner=sgd` by default; unknown keys are
+ * example/<name>.conf), `task=train learner=sgd` by default; unknown keys are
  * reported as warnings.  Reference: src/main.cc, src/common/arg_parser.h.
  */
 #include <fstream>
