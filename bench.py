@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
     ap.add_argument("--uniform-ranges", action="store_true",
                     help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
+    ap.add_argument("--exchange", choices=["sync", "overlap"], default="overlap",
+                    help="N>1: two minibatches in flight with the exchange hidden behind compute (staleness 1, what the "
+                         "reference's batch tracker does, sgd_learner.cc:219-223), or one at a time (zero staleness)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     return ap.parse_args()

@@ -137,10 +137,10 @@ def lib():
     L.dfh_shard_push_count_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_shard_push_grad_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_table_check.argtypes = [vp]
-    L.dfh_shard_resolve_multi.argtypes = [vp, vp, vp, i32, vp]
-    L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, vp]
-    L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, vp]
-    L.dfh_shard_release.argtypes = [vp, vp, sz]
+    L.dfh_shard_resolve_multi.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.dfh_shard_release.argtypes = [vp, vp, sz, i32]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_set_timing_mask.argtypes = [vp, C.c_uint32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
@@ -361,20 +361,20 @@ class Table:
         a = np.ascontiguousarray(seg, dtype=np.uint64)
         return a, len(a) - 1
 
-    def shard_resolve_multi(self, d_keys, seg, d_rowid):
+    def shard_resolve_multi(self, d_keys, seg, d_rowid, mask_slot=0):
         a, n = self._seg(seg)
-        _ck(lib().dfh_shard_resolve_multi(self.h, _dp(d_keys), _p(a), n, _dp(d_rowid)))
+        _ck(lib().dfh_shard_resolve_multi(self.h, _dp(d_keys), _p(a), n, mask_slot, _dp(d_rowid)))
 
-    def shard_push_count_multi(self, d_rowid, d_keys, seg, d_cnt):
+    def shard_push_count_multi(self, d_rowid, d_keys, seg, d_cnt, mask_slot=0):
         a, n = self._seg(seg)
-        _ck(lib().dfh_shard_push_count_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, _dp(d_cnt)))
+        _ck(lib().dfh_shard_push_count_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, mask_slot, _dp(d_cnt)))
 
-    def shard_push_grad_multi(self, d_rowid, d_keys, seg, d_grads):
+    def shard_push_grad_multi(self, d_rowid, d_keys, seg, d_grads, mask_slot=0):
         a, n = self._seg(seg)
-        _ck(lib().dfh_shard_push_grad_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, _dp(d_grads)))
+        _ck(lib().dfh_shard_push_grad_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, mask_slot, _dp(d_grads)))
 
-    def shard_release(self, d_rowid, n):
-        _ck(lib().dfh_shard_release(self.h, _dp(d_rowid), n))
+    def shard_release(self, d_rowid, n, mask_slot=0):
+        _ck(lib().dfh_shard_release(self.h, _dp(d_rowid), n, mask_slot))
 
     def check(self):
         """raise if the device-side error word is set (capacity / duplicate key / V mismatch)"""

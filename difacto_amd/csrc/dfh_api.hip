@@ -851,8 +851,10 @@ int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const ui
 
 // ---- all source ranks of a step in one launch per operation
 namespace {
-int make_segoff(const size_t* seg, int nsrc, SegOff* out) {
+int make_segoff(const size_t* seg, int nsrc, int mask_slot, SegOff* out) {
   DFH_ARG(seg && nsrc >= 1 && nsrc <= 32, "seg must hold nsrc+1 offsets, 1 <= nsrc <= 32");
+  DFH_ARG(mask_slot == 0 || mask_slot == 1, "mask_slot must be 0 or 1");
+  out->slot = mask_slot;
   DFH_ARG(seg[0] == 0, "seg[0] must be 0");
   for (int s = 0; s <= nsrc; ++s) {
     DFH_ARG(seg[s] < 0xFFFFFFF0ULL && (s == 0 || seg[s] >= seg[s - 1]), "seg must be ascending 32-bit offsets");
@@ -864,10 +866,11 @@ int make_segoff(const size_t* seg, int nsrc, SegOff* out) {
 bool hash_init_only(const dfh_table* t) { return t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0; }
 }  // namespace
 
-int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, uint32_t* d_rowid) {
+int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, int mask_slot,
+                            uint32_t* d_rowid) {
   DFH_ARG(t, "NULL table");
   SegOff g;
-  int rc = make_segoff(seg, nsrc, &g);
+  int rc = make_segoff(seg, nsrc, mask_slot, &g);
   if (rc) return rc;
   const size_t n = g.off[nsrc];
   DFH_ARG(n == 0 || (d_keys && d_rowid), "dfh_shard_resolve_multi: NULL argument");
@@ -879,14 +882,14 @@ int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* 
 }
 
 int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
-                               const float* d_cnt) {
+                               int mask_slot, const float* d_cnt) {
   DFH_ARG(t, "NULL table");
   if (!hash_init_only(t)) {
     set_error("multi-source store calls need V_init = hash (order independent)");
     return DFH_ERR_STATE;
   }
   SegOff g;
-  int rc = make_segoff(seg, nsrc, &g);
+  int rc = make_segoff(seg, nsrc, mask_slot, &g);
   if (rc) return rc;
   const size_t n = g.off[nsrc];
   DFH_ARG(n == 0 || (d_rowid && d_keys && d_cnt), "dfh_shard_push_count_multi: NULL argument");
@@ -899,14 +902,14 @@ int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint
 }
 
 int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
-                              const float* d_grads) {
+                              int mask_slot, const float* d_grads) {
   DFH_ARG(t, "NULL table");
   if (!hash_init_only(t)) {
     set_error("multi-source store calls need V_init = hash (order independent)");
     return DFH_ERR_STATE;
   }
   SegOff g;
-  int rc = make_segoff(seg, nsrc, &g);
+  int rc = make_segoff(seg, nsrc, mask_slot, &g);
   if (rc) return rc;
   const size_t n = g.off[nsrc];
   DFH_ARG(n == 0 || (d_rowid && d_keys && d_grads), "dfh_shard_push_grad_multi: NULL argument");
@@ -924,10 +927,12 @@ int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint6
   return DFH_OK;
 }
 
-int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n) {
+int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_slot) {
   DFH_ARG(t && (n == 0 || d_rowid), "dfh_shard_release: NULL argument");
+  DFH_ARG(mask_slot == 0 || mask_slot == 1, "mask_slot must be 0 or 1");
   if (n == 0) return DFH_OK;
-  hipLaunchKernelGGL(k_release_rows, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_rowid, (uint32_t)n);
+  hipLaunchKernelGGL(k_release_rows, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_rowid, (uint32_t)n,
+                     mask_slot);
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }

@@ -1139,6 +1139,8 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
 struct SegOff {
   uint32_t off[33];  // entries of source s are [off[s], off[s+1])
   int nsrc;
+  int slot;          // which of the two per-row source masks (RowHdr::pad[0..1]) this step uses: two steps
+                     // may be in flight on an owner (one resolved and pulled, the other awaiting its gradients)
 };
 
 __device__ __forceinline__ int seg_source(const SegOff& g, uint32_t e) {
@@ -1161,12 +1163,12 @@ __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, 
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const uint32_t r = find_or_insert_shared(t, keys[e]);
     rowid[e] = r;
-    atomicOr(&t.hdr[r].pad[0], 1u << seg_source(g, e));
+    atomicOr(&t.hdr[r].pad[g.slot], 1u << seg_source(g, e));
   }
 }
 
-__global__ void k_release_rows(TableView t, const uint32_t* __restrict__ rowid, uint32_t n) {
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) t.hdr[rowid[e]].pad[0] = 0;
+__global__ void k_release_rows(TableView t, const uint32_t* __restrict__ rowid, uint32_t n, int slot) {
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) t.hdr[rowid[e]].pad[slot] = 0;
 }
 
 // Push(kFeaCount) of all sources: one thread per entry, the leader adds every source's count
@@ -1179,7 +1181,7 @@ __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ row
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const uint32_t r = rowid[e];
     RowHdr& h = t.hdr[r];
-    const uint32_t mask = h.pad[0];
+    const uint32_t mask = h.pad[g.slot];
     const int s = seg_source(g, e);
     if ((mask & (0u - mask)) != (1u << s)) continue;  // an earlier source carries this key: its entry leads
     const uint64_t key = keys[e];
@@ -1212,7 +1214,7 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
   for (uint32_t e = group; e < n; e += ngroups) {
     const uint32_t r = rowid[e];
     RowHdr* hp = t.hdr + r;
-    const uint32_t mask = hp->pad[0];
+    const uint32_t mask = hp->pad[g.slot];
     const int s = seg_source(g, e);
     if ((mask & (0u - mask)) != (1u << s)) continue;
     const uint64_t key = keys[e];
@@ -1224,7 +1226,7 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
     const bool had_v = ld4(g_own).y != 0.0f;  // every source pulled the same model version: one answer
     if (had_v && !has_v) {                    // CHECK(e.V != nullptr), sgd_updater.cc:92
       if (sub == 0) atomicOr(t.err, 4u);
-      if (sub == 0) hp->pad[0] = 0;
+      if (sub == 0) hp->pad[g.slot] = 0;
       continue;
     }
     float* va = t.va + (size_t)r * (2 * t.kp);
@@ -1263,7 +1265,7 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
     }
     if (sub == 0) {
       st4(reinterpret_cast<float*>(hp), make_float4(w, __uint_as_float(has_v), sqrt_g, z));
-      hp->pad[0] = 0;
+      hp->pad[g.slot] = 0;
     }
     if (had_v && d_ok) {
       if (d + 0 >= t.k) { v.x = 0.f; acc.x = 0.f; }

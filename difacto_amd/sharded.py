@@ -89,7 +89,7 @@ def torch_view(ptr, n, dtype, device):
     return torch.as_tensor(_DevPtr(ptr, (n,), typestr), device=device)
 
 
-NSLOTS = 2  # minibatches in flight per rank: one stepping, one being localized
+NSLOTS = 3  # minibatch objects per rank: one stepping, up to two being prepared / pulled ahead
 
 
 class HipBackend:
@@ -159,30 +159,30 @@ class HipBackend:
 
     # ---- owner side: the keys received in a step (concatenated ascending lists, source s in
     # [seg[s], seg[s+1])) are resolved to rows once; every operation is one launch for all sources
-    def owner_resolve(self, keys, seg):
+    def owner_resolve(self, keys, seg, mslot=0):
         rowid = torch.empty(keys.numel(), dtype=torch.int32, device=self.device)
         if keys.numel():
-            self.table.shard_resolve_multi(keys, seg, rowid)
+            self.table.shard_resolve_multi(keys, seg, rowid, mslot)
         return rowid
 
     def owner_pull(self, rowid, keys, rows, seg):
         if keys.numel():
             self.table.shard_pull_resolved(rowid, rowid.numel(), rows)
 
-    def owner_push_count(self, rowid, keys, cnt, seg):
+    def owner_push_count(self, rowid, keys, cnt, seg, mslot=0):
         """Push(kFeaCount) of every source, applied in source order"""
         if keys.numel():
-            self.table.shard_push_count_multi(rowid, keys, seg, cnt)
+            self.table.shard_push_count_multi(rowid, keys, seg, cnt, mslot)
 
-    def owner_push_grad(self, rowid, keys, grads, seg):
+    def owner_push_grad(self, rowid, keys, grads, seg, mslot=0):
         """Push(kGradient) of every source, applied in source order; ends the step for these rows"""
         if keys.numel():
-            self.table.shard_push_grad_multi(rowid, keys, seg, grads)
+            self.table.shard_push_grad_multi(rowid, keys, seg, grads, mslot)
 
-    def owner_release(self, rowid):
+    def owner_release(self, rowid, mslot=0):
         """ends a step that pushes no gradients (validation)"""
         if rowid.numel():
-            self.table.shard_release(rowid, rowid.numel())
+            self.table.shard_release(rowid, rowid.numel(), mslot)
 
     def sync(self):
         self.ctx.sync()
@@ -198,29 +198,52 @@ class HipBackend:
         self.ctx.close()
 
 
-class _Pending:
-    __slots__ = ("slot", "counted")
+class _Done:
+    """stand-in for a collective that already completed (host-staged exchange)"""
 
-    def __init__(self, slot):
-        self.slot, self.counted = slot, False
+    def wait(self):
+        return True
+
+
+class _Pending:
+    """one submitted minibatch on its way through the stages of a step"""
+
+    def __init__(self, slot, seq, is_train, push_cnt):
+        self.slot, self.seq, self.is_train, self.push_cnt = slot, seq, is_train, push_cnt
+        self.mslot = seq & 1  # owner-side source-mask slot: consecutive steps alternate
+        self.cnt_issued = self.counted = self.sized = self.k_issued = self.pulled = self.rw_issued = False
+        self.w_cnt = self.w_keys = self.w_rows = self.w_grads = None
 
 
 class ShardedWorker:
     """one rank of the sharded SGD loop (worker + owner of one key range).
 
-    submit(batch) enqueues the Localizer of a minibatch (up to NSLOTS in flight);
-    step() runs the oldest submitted one.  Submitting batch t+1 before step(t) lets its
-    Localizer and the exchange of its per-destination key counts overlap step t, so a
-    step waits on the host only for an event that was recorded long before."""
+    submit(batch, is_train, push_cnt) enqueues the Localizer of a minibatch (up to NSLOTS in
+    flight); step() completes the oldest one.  A step is six stages,
+        K  keys (+ counts) to the owners          R  owners resolve, count-push, pull
+        RW rows back to the workers               F  forward / backward on the pulled rows
+        G  gradients to the owners                P  owners apply them, source rank after source rank
+    exchange="sync" runs them in that order for one minibatch at a time: every worker reads the
+    model all earlier minibatches have updated.  exchange="overlap" keeps TWO minibatches in
+    flight, like the reference's batch tracker (sgd_learner.cc:219-223: the next batch is issued
+    while one is still pending, so its Pull may be served before the previous Push has landed):
+    per step() call the order is  K(t+1) | F(t) G(t) | R(t+1) RW(t+1) | P(t), with the collectives
+    asynchronous, so the gradients of t travel while the owners pull for t+1 and the rows of t+1
+    travel while the gradients of t are applied.  Every table operation still runs on the one
+    compute stream in program order (nothing races on a row); minibatch t+1 reads the model
+    without t's update (staleness 1, exactly one batch)."""
 
-    def __init__(self, backend, group=None, stage_through_host=False, splits=None):
+    def __init__(self, backend, group=None, stage_through_host=False, splits=None, exchange="sync"):
         """splits: np.uint64[world-1] first keys of shards 1.. (identical on all ranks); None =
-        the uniform partition.  stage_through_host: exchange through host copies (for process groups whose backend
-        cannot move device tensors, e.g. gloo when several ranks share one GPU in a test);
-        the product path exchanges device buffers over RCCL directly"""
+        the uniform partition.  stage_through_host: exchange through host copies (for process
+        groups whose backend cannot move device tensors, e.g. gloo when several ranks share one
+        GPU in a test); the product path exchanges device buffers over RCCL directly"""
+        if exchange not in ("sync", "overlap"):
+            raise ValueError("exchange must be 'sync' or 'overlap'")
         self.be = backend
         self.group = group
         self.stage = bool(stage_through_host)
+        self.overlap = exchange == "overlap"
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = backend.device
@@ -229,6 +252,7 @@ class ShardedWorker:
         G = self.world
         self.queue = collections.deque()
         self.next_slot = 0
+        self.seq = 0
         self._bounds = [torch.zeros(G + 1, dtype=torch.int64, device=self.device) for _ in range(NSLOTS)]
         self._hcnt = [torch.zeros((2, G), dtype=torch.int64, pin_memory=self.cuda) for _ in range(NSLOTS)]
         self._ev = [torch.cuda.Event() for _ in range(NSLOTS)] if self.cuda else None
@@ -239,7 +263,10 @@ class ShardedWorker:
                 raise ValueError("splits must be world-1 ascending keys")
             self.splits = torch.from_numpy(sp.view(np.int64).copy()).to(self.device)
 
+    # ---- plumbing
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        """all_to_all_v; returns a handle whose wait() orders the compute stream after the exchange
+        (asynchronous in overlap mode, already ordered in sync mode)"""
         if self.stage and inp.device.type != "cpu":
             if self.cuda:
                 torch.cuda.current_stream().synchronize()
@@ -247,85 +274,152 @@ class ShardedWorker:
             dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
                                    group=self.group)
             out.copy_(h_out)
-            return
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            return _Done()
+        if not self.overlap:  # the compute stream waits right here: no handle to create and keep
+            dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            return _Done()
+        return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                      group=self.group, async_op=True)
 
-    def submit(self, data):
+    def submit(self, data, is_train=True, push_cnt=False):
         if len(self.queue) >= NSLOTS:
             raise RuntimeError("at most %d minibatches in flight" % NSLOTS)
         slot = self.next_slot
         self.next_slot = (slot + 1) % NSLOTS
         self.be.submit(slot, data)
-        self.queue.append(_Pending(slot))
+        self.queue.append(_Pending(slot, self.seq, is_train, push_cnt))
+        self.seq += 1
 
-    def _exchange_counts(self, p):
-        """how many keys does every rank send me?  (device -> pinned host, no host wait here)"""
+    # ---- stages
+    def _counts_issue(self, p):
+        """how many keys does every rank send me?  (asynchronous all_to_all of the per-destination counts)"""
         b = self._bounds[p.slot]
         self.be.bounds(p.slot, self.world, b, self.splits)
-        send_t = b[1:] - b[:-1]
-        recv_t = torch.empty_like(send_t)
-        self._a2a(recv_t, send_t)
+        p.send_t = b[1:] - b[:-1]
+        p.recv_t = torch.empty_like(p.send_t)
+        p.w_cnt = self._a2a(p.recv_t, p.send_t)
+        p.cnt_issued = True
+
+    def _counts_finish(self, p):
+        """device -> pinned host + event; no host wait here"""
+        p.w_cnt.wait()
         h = self._hcnt[p.slot]
-        h[0].copy_(send_t, non_blocking=True)
-        h[1].copy_(recv_t, non_blocking=True)
+        h[0].copy_(p.send_t, non_blocking=True)
+        h[1].copy_(p.recv_t, non_blocking=True)
         if self.cuda:
             self._ev[p.slot].record()
         p.counted = True
 
-    def step(self, is_train=True, push_cnt=False):
-        """one synchronous step over the oldest submitted minibatch"""
-        be, G = self.be, self.world
-        p = self.queue.popleft()
-        slot = p.slot
+    def _sizes(self, p):
+        """the one host wait of a step: on an event recorded a step (or more) ago"""
+        if not p.cnt_issued:
+            self._counts_issue(p)
         if not p.counted:
-            self._exchange_counts(p)
+            self._counts_finish(p)
         if self.cuda:
-            self._ev[slot].synchronize()
-        send = self._hcnt[slot][0].tolist()
-        recv = self._hcnt[slot][1].tolist()
-        nrecv, U = sum(recv), sum(send)
-        keys, cnt = be.unique_keys(slot, U)
+            self._ev[p.slot].synchronize()
+        p.send = self._hcnt[p.slot][0].tolist()
+        p.recv = self._hcnt[p.slot][1].tolist()
+        p.nrecv, p.U = sum(p.recv), sum(p.send)
+        p.roff = [0]
+        for n in p.recv:
+            p.roff.append(p.roff[-1] + n)
+        p.sized = True
 
-        # 1. keys (and epoch-0 counts, riding in the same message) to their owners; owners resolve
-        #    them to table rows once
-        roff = [0]
-        for n in recv:
-            roff.append(roff[-1] + n)
-        if push_cnt:
-            kc = torch.stack((keys, cnt.view(torch.int32).to(torch.int64)), dim=1)   # [U, 2] int64
-            rkc = torch.empty((nrecv, 2), dtype=torch.int64, device=self.device)
-            self._a2a(rkc, kc, recv, send)
-            rkeys = rkc[:, 0].contiguous()
-            rcnt = rkc[:, 1].to(torch.int32).view(torch.float32)
+    def _K(self, p):
+        """keys (and epoch-0 counts, riding in the same message) to their owners"""
+        if not p.sized:
+            self._sizes(p)
+        keys, cnt = self.be.unique_keys(p.slot, p.U)
+        if p.push_cnt:
+            p.kc = torch.stack((keys, cnt.view(torch.int32).to(torch.int64)), dim=1)   # [U, 2] int64
+            p.rkc = torch.empty((p.nrecv, 2), dtype=torch.int64, device=self.device)
+            p.w_keys = self._a2a(p.rkc, p.kc, p.recv, p.send)
         else:
-            rkeys = torch.empty(nrecv, dtype=torch.int64, device=self.device)
-            self._a2a(rkeys, keys, recv, send)
-        rowid = be.owner_resolve(rkeys, roff)
-        if push_cnt:
-            be.owner_push_count(rowid, rkeys, rcnt, roff)  # Push(kFeaCount), source rank after source rank
-        # 2. owners pull rows (every source reads the same model version) and send them back
-        rrows = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
-        if nrecv:
-            be.owner_pull(rowid, rkeys, rrows, roff)
-        rows = torch.empty((U, self.stride), dtype=torch.float32, device=self.device)
-        self._a2a(rows, rrows, send, recv)
-        # 3. worker math on the pulled rows
-        be.forward(slot, rows)
-        if is_train:
-            grads = torch.empty((U, self.stride), dtype=torch.float32, device=self.device)
-            be.backward(slot, rows, grads)
-        # the next minibatch's Localizer has been running beside this step: exchange its counts now,
-        # ahead of the gradient exchange, so that the next step() finds them on the host
-        if self.queue and not self.queue[0].counted:
-            self._exchange_counts(self.queue[0])
-        if is_train:
-            # 4. gradients to the owners, applied in source-rank order
-            rgrads = torch.empty((nrecv, self.stride), dtype=torch.float32, device=self.device)
-            self._a2a(rgrads, grads, recv, send)
-            be.owner_push_grad(rowid, rkeys, rgrads, roff)
+            p.keys = keys
+            p.rkeys = torch.empty(p.nrecv, dtype=torch.int64, device=self.device)
+            p.w_keys = self._a2a(p.rkeys, keys, p.recv, p.send)
+        p.k_issued = True
+
+    def _R(self, p):
+        """owners: resolve the received keys to rows once, Push(kFeaCount), Pull"""
+        be = self.be
+        p.w_keys.wait()
+        if p.push_cnt:
+            p.rkeys = p.rkc[:, 0].contiguous()
+            rcnt = p.rkc[:, 1].to(torch.int32).view(torch.float32)
+        p.rowid = be.owner_resolve(p.rkeys, p.roff, p.mslot)
+        if p.push_cnt:
+            be.owner_push_count(p.rowid, p.rkeys, rcnt, p.roff, p.mslot)  # source rank after source rank
+        p.rrows = torch.empty((p.nrecv, self.stride), dtype=torch.float32, device=self.device)
+        if p.nrecv:
+            be.owner_pull(p.rowid, p.rkeys, p.rrows, p.roff)   # every source reads the same model version
+        p.pulled = True
+
+    def _RW(self, p):
+        p.rows = torch.empty((p.U, self.stride), dtype=torch.float32, device=self.device)
+        p.w_rows = self._a2a(p.rows, p.rrows, p.send, p.recv)
+        p.rw_issued = True
+
+    def _F(self, p):
+        """worker math on the pulled rows"""
+        p.w_rows.wait()
+        self.be.forward(p.slot, p.rows)
+        if p.is_train:
+            p.grads = torch.empty((p.U, self.stride), dtype=torch.float32, device=self.device)
+            self.be.backward(p.slot, p.rows, p.grads)
+
+    def _G(self, p):
+        if p.is_train:
+            p.rgrads = torch.empty((p.nrecv, self.stride), dtype=torch.float32, device=self.device)
+            p.w_grads = self._a2a(p.rgrads, p.grads, p.recv, p.send)
+
+    def _P(self, p):
+        """owners: gradients applied in source-rank order (or the step released)"""
+        if p.is_train:
+            p.w_grads.wait()
+            self.be.owner_push_grad(p.rowid, p.rkeys, p.rgrads, p.roff, p.mslot)
         else:
-            be.owner_release(rowid)
-        return dict(unique=U, sent=send, received=recv, slot=slot)
+            self.be.owner_release(p.rowid, p.mslot)
+
+    # ---- one step
+    def step(self):
+        """completes the oldest submitted minibatch"""
+        q = self.queue
+        p = q[0]
+        nxt = q[1] if len(q) > 1 else None
+        if not self.overlap:
+            self._K(p)
+            self._R(p)
+            self._RW(p)
+            self._F(p)
+            # the next minibatch's Localizer has been running beside this step: exchange its counts now,
+            # ahead of the gradient exchange, so that the next step() finds them on the host
+            if nxt is not None and not nxt.cnt_issued:
+                self._counts_issue(nxt)
+                self._counts_finish(nxt)
+            self._G(p)
+            self._P(p)
+        else:
+            nn = q[2] if len(q) > 2 else None
+            if not p.rw_issued:          # pipeline fill: nothing of this minibatch is under way yet
+                self._K(p)
+                self._R(p)
+                self._RW(p)
+            if nxt is not None and not nxt.k_issued:
+                self._K(nxt)             # small; travels while F(t) computes
+            self._F(p)
+            self._G(p)                   # gradients of t travel ...
+            if nn is not None and not nn.cnt_issued:
+                self._counts_issue(nn)
+            if nxt is not None:
+                self._R(nxt)             # ... while the owners pull for t+1 (before t's update: staleness 1)
+                self._RW(nxt)            # rows of t+1 travel ...
+            self._P(p)                   # ... while the gradients of t are applied
+            if nn is not None and nn.cnt_issued and not nn.counted:
+                self._counts_finish(nn)
+        q.popleft()
+        return dict(unique=p.U, sent=p.send, received=p.recv, slot=p.slot)
 
 
 # --------------------------------------------------------------------------- bench (N > 1)
@@ -357,6 +451,13 @@ def bench_main(args, rank, world, local_rank, hyper):
         build_hip()
     dist.barrier()
     B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
+    # a key present in every worker's minibatch receives `world` gradient pushes per step: the learning
+    # rates are divided by the number of workers so that they move it about as far as one worker's push
+    # would (with the single-worker rates the 8-worker run drifts: logloss 0.74 after 13 steps, 3.9 with
+    # two minibatches in flight).  Throughput does not depend on it.
+    hyper = dict(hyper)
+    hyper["lr"] = hyper["lr"] / world
+    hyper["V_lr"] = hyper["V_lr"] / world
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
     # key ranges balanced on the id space (every rank derives the same split keys): the feature-group id
@@ -393,17 +494,19 @@ def bench_main(args, rank, world, local_rank, hyper):
                         offset=torch.from_numpy(hb["offset"].astype(np.uint32).view(np.int32)).to(be.device),
                         index=torch.from_numpy(hb["index"].view(np.int64)).to(be.device),
                         label=torch.from_numpy(hb["label"]).to(be.device)))
-    worker = ShardedWorker(be, stage_through_host=dry, splits=splits)
+    worker = ShardedWorker(be, stage_through_host=dry, splits=splits, exchange=args.exchange)
+    ahead = 2 if args.exchange == "overlap" else 1
     extra = 0 if args.no_timing else min(args.steps, 30)  # instrumented pass after the timed region
     total = args.warmup + args.steps + extra
 
     def step(i):
-        # the reader's overlap (sgd_learner.cc:196-224): minibatch i+1 is localized while i steps
-        if i + 1 < total:
-            worker.submit(dev[(i + 1) % nd])
-        return worker.step(is_train=True, push_cnt=True)
+        # the reader's overlap (sgd_learner.cc:196-224): later minibatches are localized while i steps
+        if i + ahead < total:
+            worker.submit(dev[(i + ahead) % nd], is_train=True, push_cnt=True)
+        return worker.step()
 
-    worker.submit(dev[0])
+    for i in range(min(ahead, total)):
+        worker.submit(dev[i % nd], is_train=True, push_cnt=True)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -446,6 +549,8 @@ def bench_main(args, rank, world, local_rank, hyper):
                        "avg_remote_keys_per_batch": stats[3].item() / world,
                        "prefilled": not args.no_prefill, "hyper": hyper, "dry_run_shared_gpu": dry,
                        "key_ranges": "uniform" if args.uniform_ranges else "balanced on the id space",
+                       "exchange": "overlap: two minibatches in flight, staleness 1 (sgd_learner.cc:219-223)"
+                                   if args.exchange == "overlap" else "sync: one minibatch at a time, zero staleness",
                        "owned_keys_rank0": int(owned)},
             "roofline": None, "cpu_baseline": None,
             "train_logloss_per_example": stats[0].item() / max(stats[1].item(), 1.0),

@@ -252,14 +252,17 @@ int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const ui
  * carry its key; in the two Push calls the entry of the lowest such source applies every
  * source's value in ascending source order (the result of nsrc per-source calls) and stores the
  * row once.  push_grad_multi ends the step for these rows; a step without it (validation) ends
- * with dfh_shard_release.  Between resolve_multi and that end no other store call may touch
- * the table. */
-int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, uint32_t* d_rowid);
+ * with dfh_shard_release.  mask_slot (0 or 1) names which of two per-row mark words the step
+ * uses: an owner may hold two steps at once — one resolved and pulled, the other still awaiting
+ * its gradients (the reference keeps two minibatches in flight, sgd_learner.cc:219-223) — and
+ * they must use different slots. */
+int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, int mask_slot,
+                            uint32_t* d_rowid);
 int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
-                               const float* d_cnt);
+                               int mask_slot, const float* d_cnt);
 int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
-                              const float* d_grads);
-int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n);
+                              int mask_slot, const float* d_grads);
+int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_slot);
 /* fetch and report the table's sticky device-side error word (capacity, duplicate key,
  * gradient with V for a row without V); synchronises */
 int dfh_table_check(dfh_table* t);

@@ -92,10 +92,10 @@ class OracleBackend:
 
     # owner side (the HIP backend's interface: all sources of a step per call; the double
     # walks the sources one Store call at a time, which is what those calls must equal)
-    def owner_resolve(self, keys, seg):
+    def owner_resolve(self, keys, seg, mslot=0):
         return torch.zeros(keys.numel(), dtype=torch.int32)
 
-    def owner_push_count(self, rowid, keys, cnt, seg):
+    def owner_push_count(self, rowid, keys, cnt, seg, mslot=0):
         for s in range(len(seg) - 1):
             if seg[s + 1] > seg[s]:
                 self.store.push(keys[seg[s]:seg[s + 1]].numpy().view(np.uint64), ob.FEA_COUNT, cnt[seg[s]:seg[s + 1]].numpy())
@@ -106,12 +106,12 @@ class OracleBackend:
             if seg[s + 1] > seg[s]:
                 self._pull(keys[seg[s]:seg[s + 1]], rows[seg[s]:seg[s + 1]])
 
-    def owner_push_grad(self, rowid, keys, grads, seg):
+    def owner_push_grad(self, rowid, keys, grads, seg, mslot=0):
         for s in range(len(seg) - 1):
             if seg[s + 1] > seg[s]:
                 self._push_grad(keys[seg[s]:seg[s + 1]], grads[seg[s]:seg[s + 1]])
 
-    def owner_release(self, rowid):
+    def owner_release(self, rowid, mslot=0):
         pass
 
     def _pull(self, keys, rows):
@@ -142,29 +142,40 @@ class OracleBackend:
         self.store.push(keys.numpy().view(np.uint64), ob.GRADIENT, np.concatenate(vals), np.array(lens, np.int32) if k else None)
 
 
-def emulate_single_store(oracle, batches, V_dim, hyper, push_cnt_steps):
-    """what the sharded step must equal: ONE store receiving, per step, all count pushes (source
-    rank order), then all pulls (same model version), then all gradient pushes (source rank order).
+def emulate_single_store(oracle, batches, V_dim, hyper, push_cnt_steps, overlap=False):
+    """what the sharded step must equal: ONE store receiving the workers' requests in a fixed order.
+    sync:    per step all count pushes (source rank order), all pulls (same model version), all
+             gradient pushes (source rank order).
+    overlap: two minibatches in flight (sgd_learner.cc:219-223): step t's gradient pushes land
+             AFTER the count pushes and pulls of step t+1.
     batches[r][i] = minibatch of rank r at step i.  Returns (store, preds[r][i], loss[r])."""
     world, steps = len(batches), len(batches[0])
     store = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
     preds = [[] for _ in range(world)]
     loss = [0.0] * world
-    for i in range(steps):
-        locs = [oracle.localize(batches[r][i]["offset"], batches[r][i]["index"]) for r in range(world)]
+    locs = [[oracle.localize(batches[r][i]["offset"], batches[r][i]["index"]) for r in range(world)] for i in range(steps)]
+    pulled = {}
+
+    def count_and_pull(i):
         if i < push_cnt_steps:
             for r in range(world):
-                store.push(locs[r]["feaids"], ob.FEA_COUNT, locs[r]["feacnt"])
-        pulled = [store.pull(locs[r]["feaids"]) for r in range(world)]
+                store.push(locs[i][r]["feaids"], ob.FEA_COUNT, locs[i][r]["feacnt"])
+        pulled[i] = [store.pull(locs[i][r]["feaids"]) for r in range(world)]
+
+    for i in range(steps):
+        if i not in pulled:
+            count_and_pull(i)
+        if overlap and i + 1 < steps:
+            count_and_pull(i + 1)
         grads = []
         for r in range(world):
-            b, loc = batches[r][i], locs[r]
-            vals, lens = pulled[r]
+            b, loc = batches[r][i], locs[i][r]
+            vals, lens = pulled[i][r]
             wp, vp = oracle.get_pos(lens)
             p = oracle.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], vals, wp, vp)
             preds[r].append(p)
             loss[r] += oracle.loss_evaluate(b["label"], p)
             grads.append(oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp))
         for r in range(world):
-            store.push(locs[r]["feaids"], ob.GRADIENT, grads[r], pulled[r][1])
+            store.push(locs[i][r]["feaids"], ob.GRADIENT, grads[r], pulled[i][r][1])
     return store, preds, loss

@@ -701,11 +701,11 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
         tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
         bt = capi.Batch(ctx, 150, max_nnz)
         seq = [(epoch, b) for epoch in range(3) for b in batches]
-        w.submit(seq[0][1])
+        w.submit(seq[0][1], True, True)
         for i, (epoch, b) in enumerate(seq):
             if i + 1 < len(seq):  # the next minibatch is localized on the preparation stream meanwhile
-                w.submit(seq[i + 1][1])
-            info = w.step(is_train=True, push_cnt=(epoch == 0))
+                w.submit(seq[i + 1][1], True, seq[i + 1][0] == 0)
+            info = w.step()
             bt.load_host(b["offset"], b["index"], b["value"], b["label"])
             bt.localize()
             bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
@@ -721,6 +721,55 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
         for o in (bt, tb):
             o.close()
         ctx.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_sharded_hip_backend_world1_overlap_over_rccl(capi, oracle):
+    """exchange="overlap" over RCCL (world_size 1: asynchronous all_to_all on the RCCL stream, waits
+    on the compute stream): two minibatches in flight, minibatch t+1 pulled before t's gradients
+    land — equal to the single-store emulation of that order"""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from difacto_amd import sharded
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_testlib import emulate_single_store
+    created = not dist.is_initialized()
+    if created:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 200), rank=0,
+                                world_size=1)
+    try:
+        rng = np.random.default_rng(56)
+        kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
+        batches = [random_batch(rng, 150, 600, 25, binary=(i % 2 == 1)) for i in range(7)]  # shared keys: staleness shows
+        max_nnz = max(int(b["offset"][-1]) for b in batches)
+        be = sharded.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
+        w = sharded.ShardedWorker(be, exchange="overlap")
+        preds = []
+        for i in range(2):
+            w.submit(batches[i], True, i < 3)
+        for i in range(len(batches)):
+            if i + 2 < len(batches):
+                w.submit(batches[i + 2], True, i + 2 < 3)
+            info = w.step()
+            preds.append(be.pred(info["slot"]).copy())
+        be.check()
+        store, want, _ = emulate_single_store(oracle, [batches], 8, kw, push_cnt_steps=3, overlap=True)
+        _, sync_preds, _ = emulate_single_store(oracle, [batches], 8, kw, push_cnt_steps=3, overlap=False)
+        for i in range(len(batches)):
+            assert_close(preds[i], want[0][i], rtol=5e-5, what="pred step %d" % i)
+        # the two orders really differ on this data (otherwise the test proves nothing)
+        assert any(np.abs(want[0][i] - sync_preds[0][i]).max() > 1e-3 for i in range(1, len(batches)))
+        keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
+        vo, lo = store.pull(keys)
+        vg, lg = be.table.pull(keys)
+        assert np.array_equal(lg, lo)
+        assert_close(vg, vo, rtol=2e-4, what="weights")
+        be.close()
     finally:
         if created:
             dist.destroy_process_group()

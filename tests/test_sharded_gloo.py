@@ -37,7 +37,7 @@ def _splits(kind):
     return balanced_splits(reverse_bytes_np(ids), WORLD)
 
 
-def _worker(rank, world, port, out_dir, kind):
+def _worker(rank, world, port, out_dir, kind, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,14 +45,16 @@ def _worker(rank, world, port, out_dir, kind):
     from sharded_testlib import OracleBackend
     be = OracleBackend(V_DIM, HYPER)
     splits = _splits(kind)
-    w = ShardedWorker(be, splits=splits)
+    w = ShardedWorker(be, splits=splits, exchange=exchange)
+    ahead = 2 if exchange == "overlap" else 1
     preds, infos = [], []
     batches = make_batches(rank)
-    w.submit(batches[0])
+    for i in range(min(ahead, len(batches))):
+        w.submit(batches[i], True, i < 2)
     for i in range(len(batches)):
-        if i + 1 < len(batches):  # the next minibatch is localized (and its counts exchanged) during this step
-            w.submit(batches[i + 1])
-        infos.append(w.step(is_train=True, push_cnt=(i < 2)))
+        if i + ahead < len(batches):  # later minibatches are localized (and their counts exchanged) during this step
+            w.submit(batches[i + ahead], True, i + ahead < 2)
+        infos.append(w.step())
         preds.append(be.pred().copy())
     # every rank owns a disjoint key range
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=be.loss,
@@ -68,15 +70,15 @@ def _worker(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["uniform", "balanced"])
-def test_sharded_world2_matches_single_store(tmp_path, oracle, kind):
+@pytest.mark.parametrize("kind,exchange", [("uniform", "sync"), ("balanced", "sync"), ("balanced", "overlap")])
+def test_sharded_world2_matches_single_store(tmp_path, oracle, kind, exchange):
     from oracle import bindings as ob
-    port = 29600 + (os.getpid() % 300) + (7 if kind == "balanced" else 0)
-    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), kind), nprocs=WORLD, join=True)
+    port = 29600 + (os.getpid() % 300) + (7 if kind == "balanced" else 0) + (13 if exchange == "overlap" else 0)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), kind, exchange), nprocs=WORLD, join=True)
 
     from sharded_testlib import emulate_single_store
     batches = [make_batches(r) for r in range(WORLD)]
-    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2)
+    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2, overlap=(exchange == "overlap"))
 
     total_keys = 0
     for r in range(WORLD):

@@ -26,7 +26,7 @@ def make_batches(rank):
     return [random_batch(rng, ROWS, 2 ** 64 - 1 if i % 2 else 3000, 30, binary=(i % 2 == 0)) for i in range(STEPS)]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, exchange):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,13 +41,15 @@ def _worker(rank, world, port, out_dir):
     if world == 4:  # one of the two cases runs with split keys balanced on the data instead of uniform ranges
         ids = np.concatenate([b["index"] for r in range(world) for b in make_batches(r)])
         splits = sharded.balanced_splits(reverse_bytes_np(ids), world)
-    w = sharded.ShardedWorker(be, stage_through_host=True, splits=splits)
+    w = sharded.ShardedWorker(be, stage_through_host=True, splits=splits, exchange=exchange)
+    ahead = 2 if exchange == "overlap" else 1
     preds, infos = [], []
-    w.submit(batches[0])
+    for i in range(min(ahead, len(batches))):
+        w.submit(batches[i], True, i < 2)
     for i in range(len(batches)):
-        if i + 1 < len(batches):
-            w.submit(batches[i + 1])
-        info = w.step(is_train=True, push_cnt=(i < 2))
+        if i + ahead < len(batches):
+            w.submit(batches[i + ahead], True, i + ahead < 2)
+        info = w.step()
         infos.append(info)
         preds.append(be.pred(info["slot"]).copy())
     be.check()
@@ -68,13 +70,13 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("WORLD", [2, 4])
-def test_sharded_hip_ranks_share_one_gpu(tmp_path, oracle, WORLD):
+@pytest.mark.parametrize("WORLD,exchange", [(2, "sync"), (4, "sync"), (2, "overlap"), (4, "overlap")])
+def test_sharded_hip_ranks_share_one_gpu(tmp_path, oracle, WORLD, exchange):
     from sharded_testlib import emulate_single_store
-    port = 29900 + (os.getpid() % 90) + WORLD
-    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    port = 29900 + (os.getpid() % 80) + WORLD + (10 if exchange == "overlap" else 0)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), exchange), nprocs=WORLD, join=True)
     batches = [make_batches(r) for r in range(WORLD)]
-    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2)
+    store, preds, loss = emulate_single_store(oracle, batches, V_DIM, HYPER, push_cnt_steps=2, overlap=(exchange == "overlap"))
     total = 0
     for r in range(WORLD):
         got = np.load(os.path.join(tmp_path, "rank%d.npz" % r))
