@@ -408,16 +408,16 @@ class ShardedWorker:
                 self._RW(p)
             if nxt is not None and not nxt.k_issued:
                 self._K(nxt)             # small; travels while F(t) computes
+            if nn is not None and not nn.cnt_issued:
+                self._counts_issue(nn)   # tiny, ahead of the big transfers on the collective stream
             self._F(p)
             self._G(p)                   # gradients of t travel ...
-            if nn is not None and not nn.cnt_issued:
-                self._counts_issue(nn)
+            if nn is not None and nn.cnt_issued and not nn.counted:
+                self._counts_finish(nn)  # early in the step: the next step()'s one host wait finds it done
             if nxt is not None:
                 self._R(nxt)             # ... while the owners pull for t+1 (before t's update: staleness 1)
                 self._RW(nxt)            # rows of t+1 travel ...
             self._P(p)                   # ... while the gradients of t are applied
-            if nn is not None and nn.cnt_issued and not nn.counted:
-                self._counts_finish(nn)
         q.popleft()
         return dict(unique=p.U, sent=p.send, received=p.recv, slot=p.slot)
 
