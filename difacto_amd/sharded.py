@@ -512,11 +512,20 @@ def bench_main(args, rank, world, local_rank, hyper):
     torch.cuda.synchronize()
     dist.barrier()
     be.progress()
+    # live timing of the forward kernel (its dispatch carries the event pair) on every 4th step of rank 0
+    fwd_mask = 0 if (args.no_timing or rank != 0) else (1 << capi.K_FORWARD)
+    be.ctx.get_timing(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        info = step(args.warmup + i)
+        if fwd_mask and i % 4 == 0:
+            be.ctx.set_timing_mask(fwd_mask)
+            info = step(args.warmup + i)
+            be.ctx.set_timing_mask(0)
+        else:
+            info = step(args.warmup + i)
     torch.cuda.synchronize()
     dist.barrier()
+    fwd_t = be.ctx.get_timing(reset=True).get("forward", (0.0, 0)) if fwd_mask else (0.0, 0)
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
@@ -536,6 +545,13 @@ def bench_main(args, rank, world, local_rank, hyper):
     if rank == 0:
         ex_per_s = args.steps * B * world / dt
         r_g = S * (1 + k) * 4
+        roofline = None
+        if fwd_t[1] > 0:
+            fwd_ms = fwd_t[0] / fwd_t[1]
+            achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel="k_forward (rows pulled into the exchange layout, rank 0)", achieved=achieved,
+                            peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=None,
+                            algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms, launches_timed=int(fwd_t[1]))
         out = {
             "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
             "value": ex_per_s, "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -552,7 +568,7 @@ def bench_main(args, rank, world, local_rank, hyper):
                        "exchange": "overlap: two minibatches in flight, staleness 1 (sgd_learner.cc:219-223)"
                                    if args.exchange == "overlap" else "sync: one minibatch at a time, zero staleness",
                        "owned_keys_rank0": int(owned)},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": None,
             "train_logloss_per_example": stats[0].item() / max(stats[1].item(), 1.0),
             "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
             "prefill_seconds": t_prefill,
