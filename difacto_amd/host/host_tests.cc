@@ -4,8 +4,9 @@
  *   FMLoss.NoV / FMLoss.HasV        tests/cpp/fm_loss_test.cc:12-83
  *   Localizer.Base / BaseHash       tests/cpp/localizer_test.cc:12-49
  *   SGDLearner.Basic                tests/cpp/sgd_learner_test.cc:9-49  (fused and literal worker loops)
- * plus Store Pull/Push and Updater Save/Load round trips.  Needs a GPU.
- * usage: difacto_host_tests <path to rcv1_100.libsvm>
+ *   BatchReader.Read / RandRead / PartRead   tests/cpp/batch_reader_test.cc:9-57
+ * plus Store Pull/Push and Updater Save/Load round trips.  Needs a GPU, except the reader cases.
+ * usage: difacto_host_tests <path to rcv1_100.libsvm> [reader]     ("reader": only the host-only cases)
  */
 #include <cmath>
 #include <cstdio>
@@ -68,6 +69,48 @@ static void TestLocalizer() {
   s = 0;
   for (auto i : uidx) s += i;
   EXPECT(s == 478817ULL);
+}
+
+// the minibatch checksums of tests/cpp/batch_reader_test.cc:9-57 (batch_size 37 over the 100 rows)
+static void TestBatchReader() {
+  const int label[] = {11, 15, 10};
+  const int len[] = {37, 37, 26};
+  const size_t os[] = {85035, 63968, 31323};
+  const uint32_t idx[] = {95285478, 70504854, 62972349};
+  const float val[] = {37.0f, 37.0f, 26.0f};
+  for (int shuffled = 0; shuffled < 2; ++shuffled) {
+    LibsvmBatchReader reader(g_data, 0, 1, 37, shuffled ? 37 : 0);
+    int i = 0;
+    while (reader.Next()) {
+      EXPECT(i < 3);
+      if (i >= 3) break;
+      const auto& b = reader.Value();
+      const int size = static_cast<int>(b.size);
+      float lab = 0, v2 = 0;
+      size_t o = 0;
+      uint32_t ix = 0;
+      for (int r = 0; r < size; ++r) lab += b.label[r];
+      for (int r = 0; r <= size; ++r) o += b.offset[r] - b.offset[0];
+      const size_t nnz = b.offset[size] - b.offset[0];
+      for (size_t j = 0; j < nnz; ++j) {
+        ix += static_cast<uint32_t>(b.index[b.offset[0] + j]);
+        const float x = b.value ? b.value[b.offset[0] + j] : 1.0f;
+        v2 += x * x;
+      }
+      EXPECT(static_cast<int>(lab) == label[i]);
+      EXPECT(size == len[i]);
+      if (shuffled) EXPECT(o != os[i]); else EXPECT(o == os[i]);   // rows permuted inside the batch
+      EXPECT(ix == idx[i]);
+      EXPECT(std::fabs(val[i] - v2) <= 1e-4);
+      ++i;
+    }
+    EXPECT(i == 3);
+  }
+  // PartRead: the second of two parts holds about half of the rows
+  LibsvmBatchReader part(g_data, 1, 2, 37);
+  int ttl = 0;
+  while (part.Next()) ttl += static_cast<int>(part.Value().size);
+  EXPECT(ttl >= 40 && ttl <= 60);
 }
 
 static void TestFMLossNoV() {
@@ -191,7 +234,14 @@ int main(int argc, char** argv) {
     return 2;
   }
   g_data = argv[1];
+  if (argc > 2 && std::string(argv[2]) == "reader") {  // host-only cases: no device is touched
+    TestBatchReader();
+    printf("[%s] %s\n", g_fail ? "FAILED" : "  OK  ", "BatchReader.Read+RandRead+PartRead");
+    printf("%s\n", g_fail ? "SOME TESTS FAILED" : "ALL HOST TESTS PASSED");
+    return g_fail ? 1 : 0;
+  }
   struct { const char* name; std::function<void()> fn; } tests[] = {
+      {"BatchReader.Read+RandRead+PartRead", TestBatchReader},
       {"Localizer.Base+BaseHash", TestLocalizer},
       {"FMLoss.NoV", TestFMLossNoV},
       {"FMLoss.HasV", TestFMLossHasV},

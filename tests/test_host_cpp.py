@@ -24,6 +24,14 @@ def test_host_binaries_build(built):
     assert "usage: difacto key1=val1" in r.stderr
 
 
+def test_batch_reader_checksums_on_cpu(built):
+    """the reader that feeds the path against the reference's own minibatch checksums
+    (tests/cpp/batch_reader_test.cc:9-57: Read, RandRead, PartRead) - host only, no device touched"""
+    r = subprocess.run([os.path.join(built, "difacto_host_tests"), DATA, "reader"], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL HOST TESTS PASSED" in r.stdout
+
+
 def test_cli_fails_loudly_without_gpu(built):
     import torch
     if torch.cuda.is_available():
