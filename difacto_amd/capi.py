@@ -25,7 +25,7 @@ SYMBOLS = [
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
-    "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
+    "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
     "dfh_shard_push_grad_multi", "dfh_shard_release",
 ]
 K_COUNT = 7
@@ -137,6 +137,8 @@ def lib():
     L.dfh_shard_push_count_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_shard_push_grad_resolved.argtypes = [vp, vp, vp, sz, vp]
     L.dfh_table_check.argtypes = [vp]
+    L.dfh_table_save.argtypes = [vp, C.c_char_p, i32, PP(u64)]
+    L.dfh_table_load.argtypes = [vp, C.c_char_p, u64, u64, PP(i32), PP(u64)]
     L.dfh_shard_resolve_multi.argtypes = [vp, vp, vp, i32, i32, vp]
     L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
@@ -328,6 +330,18 @@ class Table:
         has_V = np.ascontiguousarray(has_V, np.int32)
         V = None if V is None else np.ascontiguousarray(V, np.float32)
         _ck(lib().dfh_table_import(self.h, len(keys), _p(keys), _p(scal), _p(has_V), _p(V)))
+
+    def save(self, path, save_aux=True):
+        """Updater::Save to a file (the C++ host's model format); returns the number of entries written"""
+        n = C.c_uint64(0)
+        _ck(lib().dfh_table_save(self.h, str(path).encode(), 1 if save_aux else 0, C.byref(n)))
+        return n.value
+
+    def load(self, path, key_lo=0, key_hi=0):
+        """Updater::Load of the keys in [key_lo, key_hi) (key_hi = 0: unbounded) -> (entries loaded, has_aux)"""
+        n, aux = C.c_uint64(0), C.c_int(0)
+        _ck(lib().dfh_table_load(self.h, str(path).encode(), key_lo, key_hi, C.byref(aux), C.byref(n)))
+        return n.value, bool(aux.value)
 
     def warm_start(self, d_keys, n, w0=0.01, cnt0=100.0):
         _ck(lib().dfh_table_warm_start(self.h, _dp(d_keys), n, w0, cnt0))

@@ -1110,6 +1110,126 @@ int to_u32_offsets(const size_t* offset, size_t nrows, std::vector<uint32_t>* ou
 }
 }  // namespace
 
+// ---- model files (Updater::Save / Load, include/difacto/updater.h:40-47: stubs in the reference, so the
+// format is ours and shared with the C++ host's DeviceSGDUpdater):
+//   "DFHM", u32 version, i32 V_dim, i32 has_aux, u64 n, then n entries
+//   {u64 key, f32 w, [f32 fea_cnt, sqrt_g, z if aux], i32 has_V, [V_dim f32 V, [V_dim f32 acc if aux]] if has_V}
+int dfh_table_save(dfh_table* t, const char* path, int save_aux, uint64_t* n_saved) {
+  DFH_ARG(t && path, "dfh_table_save: NULL argument");
+  uint64_t n = 0;
+  int rc = dfh_table_size(t, &n);
+  if (rc) return rc;
+  const int k = t->v.k;
+  const size_t kk = (size_t)std::max(k, 1);
+  const uint64_t cap = std::max<uint64_t>(n, 1);
+  std::vector<uint64_t> keys(cap);
+  std::vector<float> scal(cap * 4), V(cap * 2 * kk);
+  std::vector<int> hasv(cap);
+  uint64_t m = 0;
+  rc = dfh_table_export(t, cap, keys.data(), scal.data(), hasv.data(), V.data(), &m);
+  if (rc) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    set_error(std::string("dfh_table_save: cannot open ") + path);
+    return DFH_ERR_ARG;
+  }
+  std::vector<char> iobuf(1 << 22);
+  setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+  // entries with w == 0 and no V carry nothing a predictor needs: skipped unless aux is wanted
+  uint64_t kept = 0;
+  for (uint64_t i = 0; i < m; ++i) kept += (save_aux || scal[i * 4 + 1] != 0 || hasv[i]) ? 1 : 0;
+  const uint32_t ver = 1;
+  const int32_t kv = k, aux = save_aux ? 1 : 0;
+  bool ok = fwrite("DFHM", 1, 4, f) == 4 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&kv, 4, 1, f) == 1 &&
+            fwrite(&aux, 4, 1, f) == 1 && fwrite(&kept, 8, 1, f) == 1;
+  for (uint64_t i = 0; ok && i < m; ++i) {
+    if (!(save_aux || scal[i * 4 + 1] != 0 || hasv[i])) continue;
+    ok = ok && fwrite(&keys[i], 8, 1, f) == 1 && fwrite(&scal[i * 4 + 1], 4, 1, f) == 1;
+    if (save_aux) {
+      const float a3[3] = {scal[i * 4 + 0], scal[i * 4 + 2], scal[i * 4 + 3]};
+      ok = ok && fwrite(a3, 4, 3, f) == 3;
+    }
+    const int32_t hv = hasv[i];
+    ok = ok && fwrite(&hv, 4, 1, f) == 1;
+    if (hv && k > 0) {
+      ok = ok && fwrite(&V[i * 2 * k], 4, (size_t)k, f) == (size_t)k;
+      if (save_aux) ok = ok && fwrite(&V[i * 2 * k + k], 4, (size_t)k, f) == (size_t)k;
+    }
+  }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) {
+    set_error(std::string("dfh_table_save: write error on ") + path);
+    return DFH_ERR_ARG;
+  }
+  if (n_saved) *n_saved = kept;
+  return DFH_OK;
+}
+
+int dfh_table_load(dfh_table* t, const char* path, uint64_t key_lo, uint64_t key_hi, int* has_aux, uint64_t* n_loaded) {
+  DFH_ARG(t && path, "dfh_table_load: NULL argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    set_error(std::string("dfh_table_load: cannot open ") + path);
+    return DFH_ERR_ARG;
+  }
+  std::vector<char> iobuf(1 << 22);
+  setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+  char magic[4];
+  uint32_t ver = 0;
+  int32_t k = 0, aux = 0;
+  uint64_t n = 0;
+  bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "DFHM", 4) && fread(&ver, 4, 1, f) == 1 && fread(&k, 4, 1, f) == 1 &&
+            fread(&aux, 4, 1, f) == 1 && fread(&n, 8, 1, f) == 1;
+  if (!ok || k != t->v.k) {
+    fclose(f);
+    set_error(!ok ? "dfh_table_load: not a difacto-hip model file" : "dfh_table_load: model V_dim differs from the table's");
+    return DFH_ERR_ARG;
+  }
+  if (has_aux) *has_aux = aux != 0;
+  const size_t kk = (size_t)std::max(k, 1);
+  const size_t chunk = 1 << 20;
+  std::vector<uint64_t> keys;
+  std::vector<float> scal, V, row(2 * kk);
+  std::vector<int> hasv;
+  uint64_t loaded = 0;
+  int rc = DFH_OK;
+  auto flush = [&]() -> int {
+    if (keys.empty()) return DFH_OK;
+    int r = dfh_table_import(t, keys.size(), keys.data(), scal.data(), hasv.data(), V.data());
+    loaded += keys.size();
+    keys.clear(); scal.clear(); V.clear(); hasv.clear();
+    return r;
+  };
+  for (uint64_t i = 0; ok && rc == DFH_OK && i < n; ++i) {
+    uint64_t key;
+    float w, a3[3] = {0.f, 0.f, 0.f};
+    int32_t hv;
+    ok = fread(&key, 8, 1, f) == 1 && fread(&w, 4, 1, f) == 1;
+    if (ok && aux) ok = fread(a3, 4, 3, f) == 3;
+    ok = ok && fread(&hv, 4, 1, f) == 1;
+    std::fill(row.begin(), row.end(), 0.f);
+    if (ok && hv && k > 0) {
+      ok = fread(row.data(), 4, (size_t)k, f) == (size_t)k;
+      if (ok && aux) ok = fread(row.data() + k, 4, (size_t)k, f) == (size_t)k;
+    }
+    if (!ok) break;
+    if (key < key_lo || (key_hi != 0 && key >= key_hi)) continue;  // another shard's key
+    keys.push_back(key);
+    scal.push_back(a3[0]); scal.push_back(w); scal.push_back(a3[1]); scal.push_back(a3[2]);
+    hasv.push_back(hv);
+    V.insert(V.end(), row.begin(), row.begin() + 2 * kk);
+    if (keys.size() == chunk) rc = flush();
+  }
+  fclose(f);
+  if (!ok) {
+    set_error(std::string("dfh_table_load: truncated model file ") + path);
+    return DFH_ERR_ARG;
+  }
+  if (rc == DFH_OK) rc = flush();
+  if (n_loaded) *n_loaded = loaded;
+  return rc;
+}
+
 int dfh_fm_predict(dfh_ctx* c, int V_dim, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,
                    const float* weights, size_t nweights, const int* w_pos, const int* V_pos, size_t npos, float* pred) {
   DFH_ARG(c && V_dim >= 0, "dfh_fm_predict: bad argument");

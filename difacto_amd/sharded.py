@@ -257,11 +257,44 @@ class ShardedWorker:
         self._hcnt = [torch.zeros((2, G), dtype=torch.int64, pin_memory=self.cuda) for _ in range(NSLOTS)]
         self._ev = [torch.cuda.Event() for _ in range(NSLOTS)] if self.cuda else None
         self.splits = None
+        self.splits_host = uniform_splits(G) if G > 1 else np.zeros(0, np.uint64)
         if splits is not None and G > 1:
             sp = np.ascontiguousarray(np.asarray(splits, dtype=np.uint64))
             if len(sp) != G - 1 or np.any(sp[1:] < sp[:-1]):
                 raise ValueError("splits must be world-1 ascending keys")
             self.splits = torch.from_numpy(sp.view(np.int64).copy()).to(self.device)
+            self.splits_host = sp
+
+    # ---- model files: Updater::Save / Load on the sharded table (one part per rank)
+    @staticmethod
+    def part_path(prefix, rank):
+        return "%s.part-%05d" % (prefix, rank)
+
+    def owned_range(self):
+        """[lo, hi) of the reversed keys this rank owns (hi = 0: no upper bound)"""
+        lo = int(self.splits_host[self.rank - 1]) if self.rank > 0 else 0
+        hi = int(self.splits_host[self.rank]) if self.rank < self.world - 1 else 0
+        return lo, hi
+
+    def save_model(self, prefix, save_aux=True):
+        """every rank writes its shard to <prefix>.part-<rank> (the C++ host's model format); call between steps"""
+        if self.queue and any(p.rw_issued or p.pulled for p in self.queue):
+            raise RuntimeError("save_model: a step is under way")
+        self.be.sync()
+        n = self.be.table.save(self.part_path(prefix, self.rank), save_aux)
+        dist.barrier(group=self.group)
+        return n
+
+    def load_model(self, prefix, nparts):
+        """every rank reads all `nparts` part files and keeps the keys of its own range: the model may
+        have been written under any number of ranks and any split keys"""
+        lo, hi = self.owned_range()
+        total = 0
+        for r in range(nparts):
+            n, _ = self.be.table.load(self.part_path(prefix, r), lo, hi)
+            total += n
+        dist.barrier(group=self.group)
+        return total
 
     # ---- plumbing
     def _a2a(self, out, inp, out_splits=None, in_splits=None):

@@ -129,6 +129,15 @@ int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const f
  * dump every entry: keys[n], scal[n*4] = {fea_cnt,w,sqrt_g,z}, has_V[n], V[n*2*V_dim] */
 int dfh_table_export(dfh_table* t, uint64_t cap, uint64_t* keys, float* scal, int* has_V, float* V, uint64_t* n);
 int dfh_table_import(dfh_table* t, uint64_t n, const uint64_t* keys, const float* scal, const int* has_V, const float* V);
+/* Updater::Save / Load to a file (include/difacto/updater.h:40-47; TODO stubs in the reference,
+ * src/sgd/sgd_updater.h:44-50, so the format is ours — the one the C++ host's --model_out / --model_in
+ * read and write).  save_aux: also keep fea_cnt, the FTRL state and the AdaGrad accumulators, i.e.
+ * everything needed to continue training; without it, entries with w == 0 and no V are dropped.
+ * dfh_table_load imports only keys in [key_lo, key_hi) (key_hi == 0: no upper bound): a shard
+ * loads its own range out of any number of part files, whatever sharding wrote them.
+ * Host-side I/O; both synchronise. */
+int dfh_table_save(dfh_table* t, const char* path, int save_aux, uint64_t* n_saved);
+int dfh_table_load(dfh_table* t, const char* path, uint64_t key_lo, uint64_t key_hi, int* has_aux, uint64_t* n_loaded);
 
 /* warm start (resume / benchmark preload): insert n unique keys (DEVICE pointer)
  * with w = w0, fea_cnt = cnt0 and an allocated V (hash init).  Asynchronous. */

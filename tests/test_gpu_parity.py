@@ -259,6 +259,58 @@ def test_table_export_import_roundtrip(capi, ctx, oracle):
     tb2.close()
 
 
+def test_table_save_load_files(capi, ctx, oracle, tmp_path):
+    """Updater::Save / Load through model files: with the auxiliary state the copy continues training
+    identically; without it only what a predictor needs survives; a key range loads a shard's share"""
+    rng = np.random.default_rng(8)
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=1, V_init_scale=0.2, seed=3)
+    batches = [random_batch(rng, 100, 500, 20, binary=(i == 0)) for i in range(3)]
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    ta = capi.Table(ctx, 1 << 14, V_dim=6, **kw)
+    bt = capi.Batch(ctx, 100, max_nnz)
+
+    def train(tb, bs, first_epoch):
+        for b in bs:
+            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bt.localize()
+            bt.sgd_step(tb, is_train=True, push_cnt=first_epoch)
+        return bt.pred()
+
+    train(ta, batches, True)
+    train(ta, batches, False)
+    full, lean = str(tmp_path / "full.model"), str(tmp_path / "lean.model")
+    n_full = ta.save(full, save_aux=True)
+    n_lean = ta.save(lean, save_aux=False)
+    assert n_full == ta.size() and 0 < n_lean <= n_full
+    tb = capi.Table(ctx, 1 << 14, V_dim=6, **kw)
+    assert tb.load(full) == (n_full, True)
+    ea, eb = ta.export(), tb.export()
+    oa, ob_ = np.argsort(ea["keys"]), np.argsort(eb["keys"])
+    for f in ("keys", "scal", "has_V", "V"):
+        assert np.array_equal(ea[f][oa], eb[f][ob_]), f
+    assert np.array_equal(train(ta, batches[:1], False), train(tb, batches[:1], False))  # training continues identically
+    tc = capi.Table(ctx, 1 << 14, V_dim=6, **kw)
+    assert tc.load(lean) == (n_lean, False)
+    keys = ea["keys"]
+    va, la = ta.pull(keys)
+    ta2 = capi.Table(ctx, 1 << 14, V_dim=6, **kw)
+    ta2.load(full)
+    v2, l2 = ta2.pull(keys)
+    vc, lc = tc.pull(keys)
+    assert np.array_equal(l2, lc) and np.array_equal(v2, vc)   # same weights for a predictor ...
+    assert not tc.export()["scal"][:, [0, 2, 3]].any()          # ... and no optimiser state
+    # a shard's share
+    mid = np.uint64(1 << 63)
+    td = capi.Table(ctx, 1 << 14, V_dim=6, **kw)
+    n_lo, _ = td.load(full, 0, int(mid))
+    n_hi, _ = td.load(full, int(mid), 0)
+    assert n_lo == int((keys < mid).sum()) and n_hi == int((keys >= mid).sum()) and n_lo + n_hi == n_full
+    with pytest.raises(capi.DfhError):
+        capi.Table(ctx, 1 << 10, V_dim=5, **kw).load(full)       # V_dim mismatch is an error, not a reinterpretation
+    for o in (ta, tb, tc, ta2, td, bt):
+        o.close()
+
+
 # ------------------------------------------------------------------ the fused step
 def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True, capacity=1 << 16,
                          table=None):

@@ -61,6 +61,14 @@ def test_cli_trains_from_conf(built, tmp_path):
     losses = [float(l.split("loss = ")[1].split(",")[0]) for l in r.stderr.splitlines() if "Training: loss" in l]
     assert len(losses) >= 2 and losses[-1] < losses[0]
     assert os.path.getsize(model) > 100
+    # the file the C++ host wrote loads through the C ABI (one format, two writers/readers)
+    from difacto_amd import capi
+    ctx = capi.Context(0)
+    tb = capi.Table(ctx, 1 << 17, V_dim=8, init_mode=capi.INIT_REFRAND)
+    n, _ = tb.load(model)
+    assert n > 1000 and tb.size() == n
+    tb.close()
+    ctx.close()
     # resume from the saved model: the first epoch starts where the last one ended
     r2 = subprocess.run([os.path.join(built, "difacto"), "argfile=" + os.path.join(ROOT, "example", "rcv1_fm.conf"),
                          "model_in=" + model, "max_num_epochs=1"], capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -60,6 +60,28 @@ def _worker(rank, world, port, out_dir, exchange):
                                         for r in range(world) for b in make_batches(r)]))
     mine = allkeys[sharded.owner_of(allkeys, sharded.uniform_splits(world) if splits is None else splits) == rank]
     nkeys = be.table.size()
+    # Updater::Save on the sharded table: one part per rank ...
+    prefix = os.path.join(out_dir, "model")
+    w.save_model(prefix, save_aux=True)
+    if rank == 0:
+        # ... and Load into ONE table (a different sharding than the one that wrote it): must hold the whole model
+        from difacto_amd import capi
+        t1 = capi.Table(be.ctx, 1 << 16, V_dim=V_DIM, init_mode=capi.INIT_HASH, **HYPER)
+        got = sum(t1.load(w.part_path(prefix, r))[0] for r in range(world))
+        mv, ml = t1.pull(allkeys)
+        np.savez(os.path.join(out_dir, "merged.npz"), n=got, keys=allkeys, vals=mv, lens=ml)
+        t1.close()
+    # ... and back into a sharded table of the same layout: every rank keeps exactly its own keys
+    from difacto_amd import capi
+    t2 = capi.Table(be.ctx, 1 << 16, V_dim=V_DIM, init_mode=capi.INIT_HASH, **HYPER)
+    lo, hi = w.owned_range()
+    n2 = sum(t2.load(w.part_path(prefix, r), lo, hi)[0] for r in range(world))
+    assert n2 == nkeys, (n2, nkeys)
+    e1, e2 = be.table.export(), t2.export()
+    o1, o2 = np.argsort(e1["keys"]), np.argsort(e2["keys"])
+    assert np.array_equal(e1["keys"][o1], e2["keys"][o2]) and np.array_equal(e1["scal"][o1], e2["scal"][o2])
+    assert np.array_equal(e1["has_V"][o1], e2["has_V"][o2]) and np.array_equal(e1["V"][o1], e2["V"][o2])
+    t2.close()
     vals, lens = be.table.pull(mine)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=prog.loss, nkeys=nkeys,
              sent=np.array([x["sent"] for x in infos]), recv=np.array([x["received"] for x in infos]),
@@ -90,3 +112,8 @@ def test_sharded_hip_ranks_share_one_gpu(tmp_path, oracle, WORLD, exchange):
         assert np.any(lens > 1)
         total += int(got["nkeys"])
     assert total == store.size()
+    m = np.load(os.path.join(tmp_path, "merged.npz"))
+    assert int(m["n"]) == store.size()
+    vals, lens = store.pull(m["keys"])
+    assert np.array_equal(m["lens"], lens)
+    np.testing.assert_allclose(m["vals"], vals, rtol=2e-5, atol=1e-6, err_msg="model merged from the part files")
