@@ -210,6 +210,7 @@ def main():
             ctx.set_timing_mask(0)
         else:
             step(args.warmup + i)
+    t_enqueued = time.perf_counter() - t0   # host side only: everything is queued, nothing awaited yet
     ctx.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -261,6 +262,7 @@ def main():
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "kernel_ms_per_step": breakdown,
         "kernel_ms_per_step_note": "separate instrumented pass after the timed region (HIP events around every kernel group)",
         "train_logloss_per_example": prog.loss / max(prog.nrows, 1),
