@@ -689,35 +689,42 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
         o.close()
 
 
-def test_pipelined_prep_matches_serial(capi, oracle):
-    """preparing batch t+1 on the second stream while batch t trains gives the
-    same predictions and the same model as the serial order"""
-    rng = np.random.default_rng(31)
-    batches = [random_batch(rng, 200, 500, 30, binary=(i % 2 == 0), empty_rows=False) for i in range(6)]
+@pytest.mark.parametrize("streams,nbatch,prep_lookup", [(1, 2, True), (2, 4, False), (3, 5, True)])
+def test_pipelined_prep_matches_serial(capi, oracle, streams, nbatch, prep_lookup):
+    """preparing later batches on 1..3 preparation streams (with as many or more batch objects in
+    rotation, ragged sizes) while an earlier one trains gives the same predictions and the same
+    model as the serial order"""
+    rng = np.random.default_rng(31 + streams)
+    batches = [random_batch(rng, int(rng.integers(20, 200)), 500, 30, binary=(i % 2 == 0), empty_rows=(i % 3 == 0))
+               for i in range(7)]
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=5)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     results = []
-    for pipelined in (False, True):
+    for depth in (0, streams):
         ctx = capi.Context(0)
-        ctx.set_pipeline(pipelined)
+        ctx.set_pipeline(depth)
+        ahead = max(depth, 1)
         tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
-        bts = [capi.Batch(ctx, 200, max_nnz), capi.Batch(ctx, 200, max_nnz)]
+        bts = [capi.Batch(ctx, 200, max_nnz) for _ in range(nbatch if depth else 2)]
 
         def prep(i):
             b = batches[i % len(batches)]
-            bts[i % 2].load_host(b["offset"], b["index"], b["value"], b["label"])
-            bts[i % 2].localize()
-            bts[i % 2].lookup(tb)
+            bt = bts[i % len(bts)]
+            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bt.localize()
+            if prep_lookup:
+                bt.lookup(tb)
 
         preds = []
-        nsteps = 18
-        prep(0)
+        nsteps = 23
+        for i in range(ahead):
+            prep(i)
         for i in range(nsteps):
-            if i + 1 < nsteps:
-                prep(i + 1)
-            bts[i % 2].sgd_step(tb, is_train=True, push_cnt=(i < len(batches)))
+            if i + ahead < nsteps:
+                prep(i + ahead)
+            bts[i % len(bts)].sgd_step(tb, is_train=(i % 6 != 5), push_cnt=(i < len(batches)))
             if i % 5 == 4:
-                preds.append(bts[i % 2].pred())
+                preds.append(bts[i % len(bts)].pred())
         keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
         results.append((preds, tb.pull(keys)))
         for o in bts + [tb]:
