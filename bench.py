@@ -200,7 +200,7 @@ def main():
     # live timing of the dominant kernel inside the timed region: the k_forward dispatch of every
     # TIMING_EVERY-th step carries a start/stop HIP event pair (hipExtLaunchKernelGGL: the kernel's own
     # begin/end stamps, no marker packets).  Every step would cost the job 3 %, every 4th costs 1 %.
-    fwd_mask = 0 if args.no_timing else (1 << capi.K_FORWARD)
+    fwd_mask = 0 if args.no_timing else ((1 << capi.K_FORWARD) | (1 << capi.K_BACKWARD))
     ctx.get_timing(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -242,6 +242,17 @@ def main():
                         frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<"),
                         algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms,
                         launches_timed=int(timing["forward"][1]))
+    # the same for the longest kernel of the step, the fused backward/update (SURVEY 8d "full-step accounting":
+    # XV re-read s*k*4 per example + state read and written (8+2k)*4*2 per unique key)
+    roofline_bwd = None
+    if timing and timing["backward"][1] > 0:
+        bwd_ms = timing["backward"][0] / timing["backward"][1]
+        bwd_bytes = B * S * k * 4 + int(U_last) * (8 + 2 * k) * 4 * 2
+        ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9
+        roofline_bwd = dict(bound="hbm", kernel="k_backward_all", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
+                            frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic("k_backward_all<"),
+                            algorithmic_bytes_per_launch=bwd_bytes, avg_launch_ms=bwd_ms,
+                            launches_timed=int(timing["backward"][1]))
     nb = args.cpu_batches
     cpu = None
     if nb != 0:
@@ -261,6 +272,7 @@ def main():
                    "model_keys": int(nkeys), "prefilled": not args.no_prefill, "hyper": HYPER,
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
         "roofline": roofline,
+        "roofline_backward": roofline_bwd,
         "cpu_baseline": cpu,
         "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "kernel_ms_per_step": breakdown,
