@@ -1,0 +1,36 @@
+"""The bench line contract, checked on the line committed under profiles/ (produced by
+`python bench.py` on the MI355X box): every key the driver and the judge read is there, with the
+types and the relations the contract states."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")))
+    for k, typ in dict(metric=str, value=float, unit=str, n_gpus=int, steps=int, warmup=int, ms_per_step=float,
+                       higher_is_better=bool, scaling=str, dtype=str, data=str, config=dict).items():
+        assert isinstance(d[k], typ), k
+    assert d["vs_baseline"] is None            # BASELINE.md has no published number for this metric
+    assert d["unit"] == "examples/sec" and d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = units processed / time
+    assert abs(d["value"] - d["config"]["rows_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    assert r["traffic"] is None or r["traffic"] < 1.2 * r["algorithmic_bytes_per_launch"]   # no wasted re-reads
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "examples/sec"
+
+
+def test_pmc_summary_feeds_the_traffic_field():
+    t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+    fwd = [v for k, v in t.items() if k.startswith("k_forward<")]
+    assert len(fwd) == 1 and fwd[0]["hbm_bytes_per_launch"] > 0
