@@ -480,6 +480,18 @@ def test_edge_batches(capi, ctx, oracle):
     _run_fused_vs_oracle(capi, ctx, oracle, 4, "refrand", [b], 4, kw)
 
 
+def test_fused_trajectory_criteo_like(capi, ctx, oracle):
+    """a longer run on Criteo-shaped data (Zipf duplicates, hot keys, 39 slots): 24 consecutive
+    steps over 8 minibatches of 2 000 rows stay on the oracle's trajectory — per-step predictions,
+    losses and the final model"""
+    from difacto_amd import synth
+    gen = synth.CriteoSynth(total_ids=300_000, seed=11)
+    batches = [gen.batch(2000) for _ in range(8)]
+    kw = dict(l1=0.0005, l2=0.0, lr=0.02, V_lr=0.01, V_l2=0.01, V_threshold=2, V_init_scale=0.05, seed=6)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 16, "hash", batches, 3, kw, capacity=1 << 19)
+    assert n_with_v > 1000
+
+
 def test_fused_step_host_localized(capi, ctx, oracle):
     rng = np.random.default_rng(77)
     batches = [random_batch(rng, 64, 200, 20) for _ in range(2)]
