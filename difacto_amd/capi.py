@@ -26,7 +26,7 @@ SYMBOLS = [
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
-    "dfh_shard_push_grad_multi", "dfh_shard_release",
+    "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
 ]
 K_COUNT = 7
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
@@ -148,6 +148,9 @@ def lib():
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
     L.dfh_kernel_name.restype = C.c_char_p
     L.dfh_kernel_name.argtypes = [i32]
+    L.dfh_ctx_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.dfh_table_set_has_aux.argtypes = [vp, i32]
+    L.dfh_table_has_aux.argtypes = [vp]
     _lib = L
     return L
 
@@ -199,6 +202,10 @@ class Context:
         """prepare later batches (copy, localize, lookup) on `on` preparation streams (True = 1)
         while an earlier batch trains on the main stream"""
         _ck(lib().dfh_ctx_set_pipeline(self.h, int(on)))
+
+    def set_option(self, name, value):
+        """validated launch tuning: fwd_depth, fwd_blocks, bwd_small_blocks, prep_priority"""
+        _ck(lib().dfh_ctx_set_option(self.h, name.encode(), int(value)))
 
     def set_timing(self, on=True):
         _ck(lib().dfh_ctx_set_timing(self.h, 1 if on else 0))
@@ -342,6 +349,14 @@ class Table:
         n, aux = C.c_uint64(0), C.c_int(0)
         _ck(lib().dfh_table_load(self.h, str(path).encode(), key_lo, key_hi, C.byref(aux), C.byref(n)))
         return n.value, bool(aux.value)
+
+    @property
+    def has_aux(self):
+        """SGDUpdater::has_aux_: False after loading a model saved without optimiser state"""
+        return bool(lib().dfh_table_has_aux(self.h))
+
+    def set_has_aux(self, on):
+        _ck(lib().dfh_table_set_has_aux(self.h, 1 if on else 0))
 
     def warm_start(self, d_keys, n, w0=0.01, cnt0=100.0):
         _ck(lib().dfh_table_warm_start(self.h, _dp(d_keys), n, w0, cnt0))

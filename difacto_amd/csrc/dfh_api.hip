@@ -33,6 +33,11 @@ struct dfh_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int num_cu = 256;
+  // launch tuning (dfh_ctx_set_option); the defaults are the measured optima for C3 on MI355X
+  int fwd_depth = 5;           // independent V-row loads a forward lane issues before consuming any
+  int fwd_blocks = 0;          // cap on the forward grid (0: one wave per example)
+  int bwd_small_blocks = 2048; // cap on the short-segment blocks of the backward/update launch
+  int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
   struct Span { int id; hipEvent_t a, b; };
@@ -78,6 +83,7 @@ struct dfh_table {
   TableView v{};
   uint64_t hslots = 0;
   uint64_t bytes = 0;
+  bool has_aux = true;  // SGDUpdater::has_aux_ (sgd_updater.h:80): false after loading a model saved without optimiser state
   // REFRAND scratch (need/rank/urow per pushed key) for the literal + shard calls
   uint32_t* d_need = nullptr;
   uint32_t* d_rank = nullptr;
@@ -247,10 +253,6 @@ int check_table_err(dfh_table* t) {
     set_error("model table is full (capacity_rows exceeded)");
     return DFH_ERR_CAPACITY;
   }
-  if (e & 2u) {
-    set_error("duplicate key inside one push/pull");
-    return DFH_ERR_ARG;
-  }
   if (e & 4u) {
     set_error("gradient carries V for a key whose V is not allocated (reference CHECK(e.V != nullptr))");
     return DFH_ERR_ARG;
@@ -292,6 +294,14 @@ inline int lanes_for(int kp) {
   int L = 1;
   while (L < nvec) L <<= 1;
   return L;
+}
+
+// SGDUpdater::Update(kGradient) starts with CHECK(has_aux_) << "no aux data" (sgd_updater.cc:75)
+int require_aux(const dfh_table* t, const char* who) {
+  if (t->has_aux) return DFH_OK;
+  set_error(std::string(who) + ": no aux data — the model was loaded without optimiser state (reference CHECK(has_aux_), "
+                               "sgd_updater.cc:75)");
+  return DFH_ERR_STATE;
 }
 
 RowSrc table_src(const dfh_table* t, const uint32_t* urow) {
@@ -347,7 +357,8 @@ int ensure_xv(dfh_batch* b, int kp) {
   size_t need = b->max_rows * (size_t)std::max(kp, 4);
   if (need <= b->xv_floats) return DFH_OK;
   if (b->d_xv) {
-    DFH_HIP(hipStreamSynchronize(b->ctx->stream));
+    int rc = sync_all(b->ctx);
+    if (rc) return rc;
     DFH_HIP(hipFree(b->d_xv));
   }
   DFH_HIP(hipMalloc(&b->d_xv, need * sizeof(float)));
@@ -380,9 +391,8 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_
   // bound by the latency of its dependent gathers, not by launch size
   int grid = (int)std::max<size_t>(1, std::min<size_t>((b->nrows + 3) / 4, PROG_SLOTS));
   hipStream_t s = b->ctx->stream;
-  static const int fwd_depth = getenv("DFH_FWD_DEPTH") ? atoi(getenv("DFH_FWD_DEPTH")) : 5;
-  static const int fwd_blocks = getenv("DFH_FWD_BLOCKS") ? atoi(getenv("DFH_FWD_BLOCKS")) : 0;
-  if (fwd_blocks > 0) grid = std::min(grid, fwd_blocks);
+  const int fwd_depth = b->ctx->fwd_depth;
+  if (b->ctx->fwd_blocks > 0) grid = std::min(grid, b->ctx->fwd_blocks);
   // timing: the dispatch itself carries the two events (hipExtLaunchKernelGGL), so the span is the
   // kernel's own begin/end as the command processor stamps them — what a profiler reports — and no
   // marker packet drains the stream around it
@@ -441,12 +451,9 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   constexpr size_t NWB = BWD_THREADS / 64;
   const size_t nb_hot = std::max<size_t>(1, std::min<size_t>(b->nnz / (BWD_MID + 1) + 1, 256));
   const size_t nb_mid = std::max<size_t>(1, std::min<size_t>((b->nnz / (BWD_SMALL + 1)) / NWB + 1, 512));
-  static const size_t small_cap = getenv("DFH_BWD_SMALL_BLOCKS") ? (size_t)atoi(getenv("DFH_BWD_SMALL_BLOCKS")) : 2048;
+  const size_t small_cap = (size_t)c->bwd_small_blocks;
   const size_t keys_per_block = NWB * (64 / L);
   const size_t nb_small = std::max<size_t>(1, std::min<size_t>((b->nnz + keys_per_block - 1) / keys_per_block, small_cap));
-  // debugging aid: DFH_BWD_ROLES=<bitmask> runs only some roles (1 hot, 2 mid, 4 small); results are then wrong
-  static const uint32_t role_mask = getenv("DFH_BWD_ROLES") ? (uint32_t)atoi(getenv("DFH_BWD_ROLES")) : 7u;
-  static const uint32_t dbg_small = getenv("DFH_BWD_DBG") ? (uint32_t)atoi(getenv("DFH_BWD_DBG")) : 0u;
   hipEvent_t ea = nullptr, eb = nullptr;  // timing rides on the dispatch, like the forward's
   if ((c->timing >> DFH_K_BACKWARD) & 1u) {
     ea = TimeScope::get(c);
@@ -456,14 +463,14 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   const uint32_t nh = (uint32_t)nb_hot, nm = (uint32_t)nb_mid;
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
-    const bool lean = FUSED && src.urow && !(dbg_small & 4u);
+    const bool lean = FUSED && src.urow;
 #define DFH_BWD(LEAN, EXACT)                                                                                          \
   if (ea && eb)                                                                                                       \
     hipExtLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, ea, eb, 0, bv, src, tv, grads, \
-                          gstride, k, kp, need, nh, nm, role_mask, dbg_small);                                        \
+                          gstride, k, kp, need, nh, nm);                                                              \
   else                                                                                                                \
     hipLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, \
-                       need, nh, nm, role_mask, dbg_small)
+                       need, nh, nm)
     if (lean && kp == 4 * LL) {
       DFH_BWD(FUSED, true);
     } else if (lean) {
@@ -571,8 +578,7 @@ int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
     // (measured: highest 72.9, normal 72.7, lowest 75.8 M examples/sec)
     int lo = 0, hi = 0;
     DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* pr = getenv("DFH_PREP_PRIORITY");
-    int prio = pr ? atoi(pr) : lo;
+    const int prio = c->prep_priority < 0 ? lo : (c->prep_priority > 0 ? hi : 0);
     hipStream_t p = nullptr;
     DFH_HIP(hipStreamCreateWithPriority(&p, hipStreamNonBlocking, prio));
     c->preps.push_back(p);
@@ -580,6 +586,28 @@ int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
   c->nprep = (unsigned)enable;
   c->next_prep = 0;
   c->pipeline = enable != 0;
+  return DFH_OK;
+}
+int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
+  DFH_ARG(c && name, "dfh_ctx_set_option: NULL argument");
+  const std::string n(name);
+  if (n == "fwd_depth") {
+    DFH_ARG(value == 4 || value == 5 || value == 8 || value == 10, "fwd_depth must be 4, 5, 8 or 10");
+    c->fwd_depth = value;
+  } else if (n == "fwd_blocks") {
+    DFH_ARG(value >= 0 && value <= PROG_SLOTS, "fwd_blocks must be in [0, 16384] (0: one wave per example)");
+    c->fwd_blocks = value;
+  } else if (n == "bwd_small_blocks") {
+    DFH_ARG(value >= 1 && value <= 65536, "bwd_small_blocks must be in [1, 65536]");
+    c->bwd_small_blocks = value;
+  } else if (n == "prep_priority") {
+    DFH_ARG(value >= -1 && value <= 1, "prep_priority must be -1 (lowest), 0 (default) or 1 (highest)");
+    DFH_ARG(c->preps.empty(), "prep_priority must be set before dfh_ctx_set_pipeline creates the streams");
+    c->prep_priority = value;
+  } else {
+    set_error("dfh_ctx_set_option: unknown option " + n);
+    return DFH_ERR_ARG;
+  }
   return DFH_OK;
 }
 void* dfh_ctx_stream(dfh_ctx* c) { return c ? c->stream : nullptr; }
@@ -704,7 +732,7 @@ int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_r
 int dfh_table_destroy(dfh_table* t) {
   if (!t) return DFH_OK;
   hipSetDevice(t->ctx->device);
-  hipStreamSynchronize(t->ctx->stream);
+  sync_all(t->ctx);  // preparation streams may still probe the table
   hipFree(t->v.ht);
   hipFree(t->v.hdr);
   hipFree(t->v.va);
@@ -721,6 +749,10 @@ int dfh_table_destroy(dfh_table* t) {
 int dfh_table_size(dfh_table* t, uint64_t* nkeys) {
   DFH_ARG(t && nkeys, "NULL argument");
   uint32_t n = 0;
+  {
+    int rc = sync_all(t->ctx);  // a preparation-stream lookup may still be inserting keys
+    if (rc) return rc;
+  }
   DFH_HIP(hipMemcpyAsync(&n, t->v.nrows, sizeof(n), hipMemcpyDeviceToHost, t->ctx->stream));
   DFH_HIP(hipStreamSynchronize(t->ctx->stream));
   *nkeys = std::min<uint64_t>(n, t->v.capacity);
@@ -733,6 +765,13 @@ int dfh_table_param(dfh_table* t, dfh_updater_param* out) {
   return DFH_OK;
 }
 uint64_t dfh_table_bytes(dfh_table* t) { return t ? t->bytes : 0; }
+
+int dfh_table_set_has_aux(dfh_table* t, int has_aux) {
+  DFH_ARG(t, "NULL table");
+  t->has_aux = has_aux != 0;
+  return DFH_OK;
+}
+int dfh_table_has_aux(dfh_table* t) { return (t && t->has_aux) ? 1 : 0; }
 
 int dfh_table_warm_start(dfh_table* t, const uint64_t* d_keys, size_t n, float w0, float cnt0) {
   DFH_ARG(t && (n == 0 || d_keys), "dfh_table_warm_start: NULL argument");
@@ -772,6 +811,7 @@ int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const f
 
 int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_grads) {
   DFH_ARG(t && (n == 0 || (d_keys && d_grads)), "dfh_shard_push_grad: NULL argument");
+  if (int rca = require_aux(t, "dfh_shard_push_grad")) return rca;
   if (n == 0) return DFH_OK;
   bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && t->v.k > 0;
   if (refrand) {
@@ -831,6 +871,7 @@ int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const u
 
 int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_grads) {
   DFH_ARG(t && (n == 0 || (d_rowid && d_keys && d_grads)), "dfh_shard_push_grad_resolved: NULL argument");
+  if (int rca = require_aux(t, "dfh_shard_push_grad_resolved")) return rca;
   if (!(t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0)) {
     set_error("resolved store calls need V_init = hash (order independent)");
     return DFH_ERR_STATE;
@@ -904,6 +945,7 @@ int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint
 int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
                               int mask_slot, const float* d_grads) {
   DFH_ARG(t, "NULL table");
+  if (int rca = require_aux(t, "dfh_shard_push_grad_multi")) return rca;
   if (!hash_init_only(t)) {
     set_error("multi-source store calls need V_init = hash (order independent)");
     return DFH_ERR_STATE;
@@ -943,13 +985,30 @@ int dfh_table_check(dfh_table* t) {
 }
 
 // ---- literal Store API (host pointers)
+namespace {
+// the literal calls hand every key to its own lane: a key listed twice would be updated by two
+// lanes at once (the reference applies them one after the other; the Localizer never produces them)
+int check_keys(const uint64_t* keys, size_t n) {
+  bool ascending = true;
+  for (size_t i = 0; i < n; ++i) {
+    DFH_ARG(keys[i] != kEmptyKey, "key ~0 is reserved");
+    if (i && keys[i] <= keys[i - 1]) ascending = false;
+  }
+  if (ascending) return DFH_OK;  // Localizer output: strictly ascending, hence unique
+  std::vector<uint64_t> tmp(keys, keys + n);
+  std::sort(tmp.begin(), tmp.end());
+  DFH_ARG(std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end(), "duplicate key inside one push/pull");
+  return DFH_OK;
+}
+}  // namespace
+
 int dfh_pull(dfh_table* t, const uint64_t* keys, size_t n, float* vals, size_t* nvals, int* lens, size_t* nlens) {
   DFH_ARG(t && nvals && nlens && (n == 0 || (keys && vals && lens)), "dfh_pull: NULL argument");
   const int k = t->v.k;
   *nvals = 0;
   *nlens = k == 0 ? 0 : n;  // sgd_updater.cc:40
   if (n == 0) return DFH_OK;
-  for (size_t i = 0; i < n; ++i) DFH_ARG(keys[i] != kEmptyKey, "key ~0 is reserved");
+  if (int rck = check_keys(keys, n)) return rck;
   dfh_ctx* c = t->ctx;
   DFH_HIP(hipSetDevice(c->device));
   const size_t stride = dfh_row_stride(k);
@@ -989,7 +1048,7 @@ int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const f
   dfh_ctx* c = t->ctx;
   DFH_HIP(hipSetDevice(c->device));
   const int k = t->v.k;
-  for (size_t i = 0; i < n; ++i) DFH_ARG(keys[i] != kEmptyKey, "key ~0 is reserved");
+  if (int rck = check_keys(keys, n)) return rck;
   if (val_type == DFH_FEA_COUNT) {
     DFH_ARG(nvals == n, "kFeaCount: CHECK_EQ(fea_ids.size(), values.size()) (sgd_updater.cc:63)");
     if (n == 0) return DFH_OK;
@@ -1005,6 +1064,7 @@ int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const f
     return check_table_err(t);
   }
   // kGradient (sgd_updater.cc:74-97)
+  if (int rca = require_aux(t, "dfh_push(kGradient)")) return rca;
   const bool w_only = nlens == 0;
   if (w_only) {
     DFH_ARG(nvals == n, "kGradient: CHECK_EQ(values.size(), size) (sgd_updater.cc:79)");
@@ -1227,6 +1287,7 @@ int dfh_table_load(dfh_table* t, const char* path, uint64_t key_lo, uint64_t key
   }
   if (rc == DFH_OK) rc = flush();
   if (n_loaded) *n_loaded = loaded;
+  if (rc == DFH_OK && !aux && loaded > 0) t->has_aux = false;  // entries now lack fea_cnt / FTRL / AdaGrad state
   return rc;
 }
 
@@ -1877,6 +1938,9 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   if (!b->localized) {
     set_error("dfh_sgd_step: batch is not localized (call dfh_localize first)");
     return DFH_ERR_STATE;
+  }
+  if (is_train) {
+    if (int rca = require_aux(t, "dfh_sgd_step(is_train)")) return rca;
   }
   dfh_ctx* c = t->ctx;
   hipStream_t s = c->stream;

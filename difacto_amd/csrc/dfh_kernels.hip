@@ -71,14 +71,17 @@ __device__ __forceinline__ float hash_init_value(uint64_t key, int j, unsigned s
   return (u - 0.5f) * scale;
 }
 
-// ---- key index: open addressing, linear probing.  Every launch that calls
-// this is handed UNIQUE keys, so two lanes never race on the same key; racing
-// on the same slot with different keys is resolved by the 64-bit CAS.
+// ---- key index: open addressing, linear probing.  Launches that probe the table may run
+// concurrently (preparation streams resolve the keys of later minibatches while the main stream
+// pulls, pushes or imports) and may carry the same new key, inside one launch (owner side of the
+// sharded store: several source ranks) or across launches.  The thread that wins a slot's 64-bit
+// CAS takes the next row and publishes its id with a device-scope atomic store; every other
+// carrier of the key finds the key in the slot and waits for the id (the table is created with
+// all row words = ~0).  A row id is the whole message: rows are zero until an update writes them.
 __device__ __forceinline__ uint32_t find_or_insert(const TableView& t, uint64_t key) {
   uint64_t h = splitmix64(key) & t.hmask;
   for (;;) {
     uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) return t.ht[h].row;
     if (k == kEmptyKey) {
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
                                          (unsigned long long)kEmptyKey, (unsigned long long)key);
@@ -86,15 +89,18 @@ __device__ __forceinline__ uint32_t find_or_insert(const TableView& t, uint64_t 
         uint32_t r = atomicAdd(t.nrows, 1u);
         if (r >= t.capacity) {
           atomicOr(t.err, 1u);
-          r = t.capacity - 1;  // keep memory safe; host reports DFH_ERR_CAPACITY
+          r = t.capacity - 1;  // keep memory safe; the host reports DFH_ERR_CAPACITY
         }
-        t.ht[h].row = r;
+        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return r;
       }
-      if (old == key) {  // duplicate key inside one launch: contract violation
-        atomicOr(t.err, 2u);
-        return t.capacity - 1;
-      }
+      k = old;
+    }
+    if (k == key) {
+      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r != kNoRow) return r;
+      __builtin_amdgcn_s_sleep(1);
+      continue;  // the winner of this slot is between its CAS and its store
     }
     h = (h + 1) & t.hmask;
   }
@@ -133,17 +139,21 @@ __device__ __forceinline__ float ftrl_update_w(float gw, float w, float& sqrt_g,
   return (z > 0 ? z - l1 : z + l1) / eta; // :119
 }
 
-// SGDUpdater::UpdateV — AdaGrad, one coordinate, src/sgd/sgd_updater.cc:129-138.
-// The square root and the reciprocal use the hardware approximations (<= 1 ulp each) instead
-// of the IEEE-rounded sequences: the update is 4*V_dim of these per key and the kernel is
-// issue-bound; the step differs from the reference's by ~1e-7 relative (inside the rtol 1e-5
-// band; the FTRL update of w, whose |z| <= l1 test is threshold-sensitive, stays exact).
+// SGDUpdater::UpdateV — AdaGrad, one coordinate, src/sgd/sgd_updater.cc:129-138, operation for
+// operation (IEEE-rounded square root and division, no contraction): given the same gradient the
+// new V and accumulator are the reference's, bit for bit.  -DDFH_FAST_ADAGRAD swaps in the hardware
+// v_sqrt_f32 / v_rcp_f32 approximations (1 ulp each) for A/B timing of the update kernel only.
 __device__ __forceinline__ void adagrad_update_v(float gv, float& v, float& acc, const dfh_updater_param& P) {
   float g = gv + P.V_l2 * v;           // :132
   float cg = acc;                      // :133
-  float ncg = __builtin_amdgcn_sqrtf(cg * cg + g * g);  // :134
+#ifdef DFH_FAST_ADAGRAD
+  float ncg = __builtin_amdgcn_sqrtf(cg * cg + g * g);
+  float eta = P.V_lr * __builtin_amdgcn_rcpf(ncg + P.V_lr_beta);
+#else
+  float ncg = sqrtf(cg * cg + g * g);  // :134
+  float eta = P.V_lr / (ncg + P.V_lr_beta);  // :135
+#endif
   acc = ncg;
-  float eta = P.V_lr * __builtin_amdgcn_rcpf(ncg + P.V_lr_beta);  // :135
   v -= eta * g;                        // :136
 }
 
@@ -693,7 +703,7 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
 template <int L, bool FUSED>
 __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                            size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
-                                           uint32_t nwaves, uint32_t dbg, double& pen_acc) {
+                                           uint32_t nwaves, double& pen_acc) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
@@ -711,7 +721,7 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
       const uint32_t end = mine ? end_all : beg;
       KeySums s;
       s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (uint32_t j0 = beg; j0 < ((dbg & 2u) ? beg : end); j0 += BWD_SMALL_DEPTH) {
+      for (uint32_t j0 = beg; j0 < end; j0 += BWD_SMALL_DEPTH) {
         float4 a[BWD_SMALL_DEPTH];
         float xs[BWD_SMALL_DEPTH], ps[BWD_SMALL_DEPTH];
 #pragma unroll
@@ -732,11 +742,7 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
           s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
         }
       }
-      if (dbg & 1u) {
-        pen_acc += s.gv.x + s.gw + kr.v.x + kr.acc.y + kr.z;
-      } else if (mine) {
-        finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
-      }
+      if (mine) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
     }
   }
 }
@@ -868,16 +874,15 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
 template <int L, bool FUSED, bool LEAN, bool EXACT>
 __global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
                                                                 size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
-                                                                uint32_t nb_hot, uint32_t nb_mid, uint32_t role_mask, uint32_t dbg) {
+                                                                uint32_t nb_hot, uint32_t nb_mid) {
   constexpr int NW = BWD_THREADS / 64;
   double pen_acc = 0.0;
   if (blockIdx.x < nb_hot) {
-    if (role_mask & 1u) hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, blockIdx.x, nb_hot, pen_acc);
+    hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, blockIdx.x, nb_hot, pen_acc);
   } else if (blockIdx.x < nb_hot + nb_mid) {
-    if (role_mask & 2u)
-      mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (blockIdx.x - nb_hot) * NW + (threadIdx.x >> 6),
-                             nb_mid * NW, pen_acc);
-  } else if (role_mask & 4u) {
+    mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (blockIdx.x - nb_hot) * NW + (threadIdx.x >> 6),
+                           nb_mid * NW, pen_acc);
+  } else {
     const uint32_t nb_big = nb_hot + nb_mid;
     const uint32_t wave = (blockIdx.x - nb_big) * NW + (threadIdx.x >> 6);
     const uint32_t nwaves = (gridDim.x - nb_big) * NW;
@@ -888,7 +893,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, Ro
       sa.prog = b.prog; sa.k = k; sa.kp = kp; sa.p = t.p;
       small_role_lean<L, EXACT>(sa, wave, nwaves, pen_acc);
     } else {
-      small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, dbg, pen_acc);
+      small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, pen_acc);
     }
   }
   if (FUSED) flush_penalty(b, pen_acc);
@@ -1021,38 +1026,9 @@ __global__ void __launch_bounds__(256) k_push_grad(TableView t, const uint64_t* 
 // allowed), then Pull is one gather over all of them and the two Push kinds run
 // per source rank on known rows (no probing, sequential in source order).
 // ---------------------------------------------------------------------------
-// like find_or_insert, but several threads of the launch may carry the same key:
-// the thread that wins the slot publishes the row id, the others wait for it
-__device__ __forceinline__ uint32_t find_or_insert_shared(const TableView& t, uint64_t key) {
-  uint64_t h = splitmix64(key) & t.hmask;
-  for (;;) {
-    uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == kEmptyKey) {
-      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
-                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
-      if (old == kEmptyKey) {
-        uint32_t r = atomicAdd(t.nrows, 1u);
-        if (r >= t.capacity) {
-          atomicOr(t.err, 1u);
-          r = t.capacity - 1;
-        }
-        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the id is the whole message
-        return r;
-      }
-      k = old;
-    }
-    if (k == key) {
-      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (r != 0xFFFFFFFFu) return r;
-      continue;  // the winner of this slot is between its CAS and its store
-    }
-    h = (h + 1) & t.hmask;
-  }
-}
-
 __global__ void k_resolve(TableView t, const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ rowid) {
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
-    rowid[u] = find_or_insert_shared(t, keys[u]);
+    rowid[u] = find_or_insert(t, keys[u]);
 }
 
 // Pull on resolved rows: L lanes per key copy [w, has_V, 0, 0 | V] (float4 per lane)
@@ -1161,7 +1137,7 @@ __device__ __forceinline__ uint32_t seg_find(const uint64_t* __restrict__ keys, 
 __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, SegOff g, uint32_t* __restrict__ rowid) {
   const uint32_t n = g.off[g.nsrc];
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const uint32_t r = find_or_insert_shared(t, keys[e]);
+    const uint32_t r = find_or_insert(t, keys[e]);
     rowid[e] = r;
     atomicOr(&t.hdr[r].pad[g.slot], 1u << seg_source(g, e));
   }

@@ -67,23 +67,39 @@ class DeviceSGDUpdater : public Updater {
     CHECK_EQ(k, param_.V_dim) << "model V_dim differs from the configured one";
     if (has_aux) *has_aux = aux != 0;
     const size_t kk = static_cast<size_t>(std::max(k, 1));
-    std::vector<uint64_t> keys(n);
-    std::vector<float> scal(n * 4, 0.f), V(n * 2 * kk, 0.f);
-    std::vector<int> hasv(n);
+    // entries are imported in chunks: the header's n only bounds the loop, it never sizes a buffer
+    // (a corrupt count ends in a failed read, not in an allocation)
+    const size_t chunk = 1 << 20;
+    std::vector<uint64_t> keys;
+    std::vector<float> scal, V, row(2 * kk);
+    std::vector<int> hasv;
+    auto flush = [&]() {
+      if (keys.empty()) return;
+      DFH_CALL(dfh_table_import(table_, keys.size(), keys.data(), scal.data(), hasv.data(), V.data()));
+      keys.clear(); scal.clear(); V.clear(); hasv.clear();
+    };
     for (uint64_t i = 0; i < n; ++i) {
+      uint64_t key;
       float w, cnt = 0, sg = 0, z = 0;
       int32_t hv;
-      CHECK(fi->ReadPOD(&keys[i]) && fi->ReadPOD(&w));
-      if (aux) CHECK(fi->ReadPOD(&cnt) && fi->ReadPOD(&sg) && fi->ReadPOD(&z));
-      CHECK(fi->ReadPOD(&hv));
-      scal[i * 4 + 0] = cnt; scal[i * 4 + 1] = w; scal[i * 4 + 2] = sg; scal[i * 4 + 3] = z;
-      hasv[i] = hv;
+      CHECK(fi->ReadPOD(&key) && fi->ReadPOD(&w)) << "truncated model file (entry " << i << " of " << n << ")";
+      if (aux) CHECK(fi->ReadPOD(&cnt) && fi->ReadPOD(&sg) && fi->ReadPOD(&z)) << "truncated model file";
+      CHECK(fi->ReadPOD(&hv)) << "truncated model file";
+      std::fill(row.begin(), row.end(), 0.f);
       if (hv && k > 0) {
-        CHECK_EQ(fi->Read(&V[i * 2 * k], sizeof(float) * k), sizeof(float) * k);
-        if (aux) CHECK_EQ(fi->Read(&V[i * 2 * k + k], sizeof(float) * k), sizeof(float) * k);
+        CHECK_EQ(fi->Read(row.data(), sizeof(float) * k), sizeof(float) * k) << "truncated model file";
+        if (aux) CHECK_EQ(fi->Read(row.data() + k, sizeof(float) * k), sizeof(float) * k) << "truncated model file";
       }
+      keys.push_back(key);
+      scal.push_back(cnt); scal.push_back(w); scal.push_back(sg); scal.push_back(z);
+      hasv.push_back(hv);
+      V.insert(V.end(), row.begin(), row.begin() + 2 * kk);
+      if (keys.size() == chunk) flush();
     }
-    DFH_CALL(dfh_table_import(table_, n, keys.data(), scal.data(), hasv.data(), V.data()));
+    flush();
+    // SGDUpdater::has_aux_ (sgd_updater.h:80): without optimiser state the table refuses gradient
+    // pushes and training steps, as the reference's CHECK(has_aux_) does (sgd_updater.cc:75)
+    if (!aux && n > 0) DFH_CALL(dfh_table_set_has_aux(table_, 0));
   }
 
   void Save(bool save_aux, dmlc::Stream* fo) const override {

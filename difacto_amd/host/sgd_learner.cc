@@ -143,7 +143,8 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   // prepare batch t+1 (H2D copy, Localizer, key lookup) while batch t trains
   auto prepare = [&](int slot) {
     const auto& blk = reader.Value();
-    // a growing batch would need a new buffer while the other slot may be in flight: drain first
+    // a growing batch needs new buffers while the other slot may be in flight: drain first (the
+    // main loop has already trained the pending batch)
     if (!batch_[0] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
       DFH_CALL(dfh_ctx_sync(ctx));
       sgd::Progress keep;
@@ -161,14 +162,23 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
     DFH_CALL(dfh_batch_lookup(table, b));
   };
+  auto needs_growth = [&](const dmlc::RowBlock<feaid_t>& blk) {
+    return !batch_[0] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
+  };
   bool have = reader.Next();
   int i = 0;
   if (have) prepare(0);
   while (have) {
     const int cur = i & 1;
     const bool have_next = reader.Next();
+    bool stepped = false;
+    if (have_next && needs_growth(reader.Value())) {
+      // growing re-creates BOTH batch objects: the prepared, not yet trained batch goes first
+      DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+      stepped = true;
+    }
     if (have_next) prepare(cur ^ 1);
-    DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+    if (!stepped) DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
     have = have_next;
     ++i;
   }

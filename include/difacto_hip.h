@@ -81,6 +81,13 @@ int dfh_ctx_device(dfh_ctx* ctx);
  * (src/sgd/sgd_learner.cc:196-224).  Ordering per batch object is kept with
  * events inside the library; use two dfh_batch objects alternately. */
 int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
+/* launch tuning, validated (unknown names / out-of-range values: DFH_ERR_ARG):
+ *   "fwd_depth"         4 | 5 | 8 | 10  independent V-row loads per forward lane (default 5)
+ *   "fwd_blocks"        0 .. 16384      cap on the forward grid, 0 = one wave per example (default)
+ *   "bwd_small_blocks"  1 .. 65536      cap on the short-segment blocks of the backward launch (default 2048)
+ *   "prep_priority"     -1 | 0 | 1      stream priority of the preparation streams: lowest (default),
+ *                                       normal, highest; before dfh_ctx_set_pipeline creates them */
+int dfh_ctx_set_option(dfh_ctx* ctx, const char* name, int value);
 
 /* optional per-kernel timing with HIP events recorded on the context's stream
  * (what bench.py's roofline block reads); ids index total_ms[]/calls[] */
@@ -112,6 +119,12 @@ int dfh_table_destroy(dfh_table* t);
 int dfh_table_size(dfh_table* t, uint64_t* nkeys); /* synchronises */
 int dfh_table_param(dfh_table* t, dfh_updater_param* out);
 uint64_t dfh_table_bytes(dfh_table* t);
+/* SGDUpdater::has_aux_ (src/sgd/sgd_updater.h:80): cleared by dfh_table_load of a file saved
+ * without optimiser state (or by a host that parsed such a file itself); while cleared, every
+ * gradient push and training step fails with DFH_ERR_STATE — the reference's
+ * CHECK(has_aux_) << "no aux data" (src/sgd/sgd_updater.cc:75) */
+int dfh_table_set_has_aux(dfh_table* t, int has_aux);
+int dfh_table_has_aux(dfh_table* t);
 
 /* Store::Pull(fea_ids, kWeight, vals, lens) -> SGDUpdater::Get
  * (include/difacto/store.h:69-73, src/store/store_local.h:36-44, src/sgd/sgd_updater.cc:32-56).
@@ -121,7 +134,7 @@ int dfh_pull(dfh_table* t, const uint64_t* keys, size_t n, float* vals, size_t* 
 
 /* Store::Push(fea_ids, kFeaCount|kGradient, vals, lens) -> SGDUpdater::Update
  * (include/difacto/store.h:53-57, src/store/store_local.h:24-34, src/sgd/sgd_updater.cc:58-148):
- * FTRL on w, AdaGrad on V, lazy InitV.  Host pointers.  Keys must be unique. */
+ * FTRL on w, AdaGrad on V, lazy InitV.  Host pointers.  Keys must be unique (checked: DFH_ERR_ARG). */
 int dfh_push(dfh_table* t, const uint64_t* keys, size_t n, int val_type, const float* vals, size_t nvals,
              const int* lens, size_t nlens);
 
@@ -272,8 +285,8 @@ int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint
 int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
                               int mask_slot, const float* d_grads);
 int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_slot);
-/* fetch and report the table's sticky device-side error word (capacity, duplicate key,
- * gradient with V for a row without V); synchronises */
+/* fetch and report the table's sticky device-side error word (capacity exceeded, gradient
+ * with V for a row without V); synchronises */
 int dfh_table_check(dfh_table* t);
 
 /* raw device memory for hosts without a HIP runtime of their own */
