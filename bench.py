@@ -3,14 +3,21 @@
 
   python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torchrun)
 
-A "step" is one pass of the hot path over one Criteo-shaped synthetic minibatch
-(B rows x 39 slots, ids over 33 M features, V_dim=64, binary values) whose raw
-CSR (u64 feature ids) is already resident in HBM:
-    device Localizer::Compact -> Pull (table gather) -> FMLoss::Predict ->
-    Evaluate -> FMLoss::CalcGrad (segmented sum) -> Push -> FTRL/AdaGrad in place.
+A "step" is one pass of the hot path over one synthetic minibatch whose raw CSR (u64 feature ids)
+is already resident in HBM:
+    device Localizer::Compact -> Pull (table gather) -> FMLoss::Predict -> Evaluate ->
+    FMLoss::CalcGrad (segmented sum) -> Push -> FTRL/AdaGrad in place.
+The default workload is BASELINE.json's C3 (Criteo-shaped: B rows x 39 slots, 33 M ids, V_dim 64,
+binary values).  --preset selects the other single-GPU lines of SURVEY.md 8(d):
+    c3-refdefaults   C3 with the reference's default hyper-parameters (l1 = 1, V_threshold = 10)
+    c5-slice         one GPU's share of C5: V_dim 128, l1 = 1, as many ids as fit the HBM (~2e8)
+    c2               rcv1-shaped: 100 rows x ~75 real-valued features over 47 236 ids, V_dim 8
+The timed region of K steps (sync + barrier on both sides) is repeated until at least --min-time
+seconds have been measured; the line reports the MEDIAN repetition and the spread.
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -23,16 +30,32 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+# steady-state worst-case traffic: every touched key carries V
+HYPER = dict(l1=0.0, l2=0.0, V_l2=0.01, lr=0.01, lr_beta=1.0, V_lr=0.01, V_lr_beta=1.0, V_init_scale=0.01,
+             V_threshold=0, seed=0)
+PRESETS = {
+    "c3": dict(),
+    # src/sgd/sgd_param.h:95-105
+    "c3-refdefaults": dict(hyper=dict(l1=1.0, V_threshold=10)),
+    "c5-slice": dict(vdim=128, ids=200_000_000, hyper=dict(l1=1.0)),
+    "c2": dict(vdim=8, rows=100, ids=47_236, hyper=dict(l1=1.0, lr=0.1)),
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=10000, help="minibatch rows per GPU per step (criteo_sgd.conf:10)")
-    ap.add_argument("--ids", type=int, default=33_000_000, help="feature id space")
-    ap.add_argument("--vdim", type=int, default=64)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="c3")
+    ap.add_argument("--rows", type=int, default=None, help="minibatch rows per GPU per step (criteo_sgd.conf:10: 10000)")
+    ap.add_argument("--ids", type=int, default=None, help="feature id space (33 M)")
+    ap.add_argument("--vdim", type=int, default=None)
+    ap.add_argument("--l1", type=float, default=None)
+    ap.add_argument("--v-threshold", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic batches cycled through")
+    ap.add_argument("--min-time", type=float, default=0.5, help="repeat the K-step region until this many seconds are timed")
+    ap.add_argument("--max-reps", type=int, default=400)
     ap.add_argument("--no-prefill", action="store_true", help="start from an empty model instead of a warm one")
     ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
@@ -43,73 +66,139 @@ def parse_args():
     ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
     ap.add_argument("--uniform-ranges", action="store_true",
                     help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
-    ap.add_argument("--exchange", choices=["sync", "overlap"], default="overlap",
-                    help="N>1: two minibatches in flight with the exchange hidden behind compute (staleness 1, what the "
-                         "reference's batch tracker does, sgd_learner.cc:219-223), or one at a time (zero staleness)")
+    ap.add_argument("--exchange", choices=["sync", "overlap"], default="sync",
+                    help="N>1: one minibatch at a time (zero staleness, the headline), or two in flight with the exchange "
+                         "hidden behind compute (staleness 1, what the reference's batch tracker does, sgd_learner.cc:219-223)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
-    return ap.parse_args()
+    args = ap.parse_args()
+    pre = PRESETS[args.preset]
+    args.rows = args.rows if args.rows is not None else pre.get("rows", 10000)
+    args.ids = args.ids if args.ids is not None else pre.get("ids", 33_000_000)
+    args.vdim = args.vdim if args.vdim is not None else pre.get("vdim", 64)
+    hyper = dict(HYPER)
+    hyper.update(pre.get("hyper", {}))
+    if args.l1 is not None:
+        hyper["l1"] = args.l1
+    if args.v_threshold is not None:
+        hyper["V_threshold"] = args.v_threshold
+    args.hyper = hyper
+    return args
 
 
-TIMING_EVERY = int(os.environ.get("DFH_TIMING_EVERY", "4"))  # the forward kernel is timed on every n-th step of the timed region
-
-HYPER = dict(l1=0.0, l2=0.0, V_l2=0.01, lr=0.01, lr_beta=1.0, V_lr=0.01, V_lr_beta=1.0, V_init_scale=0.01,
-             V_threshold=0, seed=0)
+TIMING_EVERY = int(os.environ.get("DFH_TIMING_EVERY", "4"))  # forward/backward are timed on every n-th step of the timed region
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/r01_pmc_hbm_traffic.json,
-    collected with `rocprofv3 --pmc ... -- python bench.py` on the default workload), or None"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        d = json.load(open(path))
-        for name, v in d.items():
-            if name.startswith(kernel):
-                return v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+def pmc_traffic(kernel, preset):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this preset
+    (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/rNN_pmc_hbm_traffic[_<preset>].json, collected
+    with `rocprofv3 --pmc ... -- python bench.py`), or None"""
+    suffix = "" if preset == "c3" else "_" + preset.replace("-", "_")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic%s.json" % suffix)), reverse=True):
+        try:
+            d = json.load(open(path))
+            for name, v in d.items():
+                if name.startswith(kernel):
+                    return v["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError, AttributeError):
+            continue
     return None
 
 
-def cpu_baseline(batches, V_dim, nbatches):
-    """the reference CPU path (oracle/_ref: the reference's own Localizer/SGDUpdater/FMLoss
-    compiled here) or the C port, timed on this box's host cores over `nbatches` batches"""
+def host_info():
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(nproc=os.cpu_count(), cpu_model=model)
+
+
+def cpu_baseline(batches, V_dim, nbatches, hyper):
+    """the reference CPU path (oracle/_ref: the reference's own Localizer / SGDUpdater / FMLoss compiled
+    here) — or the C restatement when that build is absent — timed on this box's host cores.  The
+    sample is `nbatches` batches of the GPU run's own stream; a first, untimed pass over them fills
+    the model (every touched key gets its entry, state and V row, like the GPU's pre-filled table),
+    the timed pass is the second.  Two thread settings: as shipped (2 OpenMP threads in
+    the loss and the Localizer, single-threaded updater) and scaled to the host (min(nproc, 49))."""
     from oracle import bindings as ob
+    info = host_info()
     kind = "reference" if ob.have_ref() else "port"
-    t_total = 0.0
-    rows = 0
-    if kind == "reference":
-        R = ob.Ref()
-        st = R.store_create(V_dim=V_dim, **HYPER)
-        for b in batches[:nbatches]:
-            t0 = time.perf_counter()
-            loc = R.localize(b["offset"], b["index"], nthreads=2)
-            st.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
-            vals, lens = st.pull(loc["feaids"])
-            # GetPos (sgd_learner.cc:113-127), vectorised
-            ends = np.cumsum(lens)
-            w_pos = (ends - lens).astype(np.int32)
-            V_pos = np.where(lens > 1, w_pos + 1, -1).astype(np.int32)
-            pred, grad = R.fm_predict_calcgrad(V_dim, loc["offset"], loc["index"], None, b["label"], vals, w_pos, V_pos)
-            R.loss_evaluate(b["label"], pred)
-            st.push(loc["feaids"], ob.GRADIENT, grad, lens)
-            t_total += time.perf_counter() - t0
-            rows += len(b["label"])
-        cores = 2  # blk_nthreads_ = DEFAULT_NTHREADS (sgd_learner.h:90); the updater is single-threaded
-    else:
+    B = len(batches[0]["label"])
+    sample = ("second pass over %d batches x %d rows of the GPU run's synthetic stream (the first, untimed pass fills the "
+              "model); localize + count push + pull + predict + calcgrad + push, no file I/O" % (nbatches, B))
+    if kind == "port":
         O = ob.Oracle()
-        st = O.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **HYPER)
-        for b in batches[:nbatches]:
-            t0 = time.perf_counter()
-            loc = O.localize(b["offset"], b["index"])
-            st.sgd_step(loc["offset"], loc["index"], None, b["label"], loc["feaids"], feacnt=loc["feacnt"], is_train=True)
-            t_total += time.perf_counter() - t0
-            rows += len(b["label"])
-        cores = 1
-    return dict(value=rows / t_total, unit="examples/sec", cores=cores, kind=kind,
-                sample="%d batches x %d rows of the same synthetic stream, model starting empty, "
-                       "localize+pull+predict+calcgrad+push, no file I/O" % (nbatches, len(batches[0]["label"])))
+        st = O.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
+        t_total, rows = 0.0, 0
+        for timed in (False, True):
+            for b in batches[:nbatches]:
+                t0 = time.perf_counter()
+                loc = O.localize(b["offset"], b["index"])
+                st.sgd_step(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"], feacnt=loc["feacnt"], is_train=True)
+                if timed:
+                    t_total += time.perf_counter() - t0
+                    rows += B
+        return dict(value=rows / t_total, unit="examples/sec", cores=1, kind=kind, sample=sample, **info)
+    R = ob.Ref()
+    out = None
+    for label, nthreads in (("as_shipped", 2), ("scaled", max(2, min(info["nproc"] or 2, 49)))):
+        st = R.store_create(V_dim=V_dim, **hyper)
+        stage = dict(localize=0.0, push_count=0.0, pull=0.0, predict_calcgrad=0.0, evaluate=0.0, push_grad=0.0)
+        rows = 0
+        for timed in (False, True):
+            for b in batches[:nbatches]:
+                ts = [time.perf_counter()]
+                loc = R.localize(b["offset"], b["index"], nthreads=nthreads)
+                ts.append(time.perf_counter())
+                st.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
+                ts.append(time.perf_counter())
+                vals, lens = st.pull(loc["feaids"])
+                # GetPos (sgd_learner.cc:113-127), vectorised
+                ends = np.cumsum(lens)
+                w_pos = (ends - lens).astype(np.int32)
+                V_pos = np.where(lens > 1, w_pos + 1, -1).astype(np.int32)
+                ts.append(time.perf_counter())
+                pred, grad = R.fm_predict_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, w_pos,
+                                                   V_pos, nthreads=nthreads)
+                ts.append(time.perf_counter())
+                R.loss_evaluate(b["label"], pred)
+                ts.append(time.perf_counter())
+                st.push(loc["feaids"], ob.GRADIENT, grad, lens)
+                ts.append(time.perf_counter())
+                if timed:
+                    for name, a, c in zip(stage, ts[:-1], ts[1:]):
+                        stage[name] += c - a
+                    rows += B
+        total = sum(stage.values())
+        res = dict(value=rows / total, threads=nthreads, stage_ms_per_batch={n: round(v / nbatches * 1e3, 3) for n, v in stage.items()})
+        if out is None:
+            # blk_nthreads_ = DEFAULT_NTHREADS = 2 (sgd_learner.h:90); the updater is single-threaded
+            out = dict(value=res["value"], unit="examples/sec", cores=2, kind=kind, sample=sample,
+                       stage_ms_per_batch=res["stage_ms_per_batch"], **info)
+        else:
+            out["scaled_threads"] = res
+    out["note"] = ("compute only: the reference's worker loop adds 10 ms sleep-polls (sgd_learner.cc:93,221) that are not "
+                   "reproduced here; AUC excluded on both sides")
+    return out
+
+
+def rcv1_shaped_batches(rng, n, rows, ids):
+    """C2: the shape of example/rcv1_sgd.conf — ~75 real-valued features per row over 47 236 ids, batch 100"""
+    out = []
+    for _ in range(n):
+        lens = np.clip(rng.poisson(75, size=rows), 1, None)
+        off = np.zeros(rows + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        nnz = int(off[-1])
+        idx = (rng.zipf(1.2, size=nnz) % ids + 1).astype(np.uint64)
+        val = np.abs(rng.normal(size=nnz) * 0.1).astype(np.float32)
+        lab = np.where(rng.random(rows) < 0.47, 1.0, -1.0).astype(np.float32)
+        out.append(dict(offset=off, index=idx, value=val, label=lab))
+    return out
 
 
 def main():
@@ -129,7 +218,7 @@ def main():
         return subprocess.call(cmd)
     if args.gpus > 1 or world > 1 or args.force_sharded:
         from difacto_amd import sharded
-        return sharded.bench_main(args, rank, world, local_rank, HYPER)
+        return sharded.bench_main(args, rank, world, local_rank, args.hyper)
 
     import torch  # device plumbing only: barrier-equivalent sync + sanity that a GPU exists
     if not torch.cuda.is_available():
@@ -138,18 +227,37 @@ def main():
     from difacto_amd.build import build_hip
     build_hip()
 
-    B, k = args.rows, args.vdim
-    S = synth.NUM_SLOTS
+    B, k, hyper = args.rows, args.vdim, args.hyper
+    criteo = args.preset != "c2"
     ctx = capi.Context(local_rank)
-    gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
-    table = capi.Table(ctx, int(args.ids * 1.02) + 4 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **HYPER)
+    if args.preset == "c5-slice" and not args.no_prefill:
+        # one GPU's share of C5 (1e9 ids over 8 GPUs = 1.25e8 rows each; SURVEY 8e "Capacity"): as many rows as
+        # fit, leaving room for the batches and the runtime.  per row: 2*kp*4 B V+acc, 32 B header, ~32 B index
+        free_b, _total_b = torch.cuda.mem_get_info()
+        per_row = 2 * ((k + 3) // 4 * 4) * 4 + 32 + 2 * 16 * 2
+        fit = int((free_b - (8 << 30)) / per_row)
+        if fit < args.ids:
+            args.ids = max(fit, 1_000_000)
+    gen = synth.CriteoSynth(total_ids=args.ids, seed=42) if criteo else None
+    S = synth.NUM_SLOTS if criteo else 0
+    nd = max(1, min(args.distinct, args.steps + args.warmup))
+    if criteo:
+        capacity = int(args.ids * 1.02) + 4 * B * S
+        host_batches = [gen.batch(B) for _ in range(nd)]
+    else:
+        capacity = int(args.ids * 1.5) + 4096
+        host_batches = rcv1_shaped_batches(np.random.default_rng(42), nd, B, args.ids)
+    max_nnz = max(int(hb["offset"][-1]) for hb in host_batches)
+    table = capi.Table(ctx, capacity, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
 
     t0 = time.time()
     if not args.no_prefill:
         # warm model: every feature id present with an allocated V row, so every
         # gathered row moves its full (1+k)*4 bytes (worst-case traffic)
-        for g in range(S):
-            keys = synth.reverse_bytes_np(gen.all_ids(g))
+        groups = ([synth.reverse_bytes_np(gen.all_ids(g)) for g in range(S)] if criteo and args.ids <= 40_000_000 else
+                  (synth.reverse_bytes_np(gen.all_ids(g)) for g in range(S)) if criteo else
+                  [synth.reverse_bytes_np(np.arange(1, args.ids + 1, dtype=np.uint64))])
+        for keys in groups:
             chunk = 1 << 22
             for o in range(0, len(keys), chunk):
                 part = np.ascontiguousarray(keys[o:o + chunk])
@@ -160,26 +268,26 @@ def main():
     nkeys = table.size()
     t_prefill = time.time() - t0
 
-    nd = max(1, min(args.distinct, args.steps + args.warmup))
-    host_batches = [gen.batch(B) for _ in range(nd)]
     dev = []
     for hb in host_batches:
         off32 = hb["offset"].astype(np.uint32)
         dev.append((capi.DeviceBuffer.from_numpy(ctx, off32), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
-                    capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
+                    capi.DeviceBuffer.from_numpy(ctx, hb["label"]),
+                    None if hb["value"] is None else capi.DeviceBuffer.from_numpy(ctx, hb["value"]),
+                    len(hb["label"]), int(hb["offset"][-1])))
     # depth+1 batch objects: batches t+1 .. t+depth are localized on the preparation streams while
     # batch t trains on the main stream (updates are still applied strictly in batch order)
     depth = 0 if args.no_pipeline else max(1, min(args.prep_streams, 4))
     ctx.set_pipeline(depth)
     ahead = max(depth, 1)
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
-    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + (2 if depth else 1))]
+    bts = [capi.Batch(ctx, B, max_nnz) for _ in range(ahead + (2 if depth else 1))]
     bt = bts[0]
 
     def prep(i):
-        o, x, l = dev[i % nd]
+        o, x, l, v, nr, nz = dev[i % nd]
         b = bts[i % len(bts)]
-        b.attach_device(B, B * S, o.ptr, x.ptr, None, l.ptr)  # inputs are resident in HBM: no copy
+        b.attach_device(nr, nz, o.ptr, x.ptr, None if v is None else v.ptr, l.ptr)  # inputs are resident in HBM: no copy
         b.localize()
         if args.prep_lookup:
             b.lookup(table)
@@ -188,36 +296,50 @@ def main():
         prep(i + ahead)
         bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=True)
 
-    for i in range(ahead - 1):
+    for i in range(ahead):
         prep(i)
-    prep(ahead - 1)
+    done = 0
     for i in range(args.warmup):
-        step(i)
+        step(done)
+        done += 1
     ctx.sync()
     torch.cuda.synchronize()
     for b in bts:
         b.progress(reset=True)
-    # live timing of the dominant kernel inside the timed region: the k_forward dispatch of every
+    # live timing of the two big kernels inside the timed region: the k_forward / k_backward_all dispatch of every
     # TIMING_EVERY-th step carries a start/stop HIP event pair (hipExtLaunchKernelGGL: the kernel's own
     # begin/end stamps, no marker packets).  Every step would cost the job 3 %, every 4th costs 1 %.
-    fwd_mask = 0 if args.no_timing else ((1 << capi.K_FORWARD) | (1 << capi.K_BACKWARD))
+    mask = 0 if args.no_timing else ((1 << capi.K_FORWARD) | (1 << capi.K_BACKWARD))
     ctx.get_timing(reset=True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if fwd_mask and i % TIMING_EVERY == 0:
-            ctx.set_timing_mask(fwd_mask)
-            step(args.warmup + i)
-            ctx.set_timing_mask(0)
-        else:
-            step(args.warmup + i)
-    t_enqueued = time.perf_counter() - t0   # host side only: everything is queued, nothing awaited yet
-    ctx.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    reps, enq = [], []
+    t_all = 0.0
+    while True:
+        ctx.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if mask and i % TIMING_EVERY == 0:
+                ctx.set_timing_mask(mask)
+                step(done)
+                ctx.set_timing_mask(0)
+            else:
+                step(done)
+            done += 1
+        t_enq = time.perf_counter() - t0   # host side only: everything is queued, nothing awaited yet
+        ctx.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        reps.append(dt)
+        enq.append(t_enq)
+        t_all += dt
+        if t_all >= args.min_time or len(reps) >= args.max_reps:
+            break
+    order = np.argsort(reps)
+    dt = float(reps[order[len(reps) // 2]])  # the median repetition
+    t_enqueued = float(enq[order[len(reps) // 2]])
     progs = [b.progress(reset=True) for b in bts]
-    prog = capi.Progress()
-    prog.loss = sum(p.loss for p in progs)
-    prog.nrows = sum(p.nrows for p in progs)
+    loss_sum = sum(p.loss for p in progs)
+    rows_sum = sum(p.nrows for p in progs)
     timing = {} if args.no_timing else ctx.get_timing(reset=True)
     # per-kernel breakdown from a separate, fully instrumented pass (NOT part of the timed region)
     breakdown = {}
@@ -225,59 +347,84 @@ def main():
         nb_steps = min(args.steps, 50)
         ctx.set_timing(True)
         for i in range(nb_steps):
-            step(args.warmup + args.steps + i)
+            step(done)
+            done += 1
         breakdown = {n: v[0] / nb_steps for n, v in ctx.get_timing(reset=True).items() if v[1] > 0}
         ctx.set_timing(False)
         for b in bts:
             b.progress(reset=True)
-    _, _, U_last = bt.shape()
+    U_all = []
+    for b in bts:
+        U_all.append(b.shape()[2])
+    U_mean = float(np.mean(U_all))
+    nnz_mean = float(np.mean([d[5] for d in dev]))
+    s_mean = nnz_mean / B
 
     ex_per_s = args.steps * B / dt
-    r_g = S * (1 + k) * 4  # algorithmic gather bytes per example
+    r_g = s_mean * (1 + k) * 4  # algorithmic gather bytes per example
+    u = U_mean / B
+    r_step = s_mean * (1 + k) * 4 + s_mean * k * 4 + u * (3 + 2 * k) * 4 * 2  # SURVEY 8d full-step accounting
     roofline = None
     if timing and timing["forward"][1] > 0:
         fwd_ms = timing["forward"][0] / timing["forward"][1]
         achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", kernel="k_forward", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<"),
+                        frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<", args.preset),
                         algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms,
                         launches_timed=int(timing["forward"][1]))
-    # the same for the longest kernel of the step, the fused backward/update (SURVEY 8d "full-step accounting":
-    # XV re-read s*k*4 per example + state read and written (8+2k)*4*2 per unique key)
+    # the same for the longest kernel of the step, the fused backward/update.  algorithmic = SURVEY 8d's
+    # full-step accounting (XV re-read s*k*4 per example + state read and written (3+2k)*4*2 per unique key);
+    # hbm_necessary = the state bytes alone: the XV re-read is an L2-resident B*kp*4 B array, not HBM traffic
     roofline_bwd = None
     if timing and timing["backward"][1] > 0:
         bwd_ms = timing["backward"][0] / timing["backward"][1]
-        bwd_bytes = B * S * k * 4 + int(U_last) * (8 + 2 * k) * 4 * 2
+        nec = U_mean * (3 + 2 * k) * 4 * 2
+        bwd_bytes = B * s_mean * k * 4 + nec
         ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9
         roofline_bwd = dict(bound="hbm", kernel="k_backward_all", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic("k_backward_all<"),
-                            algorithmic_bytes_per_launch=bwd_bytes, avg_launch_ms=bwd_ms,
-                            launches_timed=int(timing["backward"][1]))
+                            frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic("k_backward_all<", args.preset),
+                            algorithmic_bytes_per_launch=bwd_bytes, hbm_necessary_bytes_per_launch=nec,
+                            achieved_hbm_necessary=nec / (bwd_ms * 1e-3) / 1e9,
+                            frac_hbm_necessary=nec / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            avg_launch_ms=bwd_ms, launches_timed=int(timing["backward"][1]))
     nb = args.cpu_batches
     cpu = None
     if nb != 0:
         if nb < 0:
-            nb = max(2, min(nd, int(200000 / B)))  # ~20 batches of 10k rows: tens of seconds of CPU work
-        cpu = cpu_baseline(host_batches, k, nb)
+            # ~10-20 s of CPU work: two passes (fill + timed) at two thread settings
+            nb = max(2, min(nd, int((60000 if k <= 64 else 30000) / max(B, 1)) if criteo else 50))
+        cpu = cpu_baseline(host_batches, k, nb, hyper)
 
+    names = {"c3": "C3: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, FTRL(w)+AdaGrad(V), 1 MI355X" % (args.ids, k),
+             "c3-refdefaults": "C3 with the reference's default hyper-parameters (sgd_param.h:95-105: l1=1, V_threshold=10): "
+                               "%d ids / 39 slots, V_dim=%d, 1 MI355X" % (args.ids, k),
+             "c5-slice": "C5 slice: one GPU's share of the 1 B-id / V_dim=128 / l1-FTRL config — %d ids / 39 slots, V_dim=%d, "
+                         "1 MI355X" % (args.ids, k),
+             "c2": "C2 shape: rcv1-like synthetic, %d ids, ~%d real-valued features/row, batch %d, V_dim=%d, 1 MI355X"
+                   % (args.ids, round(s_mean), B, k)}
     out = {
-        "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
+        "metric": "examples/sec (FM SGD worker step, %s, V_dim=%d)" % ("Criteo-shape" if criteo else "rcv1-shape", k),
         "value": ex_per_s, "unit": "examples/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, FTRL(w)+AdaGrad(V), 1 MI355X"
-                               % (args.ids, k),
-                   "rows_per_step": B, "nnz_per_row": S, "unique_keys_last_batch": int(U_last),
+        "config": {"workload": names[args.preset], "preset": args.preset,
+                   "rows_per_step": B, "nnz_per_row": s_mean, "unique_keys_per_batch": U_mean,
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
-                   "model_keys": int(nkeys), "prefilled": not args.no_prefill, "hyper": HYPER,
+                   "model_keys": int(nkeys), "table_bytes": table.bytes(), "prefilled": not args.no_prefill, "hyper": hyper,
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
+        "repetitions": len(reps), "timed_region_s_total": t_all,
+        "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,
+        "value_note": "median of `repetitions` timed regions of `steps` steps each",
         "roofline": roofline,
         "roofline_backward": roofline_bwd,
+        "roofline_step": dict(bound="hbm", bytes_per_example=r_step, achieved=ex_per_s * r_step / 1e9, peak=HBM_PEAK_GBPS,
+                              unit="GB/s", frac=ex_per_s * r_step / 1e9 / HBM_PEAK_GBPS,
+                              note="SURVEY 8d R_step = s(1+k)4 + s k 4 + u(3+2k)8 with the measured u = U/B"),
         "cpu_baseline": cpu,
         "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "kernel_ms_per_step": breakdown,
         "kernel_ms_per_step_note": "separate instrumented pass after the timed region (HIP events around every kernel group)",
-        "train_logloss_per_example": prog.loss / max(prog.nrows, 1),
+        "train_logloss_per_example": loss_sum / max(rows_sum, 1),
         "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
         "prefill_seconds": t_prefill,
     }

@@ -324,12 +324,14 @@ class Ref:
         s = ";".join("%s=%r" % (k, v) for k, v in d.items())
         return RefStore(self, self.L.ref_store_create(s.encode()), d["V_dim"])
 
-    def _loss_for(self, V_dim):
-        if V_dim not in self._loss:
-            self._loss[V_dim] = self.L.ref_fmloss_create(V_dim, 2)
-        return self._loss[V_dim]
+    def _loss_for(self, V_dim, nthreads=2):
+        """one FMLoss per (V_dim, OpenMP threads); 2 threads is the reference's blk_nthreads_ (sgd_learner.h:90),
+        Loss::set_nthreads accepts 1 < n < 50 (include/difacto/loss.h:81)"""
+        if (V_dim, nthreads) not in self._loss:
+            self._loss[(V_dim, nthreads)] = self.L.ref_fmloss_create(V_dim, nthreads)
+        return self._loss[(V_dim, nthreads)]
 
-    def fm_predict(self, V_dim, offset, index, value, weights, w_pos=None, V_pos=None):
+    def fm_predict(self, V_dim, offset, index, value, weights, w_pos=None, V_pos=None, nthreads=2):
         offset = _sz(offset)
         index = np.ascontiguousarray(index, np.uint32)
         value = _f32(value)
@@ -339,11 +341,11 @@ class Ref:
         npos = 0 if w_pos is None else len(w_pos)
         w_pos = None if w_pos is None else np.ascontiguousarray(w_pos, np.int32)
         V_pos = None if V_pos is None else np.ascontiguousarray(V_pos, np.int32)
-        self.L.ref_fmloss_predict(self._loss_for(V_dim), n, _p(offset), _p(index), _p(value), _p(weights),
+        self.L.ref_fmloss_predict(self._loss_for(V_dim, nthreads), n, _p(offset), _p(index), _p(value), _p(weights),
                                   len(weights), _p(w_pos), _p(V_pos), npos, _p(pred))
         return pred
 
-    def fm_predict_calcgrad(self, V_dim, offset, index, value, label, weights, w_pos=None, V_pos=None):
+    def fm_predict_calcgrad(self, V_dim, offset, index, value, label, weights, w_pos=None, V_pos=None, nthreads=2):
         """Predict then CalcGrad on the same FMLoss instance (CalcGrad needs Predict's XV_)"""
         offset = _sz(offset)
         index = np.ascontiguousarray(index, np.uint32)
@@ -351,12 +353,12 @@ class Ref:
         weights = _f32(weights)
         label = _f32(label)
         n = len(offset) - 1
-        pred = self.fm_predict(V_dim, offset, index, value, weights, w_pos, V_pos)
+        pred = self.fm_predict(V_dim, offset, index, value, weights, w_pos, V_pos, nthreads=nthreads)
         grad = np.zeros(len(weights), np.float32)
         npos = 0 if w_pos is None else len(w_pos)
         w_pos = None if w_pos is None else np.ascontiguousarray(w_pos, np.int32)
         V_pos = None if V_pos is None else np.ascontiguousarray(V_pos, np.int32)
-        self.L.ref_fmloss_calcgrad(self._loss_for(V_dim), n, _p(offset), _p(index), _p(value), _p(label),
+        self.L.ref_fmloss_calcgrad(self._loss_for(V_dim, nthreads), n, _p(offset), _p(index), _p(value), _p(label),
                                    _p(weights), len(weights), _p(w_pos), _p(V_pos), npos, _p(pred), _p(grad))
         return pred, grad
 
@@ -385,11 +387,11 @@ class RefStore:
     def pull(self, keys):
         keys = np.ascontiguousarray(keys, np.uint64)
         n = len(keys)
-        vals = np.zeros(max(n * (1 + self.V_dim), 1), np.float32)
-        lens = np.zeros(max(n, 1), np.int32)
+        vals = np.empty(max(n * (1 + self.V_dim), 1), np.float32)  # views, no second copy: this call is timed by bench.py
+        lens = np.empty(max(n, 1), np.int32)
         nv, nl = C.c_size_t(0), C.c_size_t(0)
         self.r.L.ref_store_pull(self.h, _p(keys), n, _p(vals), C.byref(nv), _p(lens), C.byref(nl))
-        return vals[:nv.value].copy(), lens[:nl.value].copy()
+        return vals[:nv.value], lens[:nl.value]
 
     def push(self, keys, val_type, vals, lens=None):
         keys = np.ascontiguousarray(keys, np.uint64)
