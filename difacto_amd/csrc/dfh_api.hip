@@ -109,15 +109,18 @@ struct dfh_batch {
   float* o_value = nullptr;
   float* o_label = nullptr;
   // localizer workspace
-  uint64_t *d_keys = nullptr, *d_skeys = nullptr;
-  uint32_t *d_pos = nullptr, *d_spos = nullptr, *d_head = nullptr, *d_uid = nullptr;
+  uint64_t *d_keys = nullptr, *d_skeys = nullptr;   // bucket-major / sorted keys
+  uint32_t *d_pos = nullptr, *d_spos = nullptr;     // row of every nnz position (d_pos) / sorted positions
+  uint32_t *d_bpos = nullptr;                       // bucket-major positions
+  uint32_t *d_head = nullptr, *d_uid = nullptr;     // library-sort path only
   void* d_temp = nullptr;
   size_t temp_bytes = 0;
-  // sample-sort localizer workspace
-  uint64_t *d_spl_key = nullptr, *d_first_key = nullptr, *d_last_key = nullptr, *d_smp_key = nullptr;
-  uint32_t *d_smp_rank = nullptr, *d_smp_pos = nullptr, *d_spl_pos = nullptr, *d_packed = nullptr, *d_hist = nullptr, *d_run_off = nullptr, *d_bstart = nullptr,
-           *d_nheads = nullptr, *d_bpos = nullptr, *d_btotal = nullptr, *d_ubase = nullptr, *d_cont = nullptr;
+  // sample-sort localizer: bootstrap samples, persistent splitters, per-call bucket bookkeeping
+  uint64_t *d_smp_key = nullptr, *d_spl_key = nullptr, *d_first_key = nullptr, *d_last_key = nullptr;
+  uint32_t *d_smp_rank = nullptr, *d_smp_pos = nullptr, *d_spl_pos = nullptr, *d_packed = nullptr, *d_run_off = nullptr,
+           *d_bstart = nullptr, *d_btotal = nullptr, *d_nheads = nullptr, *d_lh = nullptr;
   size_t max_tiles = 0;
+  int spl_P = 0;                   // number of buckets the stored splitters partition into (0: none yet)
   // localized view
   uint64_t* d_feaids = nullptr;
   float* d_feacnt = nullptr;
@@ -125,8 +128,9 @@ struct dfh_batch {
   float* d_s_val = nullptr;
   uint32_t* d_U = nullptr;
   // step workspace
-  uint32_t* d_nnz_row = nullptr;
-  uint32_t *d_seg_n = nullptr, *d_mid_list = nullptr, *d_hot_list = nullptr;  // long-segment key lists (k_seg_lists)
+  // long-segment key lists for the backward pass (SegLists): list buckets = sort buckets
+  uint32_t *d_mid_cnt = nullptr, *d_mid_off = nullptr, *d_mid_ent = nullptr, *d_hot_cnt = nullptr, *d_hot_off = nullptr,
+           *d_hot_ent = nullptr;
   uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
   float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
@@ -341,15 +345,18 @@ BatchView batch_view(const dfh_batch* b) {
   v.s_row = b->d_s_row;
   v.s_val = b->has_value ? b->d_s_val : nullptr;
   v.urow = b->d_urow;
-  v.nnz_row = nullptr;
   v.uw = nullptr;
   v.pred = b->d_pred;
   v.slope = b->d_slope;
   v.xv = b->d_xv;
   v.prog = b->d_prog;
-  v.seg_n = b->d_seg_n;
-  v.mid_list = b->d_mid_list;
-  v.hot_list = b->d_hot_list;
+  v.seg.nb = b->d_U + SEG_NB_WORD;
+  v.seg.mid_cnt = b->d_mid_cnt;
+  v.seg.mid_off = b->d_mid_off;
+  v.seg.mid_ent = b->d_mid_ent;
+  v.seg.hot_cnt = b->d_hot_cnt;
+  v.seg.hot_off = b->d_hot_off;
+  v.seg.hot_ent = b->d_hot_ent;
   return v;
 }
 
@@ -383,9 +390,8 @@ int dispatch_L(int kp, F&& f) {
   return DFH_OK;
 }
 
-int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, bool use_nnz_rows = false, const uint2* uw = nullptr) {
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr) {
   BatchView bv = batch_view(b);
-  if (use_nnz_rows) bv.nnz_row = b->d_nnz_row;
   bv.uw = uw;
   // one wave per example, all resident at once where possible: the kernel is
   // bound by the latency of its dependent gathers, not by launch size
@@ -1501,26 +1507,24 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_skeys, N, uint64_t);
   DFH_ALLOC(b->d_pos, N, uint32_t);
   DFH_ALLOC(b->d_spos, N, uint32_t);
+  DFH_ALLOC(b->d_bpos, N, uint32_t);
   DFH_ALLOC(b->d_head, N, uint32_t);
   DFH_ALLOC(b->d_uid, N, uint32_t);
   DFH_ALLOC(b->d_temp, b->temp_bytes, char);
-  b->max_tiles = (N + SS_TILE - 1) / SS_TILE;
-  DFH_ALLOC(b->d_spl_key, SS_MAX_BUCKETS, uint64_t);
-  DFH_ALLOC(b->d_smp_key, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint64_t);
-  DFH_ALLOC(b->d_smp_pos, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint32_t);
-  DFH_ALLOC(b->d_smp_rank, SS_MAX_BUCKETS * SS_OVERSAMPLE, uint32_t);
-  DFH_ALLOC(b->d_first_key, SS_MAX_BUCKETS, uint64_t);
-  DFH_ALLOC(b->d_last_key, SS_MAX_BUCKETS, uint64_t);
-  DFH_ALLOC(b->d_spl_pos, SS_MAX_BUCKETS, uint32_t);
+  b->max_tiles = (N + LOC_TILE - 1) / LOC_TILE;
+  DFH_ALLOC(b->d_spl_key, LOC_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_spl_pos, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_smp_key, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint64_t);
+  DFH_ALLOC(b->d_smp_pos, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_smp_rank, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_first_key, LOC_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_last_key, LOC_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_packed, N, uint32_t);
-  DFH_ALLOC(b->d_hist, b->max_tiles * SS_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_run_off, b->max_tiles * SS_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_bstart, SS_MAX_BUCKETS + 1, uint32_t);
-  DFH_ALLOC(b->d_nheads, SS_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_bpos, N, uint32_t);
-  DFH_ALLOC(b->d_btotal, SS_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_ubase, SS_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_cont, SS_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_run_off, b->max_tiles * LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_bstart, LOC_MAX_BUCKETS + 1, uint32_t);
+  DFH_ALLOC(b->d_btotal, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_nheads, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_lh, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
   DFH_ALLOC(b->d_feacnt, N, float);
   DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
@@ -1529,10 +1533,14 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_s_val, N, float);
   DFH_ALLOC(b->d_U, 64, uint32_t);
   DFH_ALLOC(b->d_urow, N, uint32_t);
-  DFH_ALLOC(b->d_nnz_row, N, uint32_t);
   DFH_ALLOC(b->d_uw, N, uint2);
-  DFH_ALLOC(b->d_mid_list, N / (BWD_SMALL + 1) + 1, uint32_t);
-  DFH_ALLOC(b->d_hot_list, N / (BWD_MID + 1) + 1, uint32_t);
+  // bucket q of the sample sort may list n_q / 9 + 2 mid and n_q / 257 + 2 hot keys (k_loc_emit)
+  DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
+  DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
+  DFH_ALLOC(b->d_mid_cnt, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_mid_off, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_hot_cnt, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_hot_off, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1544,11 +1552,11 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_slab, B, uint32_t);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
-  b->d_seg_n = b->d_U + SEG_N_WORD;
   DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
   DFH_HIP(hipEventCreateWithFlags(&b->ev_free, hipEventDisableTiming));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
   return DFH_OK;
@@ -1560,12 +1568,13 @@ int dfh_batch_destroy(dfh_batch* b) {
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
   if (b->ev_free) hipEventDestroy(b->ev_free);
-  void* ptrs[] = {b->o_raw,   b->o_offset, b->o_value,   b->o_label, b->d_keys,  b->d_skeys, b->d_pos,  b->d_spos,
-                  b->d_head,  b->d_uid,    b->d_temp,    b->d_feaids, b->d_feacnt, b->d_col_ptr, b->d_index, b->d_s_row,
-                  b->d_s_val, b->d_U,      b->d_urow,    b->d_need,  b->d_rank,  b->d_nnz_row, b->d_pred,  b->d_slope, b->d_xv,
-                  b->d_prog,  b->d_smp_key, b->d_smp_pos, b->d_smp_rank, b->d_spl_key, b->d_first_key, b->d_last_key, b->d_spl_pos, b->d_packed, b->d_hist, b->d_run_off,
-                  b->d_auc_keys, b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_bstart, b->d_nheads, b->d_bpos, b->d_btotal, b->d_ubase, b->d_cont,
-                  b->d_mid_list, b->d_hot_list, b->d_uw};
+  void* ptrs[] = {b->o_raw,    b->o_offset,  b->o_value,    b->o_label,    b->d_keys,     b->d_skeys,     b->d_pos,     b->d_spos,
+                  b->d_bpos,   b->d_head,    b->d_uid,      b->d_temp,     b->d_feaids,   b->d_feacnt,    b->d_col_ptr, b->d_index,
+                  b->d_s_row,  b->d_s_val,   b->d_U,        b->d_urow,     b->d_need,     b->d_rank,      b->d_pred,    b->d_slope,
+                  b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
+                  b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
+                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid_cnt, b->d_mid_off, b->d_mid_ent,  b->d_hot_cnt, b->d_hot_off,
+                  b->d_hot_ent, b->d_uw};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1668,15 +1677,27 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   }
   const int g = grid_for_threads(N, c);
   TimeScope* tsp = new TimeScope(c, DFH_K_LOCALIZE, s);
-  const size_t P_want = (N + SS_AVG_BUCKET - 1) / SS_AVG_BUCKET;
-  if (P_want <= SS_MAX_BUCKETS && !b->force_radix) {
+  // bucket count: the stored splitters' while the average bucket stays in a sane range (they
+  // describe the data distribution, not this minibatch), else sized for this minibatch and
+  // bootstrapped from a sample
+  int P = 0;
+  bool cold = true;
+  if (b->spl_P > 0 && N / (uint32_t)b->spl_P >= (uint32_t)LOC_MIN_AVG && N / (uint32_t)b->spl_P <= (uint32_t)LOC_MAX_AVG) {
+    P = b->spl_P;
+    cold = false;
+  } else {
+    const size_t P_want = (N + LOC_AVG_BUCKET - 1) / LOC_AVG_BUCKET;
+    P = P_want <= (size_t)LOC_MAX_BUCKETS ? (int)std::max<size_t>(1, P_want) : 0;
+    if (P == 0 && N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
+  }
+  if (P > 0 && !b->force_radix) {
     // hand-written sample sort (dfh_localize.hip)
-    SSView v;
+    LocView v;
     v.raw = b->d_raw;
     v.n = N;
     v.max_index = max_index;
-    v.P = (int)std::max<size_t>(1, P_want);
-    v.ntiles = (int)((N + SS_TILE - 1) / SS_TILE);
+    v.P = P;
+    v.ntiles = (int)((N + LOC_TILE - 1) / LOC_TILE);
     v.force_global = b->force_sort_fallback ? 1 : 0;
     v.smp_key = b->d_smp_key;
     v.smp_pos = b->d_smp_pos;
@@ -1684,50 +1705,56 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     v.spl_key = b->d_spl_key;
     v.spl_pos = b->d_spl_pos;
     v.packed = b->d_packed;
-    v.hist = b->d_hist;
     v.run_off = b->d_run_off;
-    v.bstart = b->d_bstart;
     v.btotal = b->d_btotal;
+    v.bstart = b->d_bstart;
     v.bkeys = b->d_keys;
     v.bpos = b->d_bpos;
-    v.ubase = b->d_ubase;
-    v.cont = b->d_cont;
     v.skeys = b->d_skeys;
     v.spos = b->d_spos;
-    v.luid = b->d_uid;
-    v.head = b->d_head;
     v.first_key = b->d_first_key;
     v.last_key = b->d_last_key;
     v.nheads = b->d_nheads;
-    const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
-    hipLaunchKernelGGL(k_ss_sample, dim3(grid_for_threads(std::max<size_t>(b->nrows, S), c)), dim3(256), 0, s, v,
-                       (uint32_t)b->nrows, b->d_offset, b->d_pos);
-    {
+    v.lh = b->d_lh;
+    SegListsOut sl;
+    sl.nb = b->d_U + SEG_NB_WORD;
+    sl.mid_cnt = b->d_mid_cnt;
+    sl.mid_off = b->d_mid_off;
+    sl.mid_ent = b->d_mid_ent;
+    sl.hot_cnt = b->d_hot_cnt;
+    sl.hot_off = b->d_hot_off;
+    sl.hot_ent = b->d_hot_ent;
+    if (cold && P > 1) {
+      const uint32_t S = (uint32_t)P * LOC_OVERSAMPLE;
       const uint32_t nt = (S + 255) / 256;
+      hipLaunchKernelGGL(k_ss_sample, dim3(nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
+      hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    hipLaunchKernelGGL(k_ss_count, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_ss_scan, dim3((v.P + SS_SCAN_BUCKETS - 1) / SS_SCAN_BUCKETS), dim3(256), 0, s, v);
-    hipLaunchKernelGGL(k_ss_scatter, dim3(v.ntiles), dim3(SS_TILE_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_ss_sort, dim3(v.P), dim3(SS_SORT_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_ss_emit, dim3(v.P), dim3(256), 0, s, v, b->d_pos,
+    hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+    hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_loc_sort, dim3(P), dim3(LOC_SORT_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_loc_emit, dim3(P), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
                        b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                       b->d_s_val, b->d_U);
+                       b->d_s_val, b->d_U, sl);
+    b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
   } else {
     // very large batches: library LSD radix sort
-    hipLaunchKernelGGL(k_loc_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
+    hipLaunchKernelGGL(k_rdx_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
     size_t tb = b->temp_bytes;
     DFH_HIP(rocprim::radix_sort_pairs(b->d_temp, tb, b->d_keys, b->d_skeys, b->d_pos, b->d_spos, (size_t)N, 0, 64, s));
-    hipLaunchKernelGGL(k_loc_heads, dim3(g), dim3(256), 0, s, b->d_skeys, N, b->d_head);
+    hipLaunchKernelGGL(k_rdx_heads, dim3(g), dim3(256), 0, s, b->d_skeys, N, b->d_head);
     tb = b->temp_bytes;
     DFH_HIP(rocprim::inclusive_scan(b->d_temp, tb, b->d_head, b->d_uid, (size_t)N, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_loc_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
+    hipLaunchKernelGGL(k_rdx_emit, dim3(g), dim3(256), 0, s, b->d_skeys, b->d_spos, b->d_head, b->d_uid, N, (uint32_t)b->nrows,
                        b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                        b->d_s_row, b->d_s_val, b->d_U);
+    // keys with long segments, for the backward pass: one list bucket
+    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_U + SEG_NB_WORD, b->d_mid_cnt, b->d_mid_off, b->d_hot_cnt,
+                       b->d_hot_off);
+    hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
+                       b->d_col_ptr, b->d_U, b->d_mid_cnt, b->d_hot_cnt, b->d_mid_ent, b->d_hot_ent);
   }
-  // keys with long segments, for the backward pass (the emit kernels zeroed the two counters)
-  hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
-                     b->d_col_ptr, b->d_U, b->d_seg_n, b->d_mid_list, b->d_hot_list);
   delete tsp;
   DFH_HIP(hipGetLastError());
   b->localized = true;
@@ -1749,6 +1776,10 @@ int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
     b->force_sort_fallback = value != 0;
     return DFH_OK;
   }
+  if (std::string(name) == "reset_splitters") {
+    if (value) b->spl_P = 0;  // the next dfh_localize bootstraps its splitters from a sample again
+    return DFH_OK;
+  }
   set_error(std::string("unknown batch option ") + name);
   return DFH_ERR_ARG;
 }
@@ -1768,8 +1799,6 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
     TimeScope ts(c, DFH_K_LOOKUP, ps);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, t->v, b->d_feaids, b->d_U, 0u,
                        b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr);
-    hipLaunchKernelGGL(k_nnz_rows, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, b->d_index, b->d_urow,
-                       (uint32_t)b->nnz, b->d_nnz_row);
   }
   DFH_HIP(hipGetLastError());
   b->looked_up = t;
@@ -1829,12 +1858,13 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
-  DFH_HIP(hipMemsetAsync(b->d_seg_n, 0, 2 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_U + SEG_NB_WORD, b->d_mid_cnt, b->d_mid_off, b->d_hot_cnt,
+                     b->d_hot_off);
   if (U) {
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::min<size_t>((U + 1023) / 1024, 256)), dim3(1024), 0, s, b->d_col_ptr,
-                       b->d_U, b->d_seg_n, b->d_mid_list, b->d_hot_list);
-    DFH_HIP(hipGetLastError());
+                       b->d_U, b->d_mid_cnt, b->d_hot_cnt, b->d_mid_ent, b->d_hot_ent);
   }
+  DFH_HIP(hipGetLastError());
   DFH_HIP(hipStreamSynchronize(s));
   b->nrows = nrows;
   b->nnz = nnz;
@@ -1962,14 +1992,14 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   const uint32_t Nb = (uint32_t)b->nnz;  // upper bound of U for grids
   rc = main_begin(b);
   if (rc) return rc;
-  // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217).  When
-  // dfh_batch_lookup already resolved the rows on the prep stream only the count
-  // push remains (it must stay ordered with the previous step's update).
+  // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217).  When dfh_batch_lookup
+  // already resolved the rows on a preparation stream, what remains here is one pass over the
+  // known rows: the count push (it must stay ordered with the previous step's update) and
+  // {row, w} per key for the forward (w is current: the previous step's update precedes it on this
+  // stream), so that the forward touches nothing of a row but its V lines.
   const bool pre = b->looked_up == t;
-  // the lookup on THIS stream also leaves {row, w} per key for the forward (w is current: the
-  // previous step's update precedes it here); without it the forward reads the headers itself
-  uint2* uw = (!pre || push_cnt) ? b->d_uw : nullptr;
-  if (!pre || push_cnt) {
+  uint2* uw = b->d_uw;
+  {
     TimeScope ts(c, DFH_K_LOOKUP);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? 1 : 0,
@@ -1981,7 +2011,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     if (rc) return rc;
   }
   RowSrc src = table_src(t, b->d_urow);
-  rc = launch_forward(b, src, k, kp, pre, uw);
+  rc = launch_forward(b, src, k, kp, uw);
   if (rc) return rc;
   if (b->compute_auc) {
     rc = launch_auc(b);

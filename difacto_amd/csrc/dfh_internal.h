@@ -56,8 +56,23 @@ struct TableView {
   dfh_updater_param p;
 };
 
-// the batch's device scalar block d_U[64]: [0] = U, [1] = REFRAND total, [SEG_N_WORD..+1] = mid / hot list sizes
-constexpr int SEG_N_WORD = 8;
+// the batch's device scalar block d_U[64]: [0] = U, [1] = REFRAND total, [SEG_NB_WORD] = number of list buckets
+constexpr int SEG_NB_WORD = 8;
+
+// Long-segment lists for the backward pass: the keys whose segments (runs of equal key in the
+// key-ordered view) are longer than BWD_SMALL ("mid") / BWD_MID ("hot"), in *nb list buckets:
+// bucket q holds cnt[q] entries (values u = rank of the key) at ent[off[q] ..].  The sample-sort
+// Localizer fills one list bucket per sort bucket (k_loc_emit: no inter-block compaction);
+// k_seg_lists fills a single one.  Order inside and across buckets is arbitrary.
+struct SegLists {
+  const uint32_t* nb;
+  const uint32_t* mid_cnt;
+  const uint32_t* mid_off;
+  const uint32_t* mid_ent;
+  const uint32_t* hot_cnt;
+  const uint32_t* hot_off;
+  const uint32_t* hot_ent;
+};
 
 // "row source" seen by the forward / backward kernels: either the table
 // itself (rows addressed through urow[u]) or a packed [U x stride] buffer of
@@ -85,15 +100,12 @@ struct BatchView {
   const uint32_t* s_row;    // [nnz] row of each occurrence, key order (ties: row order)
   const float* s_val;       // [nnz] value of each occurrence, key order, or NULL
   uint32_t* urow;           // [U] table row of each unique key (filled by lookup)
-  const uint32_t* nnz_row;  // [nnz] urow[index[j]] when precomposed (dfh_batch_lookup), else NULL
   const uint2* uw;          // [U] {table row, w} per unique key as of this step's k_lookup, else NULL
   float* pred;              // [nrows]
   float* slope;             // [nrows] p_i = -y/(1+exp(y pred))
   float* xv;                // [nrows x kp]
   double* prog;             // [2][PROG_SLOTS] per-block partials: logloss, penalty
-  const uint32_t* seg_n;    // [2] number of mid / hot keys (k_seg_lists)
-  const uint32_t* mid_list; // keys with BWD_SMALL < occurrences <= BWD_MID, any order
-  const uint32_t* hot_list; // keys with more than BWD_MID occurrences, any order
+  SegLists seg;             // keys with BWD_SMALL < occurrences <= BWD_MID (mid) / more (hot)
 };
 
 // ------------------------------------------------------------- error plumbing

@@ -13,8 +13,8 @@
 //   k_refrand_*           rand_r-compatible lazy InitV (parity mode)
 //   k_predict_generic / k_calcgrad_generic / k_logloss   literal Loss API
 //   k_auc_keys / k_auc_area   BinClassMetric::AUC
-//   k_loc_*               Localizer::Compact around a library radix sort (very large batches);
-//                         the sample-sort Localizer lives in dfh_localize.hip
+//   k_rdx_*               Localizer::Compact around a library radix sort (very large batches);
+//                         the sample-sort Localizer (k_loc_*) lives in dfh_localize.hip
 //
 // All kernels assume 64-lane wavefronts and are launched with 256-thread
 // blocks (4 waves) unless noted.
@@ -361,12 +361,8 @@ __global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k,
           hv = 1u;
           wsum += __uint_as_float(e.y) * x;
         } else {
-          if (b.nnz_row) {
-            r = b.nnz_row[j];  // urow[index[j]] composed ahead of time on the preparation stream
-          } else {
-            const uint32_t u = b.index[j];
-            r = src.urow ? src.urow[u] : u;
-          }
+          const uint32_t u = b.index[j];
+          r = src.urow ? src.urow[u] : u;
           const float* wp = src.wbase + (size_t)r * src.wstride;
           // {w, has_V} are adjacent: one 8 B load
           float2 wf = *reinterpret_cast<const float2*>(wp);
@@ -643,13 +639,23 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
-  const uint32_t nm = b.seg_n[0];
-  for (uint32_t q = wave; q < nm; q += nwaves) {
-    const uint32_t u = b.mid_list[q];
-    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
-    const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-    KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
-    if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+  // waves are dealt to the list buckets: G waves per bucket when there are more waves than buckets
+  const uint32_t nb = *b.seg.nb;
+  if (nb == 0) return;
+  const uint32_t G = max(1u, nwaves / nb), ngroups = nwaves / G;
+  const uint32_t grp_w = wave / G, sub_w = wave % G;
+  if (grp_w >= ngroups) return;
+  for (uint32_t lb = grp_w; lb < nb; lb += ngroups) {
+    const uint32_t nm = b.seg.mid_cnt[lb];
+    if (nm == 0) continue;
+    const uint32_t* __restrict__ ent = b.seg.mid_ent + b.seg.mid_off[lb];
+    for (uint32_t q = sub_w; q < nm; q += G) {
+      const uint32_t u = ent[q];
+      const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+      const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
+      KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
+      if (grp == 0) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+    }
   }
 }
 
@@ -663,9 +669,19 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
   const int w = threadIdx.x >> 6;
-  const uint32_t nh = b.seg_n[1];
-  for (uint32_t q = blk; q < nh; q += nblk) {
-    const uint32_t u = b.hot_list[q];
+  // blocks are dealt to the list buckets like the waves of the mid role (uniform per block: the
+  // barriers below are reached by all of its threads)
+  const uint32_t nb = *b.seg.nb;
+  if (nb == 0) return;
+  const uint32_t G = max(1u, nblk / nb), ngroups = nblk / G;
+  const uint32_t grp_b = blk / G, sub_b = blk % G;
+  if (grp_b >= ngroups) return;
+  for (uint32_t lb = grp_b; lb < nb; lb += ngroups) {
+  const uint32_t nh = b.seg.hot_cnt[lb];
+  if (nh == 0) continue;
+  const uint32_t* __restrict__ ent = b.seg.hot_ent + b.seg.hot_off[lb];
+  for (uint32_t q = sub_b; q < nh; q += G) {
+    const uint32_t u = ent[q];
     const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
     const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
     KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
@@ -692,6 +708,7 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
       }
       finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc);
     }
+  }
   }
 }
 
@@ -900,10 +917,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, Ro
 }
 
 // k_seg_lists: one pass over the unique keys of a localized minibatch, compacting the keys with
-// long segments into the mid / hot lists (one atomic per block and list; seg_n zeroed before)
+// long segments into ONE list bucket (one atomic per block and list; the two counters zeroed
+// before).  Used where the minibatch did not come out of k_rdx_emit (library-sort Localizer for
+// very large batches, batches localized on the host).
 __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U,
-                                                    uint32_t* __restrict__ seg_n, uint32_t* __restrict__ mid_list,
-                                                    uint32_t* __restrict__ hot_list) {
+                                                    uint32_t* __restrict__ mid_cnt0, uint32_t* __restrict__ hot_cnt0,
+                                                    uint32_t* __restrict__ mid_ent, uint32_t* __restrict__ hot_ent) {
   __shared__ uint32_t cnt[2], base[2];
   const uint32_t U = *d_U;
   for (uint32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += gridDim.x * blockDim.x) {
@@ -915,11 +934,23 @@ __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__
     const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : -1);
     if (which >= 0) slot = atomicAdd(&cnt[which], 1u);
     __syncthreads();
-    if (threadIdx.x < 2 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&seg_n[threadIdx.x], cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && cnt[0]) base[0] = atomicAdd(mid_cnt0, cnt[0]);
+    if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(hot_cnt0, cnt[1]);
     __syncthreads();
-    if (which == 0) mid_list[base[0] + slot] = u;
-    if (which == 1) hot_list[base[1] + slot] = u;
+    if (which == 0) mid_ent[base[0] + slot] = u;
+    if (which == 1) hot_ent[base[1] + slot] = u;
     __syncthreads();
+  }
+}
+
+// one list bucket at offset 0, empty: what k_seg_lists adds to
+__global__ void k_seg_lists_reset(uint32_t* nb, uint32_t* mid_cnt, uint32_t* mid_off, uint32_t* hot_cnt, uint32_t* hot_off) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *nb = 1;
+    mid_cnt[0] = 0;
+    mid_off[0] = 0;
+    hot_cnt[0] = 0;
+    hot_off[0] = 0;
   }
 }
 
@@ -1385,7 +1416,7 @@ __global__ void k_logloss(const float* __restrict__ label, const float* __restri
 // radix sort of (key, position) pairs.
 // ---------------------------------------------------------------------------
 // keys[i] = ReverseBytes(id % max_index), pos[i] = i   (localizer.cc:22-26)
-__global__ void k_loc_keys(const uint64_t* __restrict__ raw, uint32_t nnz, uint64_t max_index,
+__global__ void k_rdx_keys(const uint64_t* __restrict__ raw, uint32_t nnz, uint64_t max_index,
                            uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
     keys[i] = reverse_bytes(raw[i] % max_index);
@@ -1394,7 +1425,7 @@ __global__ void k_loc_keys(const uint64_t* __restrict__ raw, uint32_t nnz, uint6
 }
 
 // head flags of runs of equal keys (localizer.cc:35-48)
-__global__ void k_loc_heads(const uint64_t* __restrict__ skeys, uint32_t nnz, uint32_t* __restrict__ head) {
+__global__ void k_rdx_heads(const uint64_t* __restrict__ skeys, uint32_t nnz, uint32_t* __restrict__ head) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
     head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
   }
@@ -1403,12 +1434,11 @@ __global__ void k_loc_heads(const uint64_t* __restrict__ skeys, uint32_t nnz, ui
 // uid = inclusive_scan(head) - 1.  Emits the dictionary, the segment starts,
 // the compact index per nnz (RemapIndex, localizer.cc:63-77) and the
 // key-ordered occurrence view (row, value) the backward pass walks.
-__global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ spos,
+__global__ void k_rdx_emit(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ spos,
                            const uint32_t* __restrict__ head, const uint32_t* __restrict__ uid_incl, uint32_t nnz,
                            uint32_t nrows, const uint32_t* __restrict__ offset, const float* __restrict__ value,
                            uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
                            uint32_t* __restrict__ s_row, float* __restrict__ s_val, uint32_t* __restrict__ d_U) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { d_U[SEG_N_WORD] = 0; d_U[SEG_N_WORD + 1] = 0; }  // for k_seg_lists
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
     const uint32_t uid = uid_incl[i] - 1;
     const uint32_t pos = spos[i];
@@ -1433,13 +1463,6 @@ __global__ void k_loc_emit(const uint64_t* __restrict__ skeys, const uint32_t* _
 }
 
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
-
-// nnz_row[j] = urow[index[j]]: the table row of every nnz, so that the forward kernel's gather
-// chain is offset -> nnz_row -> {w, V} instead of offset -> index -> urow -> w -> V
-__global__ void k_nnz_rows(const uint32_t* __restrict__ index, const uint32_t* __restrict__ urow, uint32_t nnz,
-                           uint32_t* __restrict__ nnz_row) {
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += gridDim.x * blockDim.x) nnz_row[j] = urow[index[j]];
-}
 
 // bounds[d] = first unique key of the batch owned by shard d (keys ascending; owner = key / span)
 __global__ void k_key_ranges(const uint64_t* __restrict__ feaids, const uint32_t* __restrict__ d_U, int nparts,

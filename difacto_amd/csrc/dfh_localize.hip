@@ -1,82 +1,103 @@
 // Device Localizer::Compact (src/data/localizer.cc:11-103) as a hand-written
 // sample sort for gfx950.
 //
-// The reference sorts (ReverseBytes(id % max), position) pairs by key
+// The reference sorts (ReverseBytes(id % max_index), position) pairs by key
 // (localizer.cc:22-29), walks the sorted run to emit the unique keys with their
 // counts (:35-48) and maps every nnz to the rank of its key (:63-77).  A
 // minibatch is small for a GPU (N ~ 4e5 pairs of 12 B: the whole thing lives
-// in L2), so an 8-pass LSD radix sort is launch- and latency-bound (9 x 2
-// launches, ~110 us measured with rocPRIM).  Instead, one partition pass and
-// one local pass:
+// in L2 / the memory-side cache), so the job is launch- and latency-bound; the
+// design minimises dependent passes.  Steady state = FOUR launches:
 //
-//   k_ss_sample     jittered samples of the composite (key, pos); also the row of every nnz
-//   k_ss_rank       rank of every sample among all samples, tiled over the whole
-//                   chip: every SS_OVERSAMPLE-th becomes a splitter
-//   k_ss_count      per tile: bucket of every pair (binary search over the
-//                   splitters in LDS) + LDS histogram; the LDS atomic's return
-//                   value is the pair's rank inside (tile, bucket)
-//   k_ss_scan       per bucket: prefix over tiles, bucket totals
-//   k_ss_scatter    pairs -> bucket-major order
-//   k_ss_sort       one block per bucket: merge sort in LDS by (key, pos)
-//                   (64-wide runs by ranking, then log2(n/64) rounds of
-//                   merge-by-binary-search), run heads + local unique ranks
-//   k_ss_emit       stitch the buckets (unique keys before each one); dictionary, segment starts, compact index per nnz and the
-//                   key-ordered (row, value) view for the backward pass
+//   k_loc_count    per tile of 2048 pairs: bucket of every pair (binary search over <= 1023
+//                  splitters in LDS) + LDS histogram, whose atomic's return value is the pair's
+//                  rank inside (tile, bucket); one global atomic per (tile, bucket) reserves the
+//                  run's place inside its bucket — no scan pass: the order of the runs inside a
+//                  bucket is irrelevant, the bucket is sorted next.  Side job: row of every nnz.
+//   k_loc_scatter  bucket starts (block scan of the 1024 totals) + pairs -> bucket-major order
+//   k_loc_sort     one block per bucket: merge sort in LDS by (key, pos) (64-wide runs by ranking,
+//                  then log2(n/64) rounds of merge-by-binary-search); bucket summary
+//   k_loc_emit     one block per bucket: unique ids before the bucket from the summaries, then the
+//                  Localizer's outputs (dictionary, segment starts, compact index per nnz), the
+//                  key-ordered (row, value) view for the backward pass, the long-segment lists of
+//                  k_backward_all, and THE SPLITTERS OF THE NEXT CALL: the exact P-quantiles of this
+//                  minibatch's sorted (key, pos) order.
 //
-// Splitting on the COMPOSITE (key, pos) makes every element distinct, so
-// buckets stay balanced however skewed the key distribution is (a feature
-// present in every row just spreads over several buckets); equal keys that
-// straddle a bucket boundary are stitched in k_ss_emit.  Measured
-// dead ends, kept out: a bitonic network (60+ barrier-separated stages at one
-// or two waves per SIMD: ~1 us of dependent issue latency each, 50-65 us per
-// bucket pass) and full O(n^2) ranking of a bucket (the largest bucket sets the
-// kernel time: 80-175 us).  Merge-by-binary-search needs log2(n/64) barriers.
-// The result is the fully sorted pair list (ties by position), i.e.
-// bit-identical to the reference's outputs.  Everything is deterministic.
+// Splitters are a property of the data distribution, not of the minibatch: consecutive
+// minibatches of one stream are partitioned almost perfectly by the previous one's quantiles
+// (buckets of 381 +- ~30 pairs at C3 size), which removes the sampling and sample-ranking passes
+// and — more important — the 2-3x oversize buckets that used to set the sort kernel's time.  They
+// affect balance only, never the result: any splitters give the same, unique sorted order, and
+// a bucket that outgrows the LDS budget is sorted through global memory.  The first call on a
+// batch object (or a change of size class) bootstraps them from a jittered sample:
+//
+//   k_ss_sample    jittered stratified sample of the composite (key, pos)
+//   k_ss_rank      all-pairs rank of the samples, tiled over the whole chip
+//   k_loc_splitters  every LOC_OVERSAMPLE-th sample becomes a splitter
+//
+// Splitting on the COMPOSITE (key, pos) makes every element distinct, so buckets stay balanced
+// however skewed the key distribution is (a feature present in every row just spreads over
+// several buckets); equal keys that straddle a bucket boundary are stitched in k_loc_emit.
+// Measured dead ends, kept out: a bitonic network (60+ barrier-separated stages at one or two
+// waves per SIMD: ~1 us of dependent issue latency each), full O(n^2) ranking of a bucket
+// (VALU-bound: 7+ us even when perfectly balanced), an 8-pass LSD radix sort (18 launches).
+// The result is the fully sorted pair list (ties by position), i.e. bit-identical to the
+// reference's outputs.  Everything is deterministic.
 #ifndef DFH_LOCALIZE_HIP_
 #define DFH_LOCALIZE_HIP_
 #include "dfh_internal.h"
 
 namespace dfh {
 
-constexpr int SS_OVERSAMPLE = 8;      // samples per bucket
-constexpr int SS_MAX_BUCKETS = 1024;   // => the sample sort serves batches up to 524 k pairs
-constexpr int SS_AVG_BUCKET = 512;    // target pairs per bucket
-constexpr int SS_LDS_CAP = 2048;      // pairs a bucket may hold to be sorted in LDS (4x the mean)
-constexpr int SS_TILE = 4096;         // pairs per block in count / scatter
-constexpr int SS_TILE_THREADS = 1024;
-constexpr int SS_PER_THREAD = SS_TILE / SS_TILE_THREADS;
-constexpr int SS_SORT_THREADS = 512;
-constexpr int SS_SCAN_BUCKETS = 64;   // buckets per block in k_ss_scan
+constexpr int LOC_OVERSAMPLE = 8;      // bootstrap: samples per bucket
+constexpr int LOC_MAX_BUCKETS = 1024;
+constexpr int LOC_AVG_BUCKET = 384;    // target pairs per bucket
+constexpr int LOC_MIN_AVG = 48;        // stored splitters are reused while N / P stays in [MIN, MAX]
+constexpr int LOC_MAX_AVG = 700;
+constexpr int LOC_LDS_CAP = 1024;      // pairs a bucket may hold to be sorted in LDS
+constexpr int LOC_TILE = 2048;         // pairs per block in count / scatter
+constexpr int LOC_TILE_THREADS = 1024;
+constexpr int LOC_PER_THREAD = LOC_TILE / LOC_TILE_THREADS;
+constexpr int LOC_SORT_THREADS = 256;
+constexpr int LOC_EMIT_THREADS = 256;
 
-struct SSView {
+struct LocView {
   const uint64_t* raw;    // [N] raw feature ids
   uint32_t n;             // N
   uint64_t max_index;
   int P;                  // buckets
   int ntiles;
   int force_global;       // tests: sort every bucket through the global-memory path
-  uint64_t* smp_key;      // [P * SS_OVERSAMPLE] jittered samples of the composite (key, pos)
+  // bootstrap
+  uint64_t* smp_key;      // [P * LOC_OVERSAMPLE] jittered samples of the composite (key, pos)
   uint32_t* smp_pos;
-  uint32_t* smp_rank;     // [P * SS_OVERSAMPLE] sorted position of every sample
-  uint64_t* spl_key;      // [P] splitters (bucket b holds composites in [spl[b-1], spl[b]) )
+  uint32_t* smp_rank;     // sorted position of every sample
+  // persistent per batch object
+  uint64_t* spl_key;      // [P - 1] splitters: bucket b holds composites in [spl[b-1], spl[b])
   uint32_t* spl_pos;
-  uint32_t* packed;       // [N] bucket << 16 | rank-in-(tile,bucket)
-  uint32_t* hist;         // [ntiles * P]
+  // per call
+  uint32_t* packed;       // [N] bucket << 16 | rank-in-(tile, bucket)
   uint32_t* run_off;      // [ntiles * P] offset of every (tile, bucket) run inside its bucket
-  uint32_t* btotal;       // [P] pairs per bucket
+  uint32_t* btotal;       // [P] pairs per bucket; zero between calls (k_loc_sort resets it)
   uint32_t* bstart;       // [P + 1]
   uint64_t* bkeys;        // [N] bucket-major keys (unsorted inside a bucket)
   uint32_t* bpos;         // [N]
   uint64_t* skeys;        // [N] sorted keys
   uint32_t* spos;         // [N] sorted positions
-  uint32_t* luid;         // [N] 1-based unique rank inside the bucket
-  uint32_t* head;         // [N] run head inside the bucket
-  uint64_t* first_key;    // [P] bucket meta
+  uint64_t* first_key;    // [P] bucket summaries
   uint64_t* last_key;
-  uint32_t* nheads;
-  uint32_t* ubase;        // [P] unique keys before the bucket
-  uint32_t* cont;         // [P] bucket's first key continues the previous bucket's last key
+  uint32_t* nheads;       // [P] runs of equal keys inside the bucket
+  uint32_t* lh;           // [P] local index of the bucket's last run head (0: one run only)
+};
+
+// long-segment lists for k_backward_all, one slot range per list bucket (dfh_internal.h: SegLists)
+struct SegListsOut {
+  uint32_t* nb;
+  uint32_t* mid_cnt;
+  uint32_t* mid_off;
+  uint32_t* mid_ent;
+  uint32_t* hot_cnt;
+  uint32_t* hot_off;
+  uint32_t* hot_ent;
 };
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
@@ -114,44 +135,63 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t val, uint32_t*
   return woff + s - val;
 }
 
+// the same for a running maximum: returns max over the threads BEFORE this one (0 if none)
+template <int NWAVES>
+__device__ __forceinline__ uint32_t block_exclusive_max(uint32_t val, uint32_t* wmax /* [NWAVES] shared */, uint32_t* total) {
+  uint32_t s = val;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(s, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) s = max(s, y);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6] = s;
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) {
+    const uint32_t x = wmax[w];
+    if (w < (int)(threadIdx.x >> 6)) before = max(before, x);
+    tot = max(tot, x);
+  }
+  if (total) *total = tot;
+  // exclusive inside the wave: the inclusive value of the previous lane
+  uint32_t prev = __shfl_up(s, 1, 64);
+  if ((threadIdx.x & 63) == 0) prev = 0;
+  return max(before, prev);
+}
+
+// ---------------------------------------------------------------------------------------
+// bootstrap of the splitters (first call on a batch object / new size class)
+// ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ss_sample_pos(uint32_t t, uint32_t stride, uint32_t n) {
   const uint32_t j = (uint32_t)(splitmix64(t) >> 33) % stride;
   return min(t * stride + j, n - 1);
 }
 
-// ---- sampling: the S = SS_OVERSAMPLE * P jittered samples of the composite (key, pos);
-// side job, independent of the sort until k_ss_emit: rowid[pos] = row of nnz position pos
-__global__ void __launch_bounds__(256) k_ss_sample(SSView v, uint32_t nrows, const uint32_t* __restrict__ offset,
-                                                   uint32_t* __restrict__ rowid) {
-  const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
-  // jittered stratified sampling: sample t is a hashed position inside its own stratum
-  // [t*stride, (t+1)*stride) (distinct by construction).  A plain stride aliases with the
-  // row structure — 39 features per row, stride 63: only 13 of the 39 slots were ever
-  // sampled and whole slots collapsed into one bucket.
+// the S = LOC_OVERSAMPLE * P jittered samples of the composite (key, pos).  Jittered stratified
+// sampling: sample t is a hashed position inside its own stratum [t*stride, (t+1)*stride)
+// (distinct by construction).  A plain stride aliases with the row structure — 39 features per
+// row, stride 63: only 13 of the 39 slots were ever sampled and whole slots collapsed into one bucket.
+__global__ void __launch_bounds__(256) k_ss_sample(LocView v) {
+  const uint32_t S = (uint32_t)v.P * LOC_OVERSAMPLE;
   const uint32_t stride = max(1u, v.n / S);
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-  for (uint32_t t = tid; t < S; t += nthreads) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
     const uint32_t i = ss_sample_pos(t, stride, v.n);
     v.smp_key[t] = make_key(v.raw[i], v.max_index);
     v.smp_pos[t] = i;
     v.smp_rank[t] = 0;
   }
-  for (uint32_t r = tid; r < nrows; r += nthreads) {
-    const uint32_t e = offset[r + 1];
-    for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
-  }
 }
 
-// ---- ranking of the samples, tiled over the whole chip: block (i, j) compares 256 "row"
-// samples (one per thread, in registers) with 256 "column" samples (LDS broadcast reads) and
-// adds the partial ranks with one atomic per sample.  The composites are distinct, so the
-// final rank of a sample is its sorted position; every SS_OVERSAMPLE-th becomes a splitter
-// (picked up by k_ss_count).  (One block sorting the samples costs 50-60 us: a single CU is
-// issue-bound on it.)
-__global__ void __launch_bounds__(256) k_ss_rank(SSView v) {
+// ranking of the samples, tiled over the whole chip: block (i, j) compares 256 "row" samples (one
+// per thread, in registers) with 256 "column" samples (LDS broadcast reads) and adds the partial
+// ranks with one atomic per sample.  The composites are distinct (ties by sample index), so the
+// final rank of a sample is its sorted position.
+__global__ void __launch_bounds__(256) k_ss_rank(LocView v) {
   __shared__ uint64_t ck[256];
   __shared__ uint32_t cp[256];
-  const uint32_t S = (uint32_t)v.P * SS_OVERSAMPLE;
+  const uint32_t S = (uint32_t)v.P * LOC_OVERSAMPLE;
   const uint32_t ntile = (S + 255) / 256;
   const uint32_t ti = blockIdx.x / ntile, tj = blockIdx.x % ntile;
   const uint32_t col = tj * 256 + threadIdx.x;
@@ -164,160 +204,120 @@ __global__ void __launch_bounds__(256) k_ss_rank(SSView v) {
   const uint32_t lim = min(256u, S - tj * 256);
   uint32_t rank = 0;
 #pragma unroll 8
-  for (uint32_t j = 0; j < lim; ++j) rank += comp_less(ck[j], cp[j], mk, mp) ? 1u : 0u;
+  for (uint32_t j = 0; j < lim; ++j) {
+    // small batches sample the same position more than once: equal composites are ordered by sample index
+    const bool less = comp_less(ck[j], cp[j], mk, mp) || (ck[j] == mk && cp[j] == mp && tj * 256 + j < row);
+    rank += less ? 1u : 0u;
+  }
   if (row < S && rank) atomicAdd(&v.smp_rank[row], rank);
 }
 
-// ---- count: bucket + rank-in-(tile,bucket) of every pair; per-tile histogram
-__global__ void __launch_bounds__(SS_TILE_THREADS) k_ss_count(SSView v) {
-  __shared__ uint64_t sk[SS_MAX_BUCKETS];
-  __shared__ uint32_t sp[SS_MAX_BUCKETS];
-  __shared__ uint32_t hist[SS_MAX_BUCKETS];
-  const int P = v.P;
-  for (int b = threadIdx.x; b < P; b += blockDim.x) hist[b] = 0;
-  // splitters: sample with rank r = m * SS_OVERSAMPLE (m >= 1) is splitter m-1; spl[P-1] = +inf
-  {
-    const uint32_t S = (uint32_t)P * SS_OVERSAMPLE;
-    for (uint32_t t0 = threadIdx.x; t0 < S; t0 += blockDim.x * 8) {  // 8 independent rank loads in flight
-      uint32_t r[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t t = t0 + u * blockDim.x;
-        r[u] = t < S ? v.smp_rank[t] : 1u;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t t = t0 + u * blockDim.x;
-        if (r[u] > 0 && r[u] % SS_OVERSAMPLE == 0) {
-          sk[r[u] / SS_OVERSAMPLE - 1] = v.smp_key[t];
-          sp[r[u] / SS_OVERSAMPLE - 1] = v.smp_pos[t];
-        }
-      }
-    }
-    if (threadIdx.x == 0) {
-      sk[P - 1] = ~0ULL;
-      sp[P - 1] = ~0u;
+// sample with rank r = m * LOC_OVERSAMPLE (1 <= m <= P-1) is splitter m-1
+__global__ void __launch_bounds__(256) k_loc_splitters(LocView v) {
+  const uint32_t S = (uint32_t)v.P * LOC_OVERSAMPLE;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
+    const uint32_t r = v.smp_rank[t];
+    if (r > 0 && r % LOC_OVERSAMPLE == 0) {
+      v.spl_key[r / LOC_OVERSAMPLE - 1] = v.smp_key[t];
+      v.spl_pos[r / LOC_OVERSAMPLE - 1] = v.smp_pos[t];
     }
   }
-  const uint32_t base = blockIdx.x * SS_TILE;
-  uint64_t key[SS_PER_THREAD];
+}
+
+// ---------------------------------------------------------------------------------------
+// count: bucket + rank-in-(tile, bucket) of every pair; the tile's runs reserve their places
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
+                                                                uint32_t* __restrict__ rowid) {
+  __shared__ uint64_t sk[LOC_MAX_BUCKETS];
+  __shared__ uint32_t sp[LOC_MAX_BUCKETS];
+  __shared__ uint32_t hist[LOC_MAX_BUCKETS];
+  const int P = v.P;
+  for (int b = threadIdx.x; b < P; b += blockDim.x) {
+    hist[b] = 0;
+    sk[b] = b < P - 1 ? v.spl_key[b] : ~0ULL;  // spl[P-1] = +inf
+    sp[b] = b < P - 1 ? v.spl_pos[b] : ~0u;
+  }
+  const uint32_t base = blockIdx.x * LOC_TILE;
+  uint64_t key[LOC_PER_THREAD];
 #pragma unroll
-  for (int e = 0; e < SS_PER_THREAD; ++e) {  // independent loads first
-    const uint32_t i = base + e * SS_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {  // independent loads first
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
     key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
   }
+  // side job, independent of the sort until k_loc_emit: rowid[pos] = row of nnz position pos,
+  // this block's share of the rows
+  {
+    const uint32_t rpb = (nrows + gridDim.x - 1) / gridDim.x;
+    const uint32_t r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+      const uint32_t e = offset[r + 1];
+      for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
+    }
+  }
   __syncthreads();
-  // SS_PER_THREAD interleaved binary searches: first b with (key, i) < spl[b]  (spl[P-1] = +inf)
-  int lo[SS_PER_THREAD], hi[SS_PER_THREAD];
+  // LOC_PER_THREAD interleaved binary searches: first b with (key, i) < spl[b]
+  int lo[LOC_PER_THREAD], hi[LOC_PER_THREAD];
 #pragma unroll
-  for (int e = 0; e < SS_PER_THREAD; ++e) { lo[e] = 0; hi[e] = P - 1; }
+  for (int e = 0; e < LOC_PER_THREAD; ++e) { lo[e] = 0; hi[e] = P - 1; }
   for (int step = P; step > 1; step = (step + 1) >> 1) {  // ceil(log2 P) rounds
 #pragma unroll
-    for (int e = 0; e < SS_PER_THREAD; ++e) {
+    for (int e = 0; e < LOC_PER_THREAD; ++e) {
       if (lo[e] < hi[e]) {
-        const uint32_t i = base + e * SS_TILE_THREADS + threadIdx.x;
+        const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
         const int mid = (lo[e] + hi[e]) >> 1;
         if (comp_less(key[e], i, sk[mid], sp[mid])) hi[e] = mid; else lo[e] = mid + 1;
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < SS_PER_THREAD; ++e) {
-    const uint32_t i = base + e * SS_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
     if (i < v.n) {
       const uint32_t r = atomicAdd(&hist[lo[e]], 1u);
       v.packed[i] = ((uint32_t)lo[e] << 16) | r;
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < P; b += blockDim.x) v.hist[blockIdx.x * P + b] = hist[b];
-}
-
-// ---- scan: run_off[tile][b] = pairs of bucket b in earlier tiles; btotal[b].
-// One block per SS_SCAN_BUCKETS buckets; 64 lanes = 64 consecutive buckets
-// (coalesced), the block's 4 waves split the tiles and combine through LDS.
-__global__ void __launch_bounds__(256) k_ss_scan(SSView v) {
-  __shared__ uint32_t wtot[4][SS_SCAN_BUCKETS];
-  const int P = v.P;
-  const int b = blockIdx.x * SS_SCAN_BUCKETS + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  const int per = (v.ntiles + 3) / 4;
-  const int t_beg = w * per, t_end = min(v.ntiles, t_beg + per);
-  const uint32_t* __restrict__ hist = v.hist;
-  uint32_t* __restrict__ run_off = v.run_off;
-  uint32_t sum = 0;
-  if (b < P) {
-    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
-      uint32_t h[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? hist[(t0 + q) * P + b] : 0u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sum += h[q];
-    }
-  }
-  wtot[w][threadIdx.x & 63] = sum;
-  __syncthreads();
-  uint32_t run = 0;
-  for (int q = 0; q < w; ++q) run += wtot[q][threadIdx.x & 63];
-  if (b < P) {
-    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
-      uint32_t h[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? hist[(t0 + q) * P + b] : 0u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (t0 + q < t_end) run_off[(t0 + q) * P + b] = run;
-        run += h[q];
-      }
-    }
-    if (w == 3) v.btotal[b] = run;
+  // one global atomic per non-empty (tile, bucket) run: its offset inside the bucket.  The order in
+  // which the tiles arrive differs from run to run; the bucket is sorted afterwards, so the
+  // result does not.
+  for (int b = threadIdx.x; b < P; b += blockDim.x) {
+    const uint32_t h = hist[b];
+    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[b], h) : 0u;
   }
 }
 
-// ---- scatter into bucket-major order; every block derives the bucket starts
-// from the totals (block 0 publishes them)
-__global__ void __launch_bounds__(SS_TILE_THREADS) k_ss_scatter(SSView v) {
-  __shared__ uint32_t off[SS_MAX_BUCKETS];
-  __shared__ uint32_t wsum[SS_TILE_THREADS / 64];
+// ---- scatter into bucket-major order; every block derives the bucket starts from the totals
+// (block 0 publishes them)
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
+  __shared__ uint32_t off[LOC_MAX_BUCKETS];
+  __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
+  static_assert(LOC_MAX_BUCKETS == LOC_TILE_THREADS, "one bucket per thread in the scan");
   const int P = v.P;
-  // exclusive scan of btotal[0..P): BPT consecutive buckets per thread
-  {
-    constexpr int BPT = SS_MAX_BUCKETS / SS_TILE_THREADS;
-    const int b0 = threadIdx.x * BPT;
-    uint32_t tt[BPT];
-    uint32_t sum = 0;
+  const uint32_t base = blockIdx.x * LOC_TILE;
+  uint64_t raw[LOC_PER_THREAD];
+  uint32_t pk[LOC_PER_THREAD];
 #pragma unroll
-    for (int q = 0; q < BPT; ++q) {
-      tt[q] = b0 + q < P ? v.btotal[b0 + q] : 0u;
-      sum += tt[q];
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan<SS_TILE_THREADS / 64>(sum, wsum, &total);
-#pragma unroll
-    for (int q = 0; q < BPT; ++q) {
-      if (b0 + q < P) {
-        off[b0 + q] = ex;
-        if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
-      }
-      ex += tt[q];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
-  }
-  const uint32_t base = blockIdx.x * SS_TILE;
-  uint64_t raw[SS_PER_THREAD];
-  uint32_t pk[SS_PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < SS_PER_THREAD; ++e) {
-    const uint32_t i = base + e * SS_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
     raw[e] = i < v.n ? v.raw[i] : 0;
     pk[e] = i < v.n ? v.packed[i] : 0;
   }
-  __syncthreads();
-  for (int b = threadIdx.x; b < P; b += blockDim.x) off[b] += v.run_off[blockIdx.x * P + b];
+  const int b0 = threadIdx.x;
+  const uint32_t tot = b0 < P ? v.btotal[b0] : 0u;
+  const uint32_t ro = b0 < P ? v.run_off[blockIdx.x * P + b0] : 0u;
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(tot, wsum, &total);
+  if (b0 < P) {
+    off[b0] = ex + ro;
+    if (blockIdx.x == 0) v.bstart[b0] = ex;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < SS_PER_THREAD; ++e) {
-    const uint32_t i = base + e * SS_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
     if (i < v.n) {
       const uint32_t dst = off[pk[e] >> 16] + (pk[e] & 0xFFFFu);
       v.bkeys[dst] = make_key(raw[e], v.max_index);
@@ -326,19 +326,21 @@ __global__ void __launch_bounds__(SS_TILE_THREADS) k_ss_scatter(SSView v) {
   }
 }
 
-// ---- sort one bucket; heads and 1-based local unique ranks
-__global__ void __launch_bounds__(SS_SORT_THREADS) k_ss_sort(SSView v) {
-  __shared__ uint64_t ak[SS_LDS_CAP];
-  __shared__ uint32_t ap[SS_LDS_CAP];
-  __shared__ uint64_t bk[SS_LDS_CAP];
-  __shared__ uint32_t bp[SS_LDS_CAP];
-  __shared__ uint32_t wsum[SS_SORT_THREADS / 64];
+// ---- sort one bucket; summary of its runs of equal keys
+__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
+  __shared__ uint64_t ak[LOC_LDS_CAP];
+  __shared__ uint32_t ap[LOC_LDS_CAP];
+  __shared__ uint64_t bk[LOC_LDS_CAP];
+  __shared__ uint32_t bp[LOC_LDS_CAP];
+  __shared__ uint32_t red[3][LOC_SORT_THREADS / 64];
   const uint32_t b = blockIdx.x;
   const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
   const uint32_t n = end - beg;
+  if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_scatter: ready for the next call
   if (n == 0) {
     if (threadIdx.x == 0) {
       v.nheads[b] = 0;
+      v.lh[b] = 0;
       v.first_key[b] = 0;
       v.last_key[b] = 0;
     }
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(SS_SORT_THREADS) k_ss_sort(SSView v) {
   }
   const uint64_t* gk = v.bkeys + beg;
   const uint32_t* gp = v.bpos + beg;
-  const bool in_lds = n <= SS_LDS_CAP && !v.force_global;
+  const bool in_lds = n <= LOC_LDS_CAP && !v.force_global;
   uint64_t* sk = bk;  // where the sorted bucket ends up (LDS path)
   uint32_t* sp = bp;
   if (in_lds) {
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(SS_SORT_THREADS) k_ss_sort(SSView v) {
     __syncthreads();
     // runs of 64: rank every element inside its 64-chunk (LDS broadcast reads, no barriers)
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += SS_SORT_THREADS) {
+    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += LOC_SORT_THREADS) {
       const uint32_t idx = c0 + lane;
       const bool valid = idx < n;
       const uint64_t mk = valid ? ak[idx] : ~0ULL;
@@ -400,15 +402,15 @@ __global__ void __launch_bounds__(SS_SORT_THREADS) k_ss_sort(SSView v) {
       v.spos[beg + t] = sp[t];
     }
   } else {
-    // oversize bucket (an outlier of the sampling; kept for correctness and bounded
-    // at n log n): the same run-ranking + merge rounds on the global arrays,
-    // ping-ponging between the bucket-major and the sorted buffers
+    // oversize bucket (stale or unlucky splitters; kept for correctness and bounded at n log n):
+    // the same run-ranking + merge rounds on the global arrays, ping-ponging between the
+    // bucket-major and the sorted buffers
     uint64_t* xk = v.bkeys + beg;
     uint32_t* xp = v.bpos + beg;
     uint64_t* yk = v.skeys + beg;
     uint32_t* yp = v.spos + beg;
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += SS_SORT_THREADS) {
+    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += LOC_SORT_THREADS) {
       const uint32_t idx = c0 + lane;
       const bool valid = idx < n;
       const uint64_t mk = valid ? xk[idx] : ~0ULL;
@@ -453,75 +455,151 @@ __global__ void __launch_bounds__(SS_SORT_THREADS) k_ss_sort(SSView v) {
     }
     __syncthreads();
   }
-  // heads + inclusive scan of heads over the bucket
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += blockDim.x) {
-    const uint32_t t = base + threadIdx.x;
-    uint32_t h = 0;
-    if (t < n) {
-      const uint64_t k = in_lds ? sk[t] : v.skeys[beg + t];
-      h = (t == 0 || k != (in_lds ? sk[t - 1] : v.skeys[beg + t - 1])) ? 1u : 0u;
+  // bucket summary: number of runs of equal keys, local index of the last run head
+  uint32_t cnt = 0, last = 0;
+  for (uint32_t t = 1 + threadIdx.x; t < n; t += blockDim.x) {
+    const uint64_t k1 = in_lds ? sk[t] : v.skeys[beg + t];
+    const uint64_t k0 = in_lds ? sk[t - 1] : v.skeys[beg + t - 1];
+    if (k1 != k0) {
+      ++cnt;
+      last = t;  // ascending t per thread
     }
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<SS_SORT_THREADS / 64>(h, wsum, &total);
-    if (t < n) {
-      v.head[beg + t] = h;
-      v.luid[beg + t] = carry + ex + h;
-    }
-    carry += total;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    last = max(last, (uint32_t)__shfl_xor(last, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = cnt;
+    red[1][threadIdx.x >> 6] = last;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    v.nheads[b] = carry;
+    uint32_t c = 1, l = 0;  // position 0 opens the first run
+    for (int w = 0; w < LOC_SORT_THREADS / 64; ++w) {
+      c += red[0][w];
+      l = max(l, red[1][w]);
+    }
+    v.nheads[b] = c;
+    v.lh[b] = l;
     v.first_key[b] = in_lds ? sk[0] : v.skeys[beg];
     v.last_key[b] = in_lds ? sk[n - 1] : v.skeys[beg + n - 1];
   }
 }
 
-// ---- emit: one block per bucket stitches itself to its predecessors (unique
-// keys before the bucket; does its first key continue the previous bucket's
-// last key?) and writes the Localizer's outputs
-__global__ void __launch_bounds__(256) k_ss_emit(SSView v, const uint32_t* __restrict__ rowid,
-                                                 const float* __restrict__ value, uint64_t* __restrict__ feaids,
-                                                 uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
-                                                 uint32_t* __restrict__ s_row, float* __restrict__ s_val,
-                                                 uint32_t* __restrict__ d_U) {
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t sh_cont;
+// ---- emit: one block per bucket stitches itself to its predecessors (unique keys before the
+// bucket; does its first key continue the previous bucket's last key; where did the run that is
+// open at the bucket's start begin) and writes the Localizer's outputs.
+//
+// Segment lengths — needed to sort the keys into the short / mid / hot roles of
+// k_backward_all — are known where a segment ENDS: the head of the next run (or the end of the
+// minibatch) closes it, and the closing thread knows the start from the running maximum of head
+// positions.  Every bucket lists the long segments it closes in its own slot range (at most
+// n_b / 9 + 2 mid and n_b / 257 + 2 hot ones: no atomics between blocks, no compaction pass).
+__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const uint32_t* __restrict__ rowid,
+                                                                const float* __restrict__ value, uint64_t* __restrict__ feaids,
+                                                                uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
+                                                                uint32_t* __restrict__ s_row, float* __restrict__ s_val,
+                                                                uint32_t* __restrict__ d_U, SegListsOut sl) {
+  constexpr int NW = LOC_EMIT_THREADS / 64;
+  __shared__ uint32_t wsum[NW], wmax[NW];
+  __shared__ uint32_t sh_cont, n_mid, n_hot;
   const uint32_t b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0) { d_U[SEG_N_WORD] = 0; d_U[SEG_N_WORD + 1] = 0; }  // for k_seg_lists
+  const uint32_t P = (uint32_t)v.P;
   const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
-  if (beg == end) return;
-  // uniq(b') = nheads[b'] - cont[b'] summed over b' < b; cont[b'] compares first_key[b'] with the
-  // last key of the previous NON-EMPTY bucket
-  uint32_t part = 0;
+  const uint32_t n = end - beg;
+  const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b;
+  if (threadIdx.x == 0) {
+    n_mid = 0;
+    n_hot = 0;
+    if (b == 0) *sl.nb = P;
+    if (n == 0) {
+      sl.mid_cnt[b] = 0;
+      sl.hot_cnt[b] = 0;
+    }
+  }
+  if (n == 0) return;
+  // over the buckets q < b: unique keys (nheads[q] - cont[q], cont[q]: first_key[q] equals the last key of the
+  // previous NON-EMPTY bucket) and the position of the last run head that opens a new key
+  uint32_t part = 0, carry1 = 0;  // carry1: position + 1 (0: none)
   for (uint32_t q0 = threadIdx.x; q0 <= b; q0 += blockDim.x) {
-    const uint32_t nq = v.bstart[q0 + 1] - v.bstart[q0];
+    const uint32_t bq = v.bstart[q0], nq = v.bstart[q0 + 1] - bq;
     if (nq == 0) continue;
     int p = (int)q0 - 1;
     while (p >= 0 && v.bstart[p + 1] == v.bstart[p]) --p;
     const uint32_t c = (p >= 0 && v.first_key[q0] == v.last_key[p]) ? 1u : 0u;
-    if (q0 == b) sh_cont = c; else part += v.nheads[q0] - c;
+    if (q0 == b) {
+      sh_cont = c;
+    } else {
+      part += v.nheads[q0] - c;
+      const uint32_t l = v.lh[q0];
+      if (l > 0) carry1 = max(carry1, bq + l + 1);
+      else if (!c) carry1 = max(carry1, bq + 1);
+    }
   }
-  uint32_t total;
-  block_exclusive_scan<4>(part, wsum, &total);
+  uint32_t ubase, carry_all;
+  block_exclusive_scan<NW>(part, wsum, &ubase);
+  block_exclusive_max<NW>(carry1, wmax, &carry_all);
   __syncthreads();
-  const uint32_t c = sh_cont;
-  const uint32_t ub = total;
-  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const uint32_t uid = ub + v.luid[i] - 1 - c;
-    const bool head = v.head[i] && !(c && i == beg);
-    const uint32_t pos = v.spos[i];
-    if (head) {
-      feaids[uid] = v.skeys[i];
-      col_ptr[uid] = i;
+  const uint32_t cont = sh_cont;
+  uint32_t run_heads = 0, run_max1 = carry_all;
+  for (uint32_t base = 0; base < n; base += blockDim.x) {
+    const uint32_t t = base + threadIdx.x;
+    const uint32_t i = beg + t;
+    const bool valid = t < n;
+    uint64_t key = 0;
+    uint32_t pos = 0;
+    bool head = false;
+    if (valid) {
+      key = v.skeys[i];
+      pos = v.spos[i];
+      head = t == 0 ? !cont : key != v.skeys[i - 1];
     }
-    index[pos] = uid;  // RemapIndex, localizer.cc:63-77
-    s_row[i] = rowid[pos];
-    if (value) s_val[i] = value[pos];
-    if (i == v.n - 1) {
-      *d_U = uid + 1;
-      col_ptr[uid + 1] = v.n;
+    uint32_t nh, mx;
+    const uint32_t ex = block_exclusive_scan<NW>(head ? 1u : 0u, wsum, &nh);
+    const uint32_t pm = block_exclusive_max<NW>(head ? i + 1 : 0u, wmax, &mx);
+    if (valid) {
+      const uint32_t incl = run_heads + ex + (head ? 1u : 0u);
+      const uint32_t uid = ubase + incl - 1;          // cont && no head yet: the previous bucket's last id
+      const uint32_t prev1 = max(run_max1, pm);       // start + 1 of the run open just before this element
+      if (head) {
+        feaids[uid] = key;
+        col_ptr[uid] = i;
+        if (prev1) {  // closes segment uid - 1 = [prev1 - 1, i)
+          const uint32_t len = i - (prev1 - 1);
+          if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(&n_hot, 1u)] = uid - 1;
+          else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(&n_mid, 1u)] = uid - 1;
+        }
+      }
+      index[pos] = uid;  // RemapIndex, localizer.cc:63-77
+      s_row[i] = rowid[pos];
+      if (value) s_val[i] = value[pos];
+      if (i == v.n - 1) {  // the end of the minibatch closes the last segment
+        *d_U = uid + 1;
+        col_ptr[uid + 1] = v.n;
+        const uint32_t len = v.n - (head ? i : prev1 - 1);
+        if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(&n_hot, 1u)] = uid;
+        else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(&n_mid, 1u)] = uid;
+      }
+      // the splitters of the next call: the exact P-quantiles of this sorted order
+      if (P > 1) {
+        const uint64_t m = ((uint64_t)i * P + v.n - 1) / v.n;  // smallest m with m * n / P >= i
+        if (m >= 1 && m <= P - 1 && (m * v.n) / P == i) {
+          v.spl_key[m - 1] = key;
+          v.spl_pos[m - 1] = pos;
+        }
+      }
     }
+    run_heads += nh;
+    run_max1 = max(run_max1, mx);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sl.mid_cnt[b] = n_mid;
+    sl.mid_off[b] = moff;
+    sl.hot_cnt[b] = n_hot;
+    sl.hot_off[b] = hoff;
   }
 }
 

@@ -199,16 +199,21 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
  * index per nnz — bit-exact with the reference — plus the key-ordered view the
  * backward pass's segmented sum walks. */
 int dfh_localize(dfh_batch* b, uint64_t max_index);
-/* tuning / test switches: "force_radix_sort" = 1 makes dfh_localize take its
+/* dfh_localize is a pure function of the minibatch, but a batch object remembers the exact quantiles
+ * of the last minibatch it localized and partitions the next one with them (consecutive minibatches
+ * of one stream share their key distribution); they affect speed only, never the result.
+ * tuning / test switches: "force_radix_sort" = 1 makes dfh_localize take its
  * large-batch path (library LSD radix sort) whatever the batch size;
  * "force_sort_fallback" = 1 sorts every bucket through the oversize-bucket path;
+ * "reset_splitters" = 1 forgets the stored quantiles (the next call samples again);
  * "compute_auc" = 1 makes dfh_sgd_step accumulate BinClassMetric::AUC (x nrows) of every
  * batch into dfh_progress.auc, as src/sgd/sgd_learner.cc:153-155 does */
 int dfh_batch_set_option(dfh_batch* b, const char* name, int value);
 
 /* resolve the batch's unique keys to table rows ahead of dfh_sgd_step (inserting
- * unseen keys as zero rows, src/sgd/sgd_updater.cc:44); runs with the preparation
- * work.  Optional: dfh_sgd_step does it itself when this was not called. */
+ * unseen keys as zero rows, src/sgd/sgd_updater.cc:44): the random probes of the key index run
+ * with the preparation work, and the step's own pass over the keys (count push, current w) finds
+ * the rows known.  Optional: dfh_sgd_step probes itself when this was not called. */
 int dfh_batch_lookup(dfh_table* t, dfh_batch* b);
 
 /* already-localized batch from the host (what SGDLearner hands its batch thread,

@@ -173,6 +173,49 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     bt.close()
 
 
+def test_device_localizer_stored_splitters(capi, ctx, oracle):
+    """dfh_localize keeps the exact quantiles of one minibatch as the splitters of the next
+    (dfh_localize.hip): a stream of minibatches through ONE batch object must stay bit-exact when
+    the splitters fit (same distribution), when they are stale (another distribution: one bucket
+    swallows nearly everything and takes the global-memory sort), when the size class changes
+    (bootstrap from a sample again) and when the same minibatch comes twice"""
+    from difacto_amd import synth
+    rng = np.random.default_rng(5)
+    gen = synth.CriteoSynth(total_ids=300000, seed=9)
+
+    def uniform(nr, s):
+        return random_batch(rng, nr, 2 ** 64 - 1, s, binary=True, empty_rows=False)
+
+    def jammed(nr, s):  # 97 % of the ids in one narrow key range
+        idx = rng.integers(0, 2 ** 64 - 1, size=nr * s, dtype=np.uint64)
+        jam = rng.random(nr * s) < 0.97
+        idx[jam] = rng.integers(0, 50000, size=int(jam.sum()), dtype=np.uint64) << np.uint64(44)
+        return dict(offset=(np.arange(nr + 1) * s).astype(np.uint64), index=idx, value=None, label=np.ones(nr, np.float32))
+
+    def same_key(nr, s):
+        return dict(offset=(np.arange(nr + 1) * s).astype(np.uint64), index=np.full(nr * s, 4242, np.uint64),
+                    value=rng.normal(size=nr * s).astype(np.float32), label=np.ones(nr, np.float32))
+
+    c1 = gen.batch(2000)
+    stream = [c1, gen.batch(2000), gen.batch(2000), c1, jammed(2000, 39), gen.batch(2000), uniform(2000, 39), same_key(2000, 39),
+              gen.batch(2000), gen.batch(150), gen.batch(150), uniform(40, 3), gen.batch(2000), gen.batch(1990)]
+    bt = capi.Batch(ctx, 2000, 2000 * 39)
+    for n, b in enumerate(stream):
+        bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+        bt.localize()
+        got = bt.get_localized()
+        want = oracle.localize(b["offset"], b["index"])
+        assert got["U"] == want["U"], n
+        assert np.array_equal(got["feaids"], want["feaids"]), n
+        assert np.array_equal(got["feacnt"], want["feacnt"]), n
+        assert np.array_equal(got["index"], want["index"]), n
+    bt.set_option("reset_splitters", 1)
+    bt.load_host(c1["offset"], c1["index"], c1["value"], c1["label"])
+    bt.localize()
+    assert np.array_equal(bt.get_localized()["index"], oracle.localize(c1["offset"], c1["index"])["index"])
+    bt.close()
+
+
 def test_golden_localizer(capi, ctx, rcv1):
     """tests/cpp/localizer_test.cc:12-49 on the device localizer"""
     for mx, want in ((U64MAX, 65111856), (1000, 478817)):
