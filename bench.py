@@ -60,10 +60,13 @@ def parse_args():
     ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-pipeline", action="store_true", help="prepare and train on one stream")
-    ap.add_argument("--prep-streams", type=int, default=2,
+    ap.add_argument("--prep-streams", type=int, default=1,
                     help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
                          "keeps 2 in flight)")
-    ap.add_argument("--prep-lookup", action="store_true", help="resolve key->row on the preparation stream too")
+    ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
+                    help="probe the key index inside the step instead of on the preparation stream")
+    ap.add_argument("--no-relocalize", action="store_true",
+                    help="diagnostic (NOT the metric): localize every batch object once and time lookup + forward + backward alone")
     ap.add_argument("--uniform-ranges", action="store_true",
                     help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
     ap.add_argument("--exchange", choices=["sync", "overlap"], default="sync",
@@ -293,7 +296,8 @@ def main():
             b.lookup(table)
 
     def step(i):
-        prep(i + ahead)
+        if not args.no_relocalize or i + ahead < len(bts):
+            prep(i + ahead)
         bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=True)
 
     for i in range(ahead):
@@ -414,7 +418,8 @@ def main():
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,
-        "value_note": "median of `repetitions` timed regions of `steps` steps each",
+        "value_note": "median of `repetitions` timed regions of `steps` steps each"
+                      + (" — DIAGNOSTIC RUN without the Localizer in the step (--no-relocalize), not the metric" if args.no_relocalize else ""),
         "roofline": roofline,
         "roofline_backward": roofline_bwd,
         "roofline_step": dict(bound="hbm", bytes_per_example=r_step, achieved=ex_per_s * r_step / 1e9, peak=HBM_PEAK_GBPS,

@@ -129,8 +129,9 @@ struct dfh_batch {
   uint32_t* d_U = nullptr;
   // step workspace
   // long-segment key lists for the backward pass (SegLists): list buckets = sort buckets
-  uint32_t *d_mid_cnt = nullptr, *d_mid_off = nullptr, *d_mid_ent = nullptr, *d_hot_cnt = nullptr, *d_hot_off = nullptr,
-           *d_hot_ent = nullptr;
+  uint2 *d_mid = nullptr, *d_hot = nullptr;         // [list buckets] {cnt, off}
+  uint32_t *d_mid_ent = nullptr, *d_hot_ent = nullptr;
+  uint32_t seg_nb = 0;                              // list buckets of the current localized view
   uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
   float *d_pred = nullptr, *d_slope = nullptr, *d_xv = nullptr;
@@ -350,12 +351,9 @@ BatchView batch_view(const dfh_batch* b) {
   v.slope = b->d_slope;
   v.xv = b->d_xv;
   v.prog = b->d_prog;
-  v.seg.nb = b->d_U + SEG_NB_WORD;
-  v.seg.mid_cnt = b->d_mid_cnt;
-  v.seg.mid_off = b->d_mid_off;
+  v.seg.mid = b->d_mid;
   v.seg.mid_ent = b->d_mid_ent;
-  v.seg.hot_cnt = b->d_hot_cnt;
-  v.seg.hot_off = b->d_hot_off;
+  v.seg.hot = b->d_hot;
   v.seg.hot_ent = b->d_hot_ent;
   return v;
 }
@@ -456,7 +454,10 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
   // the long chains start first; surplus blocks find their list exhausted and leave at once
   constexpr size_t NWB = BWD_THREADS / 64;
   const size_t nb_hot = std::max<size_t>(1, std::min<size_t>(b->nnz / (BWD_MID + 1) + 1, 256));
-  const size_t nb_mid = std::max<size_t>(1, std::min<size_t>((b->nnz / (BWD_SMALL + 1)) / NWB + 1, 512));
+#ifndef DFH_BWD_MID_BLOCKS
+#define DFH_BWD_MID_BLOCKS 512
+#endif
+  const size_t nb_mid = std::max<size_t>(1, std::min<size_t>((b->nnz / (BWD_SMALL + 1)) / NWB + 1, DFH_BWD_MID_BLOCKS));
   const size_t small_cap = (size_t)c->bwd_small_blocks;
   const size_t keys_per_block = NWB * (64 / L);
   const size_t nb_small = std::max<size_t>(1, std::min<size_t>((b->nnz + keys_per_block - 1) / keys_per_block, small_cap));
@@ -466,17 +467,17 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
     eb = TimeScope::get(c);
   }
   const dim3 grid((unsigned)(nb_hot + nb_mid + nb_small)), block(BWD_THREADS);
-  const uint32_t nh = (uint32_t)nb_hot, nm = (uint32_t)nb_mid;
+  const uint32_t nh = (uint32_t)nb_hot, nm = (uint32_t)nb_mid, nlist = b->seg_nb;
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
     const bool lean = FUSED && src.urow;
 #define DFH_BWD(LEAN, EXACT)                                                                                          \
   if (ea && eb)                                                                                                       \
     hipExtLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, ea, eb, 0, bv, src, tv, grads, \
-                          gstride, k, kp, need, nh, nm);                                                              \
+                          gstride, k, kp, need, nh, nm, nlist);                                                       \
   else                                                                                                                \
     hipLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, \
-                       need, nh, nm)
+                       need, nh, nm, nlist)
     if (lean && kp == 4 * LL) {
       DFH_BWD(FUSED, true);
     } else if (lean) {
@@ -984,6 +985,15 @@ int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
+
+#ifdef DFH_BWD_TRACE
+// measurement build only (tools/): {role, start, end} of every block of the last k_backward_all launch
+int dfh_debug_bwd_trace(unsigned long long* out, size_t n) {
+  DFH_HIP(hipDeviceSynchronize());
+  DFH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_trace), std::min<size_t>(n, 3 * 8192) * sizeof(unsigned long long)));
+  return DFH_OK;
+}
+#endif
 
 int dfh_table_check(dfh_table* t) {
   DFH_ARG(t, "NULL table");
@@ -1537,10 +1547,8 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   // bucket q of the sample sort may list n_q / 9 + 2 mid and n_q / 257 + 2 hot keys (k_loc_emit)
   DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
   DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
-  DFH_ALLOC(b->d_mid_cnt, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_mid_off, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_hot_cnt, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_hot_off, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_mid, LOC_MAX_BUCKETS, uint2);
+  DFH_ALLOC(b->d_hot, LOC_MAX_BUCKETS, uint2);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1573,8 +1581,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_s_row,  b->d_s_val,   b->d_U,        b->d_urow,     b->d_need,     b->d_rank,      b->d_pred,    b->d_slope,
                   b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
                   b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
-                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid_cnt, b->d_mid_off, b->d_mid_ent,  b->d_hot_cnt, b->d_hot_off,
-                  b->d_hot_ent, b->d_uw};
+                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1670,8 +1677,9 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   b->looked_up = nullptr;
   if (N == 0) {
     // reference would index an empty vector (localizer.cc:35); define: no keys
-    DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), s));  // U = 0, no long segments
+    DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), s));  // U = 0
     DFH_HIP(hipMemsetAsync(b->d_col_ptr, 0, 4, s));
+    b->seg_nb = 0;  // no long segments
     b->localized = true;
     return prep_end(b);
   }
@@ -1717,12 +1725,9 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     v.nheads = b->d_nheads;
     v.lh = b->d_lh;
     SegListsOut sl;
-    sl.nb = b->d_U + SEG_NB_WORD;
-    sl.mid_cnt = b->d_mid_cnt;
-    sl.mid_off = b->d_mid_off;
+    sl.mid = b->d_mid;
     sl.mid_ent = b->d_mid_ent;
-    sl.hot_cnt = b->d_hot_cnt;
-    sl.hot_off = b->d_hot_off;
+    sl.hot = b->d_hot;
     sl.hot_ent = b->d_hot_ent;
     if (cold && P > 1) {
       const uint32_t S = (uint32_t)P * LOC_OVERSAMPLE;
@@ -1732,12 +1737,20 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
     hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+#ifdef DFH_LOC_USE_SCAN
+    hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
+#endif
     hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_loc_sort, dim3(P), dim3(LOC_SORT_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_loc_emit, dim3(P), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
+#ifndef DFH_LOC_GRID_CAP
+#define DFH_LOC_GRID_CAP 1024
+#endif
+    const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
+    hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
                        b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
                        b->d_s_val, b->d_U, sl);
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
+    b->seg_nb = (uint32_t)P;
   } else {
     // very large batches: library LSD radix sort
     hipLaunchKernelGGL(k_rdx_keys, dim3(g), dim3(256), 0, s, b->d_raw, N, max_index, b->d_keys, b->d_pos);
@@ -1750,10 +1763,10 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
                        b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                        b->d_s_row, b->d_s_val, b->d_U);
     // keys with long segments, for the backward pass: one list bucket
-    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_U + SEG_NB_WORD, b->d_mid_cnt, b->d_mid_off, b->d_hot_cnt,
-                       b->d_hot_off);
+    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot);
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
-                       b->d_col_ptr, b->d_U, b->d_mid_cnt, b->d_hot_cnt, b->d_mid_ent, b->d_hot_ent);
+                       b->d_col_ptr, b->d_U, b->d_mid, b->d_hot, b->d_mid_ent, b->d_hot_ent);
+    b->seg_nb = 1;
   }
   delete tsp;
   DFH_HIP(hipGetLastError());
@@ -1858,12 +1871,12 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_U + SEG_NB_WORD, b->d_mid_cnt, b->d_mid_off, b->d_hot_cnt,
-                     b->d_hot_off);
+  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot);
   if (U) {
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::min<size_t>((U + 1023) / 1024, 256)), dim3(1024), 0, s, b->d_col_ptr,
-                       b->d_U, b->d_mid_cnt, b->d_hot_cnt, b->d_mid_ent, b->d_hot_ent);
+                       b->d_U, b->d_mid, b->d_hot, b->d_mid_ent, b->d_hot_ent);
   }
+  b->seg_nb = 1;
   DFH_HIP(hipGetLastError());
   DFH_HIP(hipStreamSynchronize(s));
   b->nrows = nrows;

@@ -56,21 +56,18 @@ struct TableView {
   dfh_updater_param p;
 };
 
-// the batch's device scalar block d_U[64]: [0] = U, [1] = REFRAND total, [SEG_NB_WORD] = number of list buckets
-constexpr int SEG_NB_WORD = 8;
+// the batch's device scalar block d_U[64]: [0] = U, [1] = REFRAND total
 
 // Long-segment lists for the backward pass: the keys whose segments (runs of equal key in the
 // key-ordered view) are longer than BWD_SMALL ("mid") / BWD_MID ("hot"), in *nb list buckets:
-// bucket q holds cnt[q] entries (values u = rank of the key) at ent[off[q] ..].  The sample-sort
+// bucket q holds cnt entries (values u = rank of the key) at ent[off ..].  The sample-sort
 // Localizer fills one list bucket per sort bucket (k_loc_emit: no inter-block compaction);
-// k_seg_lists fills a single one.  Order inside and across buckets is arbitrary.
+// k_seg_lists fills a single one.  Order inside and across buckets is arbitrary.  The number of
+// list buckets is known to the host when it queues the Localizer and travels as a kernel argument.
 struct SegLists {
-  const uint32_t* nb;
-  const uint32_t* mid_cnt;
-  const uint32_t* mid_off;
+  const uint2* mid;         // [nb] {cnt, off}
   const uint32_t* mid_ent;
-  const uint32_t* hot_cnt;
-  const uint32_t* hot_off;
+  const uint2* hot;         // [nb] {cnt, off}
   const uint32_t* hot_ent;
 };
 

@@ -200,12 +200,32 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
   }
 }
 
-constexpr uint32_t BWD_SMALL = 8;
-constexpr uint32_t BWD_MID = 256;
-constexpr int BWD_MIDW = 16;
-constexpr int BWD_DEPTH = 2;
-constexpr int BWD_SMALL_DEPTH = 2;
+#ifndef DFH_BWD_SMALL
+#define DFH_BWD_SMALL 8
+#endif
+#ifndef DFH_BWD_MID
+#define DFH_BWD_MID 256
+#endif
+#ifndef DFH_BWD_DEPTH
+#define DFH_BWD_DEPTH 2
+#endif
+#ifndef DFH_FWD_WAVES
+#define DFH_FWD_WAVES 5
+#endif
+#ifndef DFH_BWD_SMALL_DEPTH
+#define DFH_BWD_SMALL_DEPTH 2
+#endif
+#ifndef DFH_BWD_INTERLEAVE
+#define DFH_BWD_INTERLEAVE 0
+#endif
+constexpr uint32_t BWD_SMALL = DFH_BWD_SMALL;
+constexpr uint32_t BWD_MID = DFH_BWD_MID;
+constexpr int BWD_DEPTH = DFH_BWD_DEPTH;
+constexpr int BWD_SMALL_DEPTH = DFH_BWD_SMALL_DEPTH;
 constexpr int BWD_THREADS = 512;    // threads per block of k_backward_all
+#ifdef DFH_BWD_TRACE
+__device__ unsigned long long g_bwd_trace[3 * 8192];
+#endif
 
 // ---------------------------------------------------------------------------
 // k_lookup: one thread per unique key.  urow[u] = row of feaids[u] (inserted as
@@ -330,7 +350,7 @@ constexpr int PROG_SLOTS = 16384;
 constexpr int PROG_LOSS = 0, PROG_PENALTY = 1, PROG_AUC = 2;  // [PROG_AUC * PROG_SLOTS] is a single accumulator
 
 template <int L, int FWD_DEPTH>
-__global__ void __launch_bounds__(256) k_forward(BatchView b, RowSrc src, int k, int kp) {
+__global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, RowSrc src, int k, int kp) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
@@ -634,21 +654,21 @@ __device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_
 template <int L, bool FUSED, int NW>
 __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                          size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
-                                         uint32_t nwaves, double& pen_acc) {
+                                         uint32_t nwaves, uint32_t nb, double& pen_acc) {
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;
   // waves are dealt to the list buckets: G waves per bucket when there are more waves than buckets
-  const uint32_t nb = *b.seg.nb;
   if (nb == 0) return;
   const uint32_t G = max(1u, nwaves / nb), ngroups = nwaves / G;
   const uint32_t grp_w = wave / G, sub_w = wave % G;
   if (grp_w >= ngroups) return;
   for (uint32_t lb = grp_w; lb < nb; lb += ngroups) {
-    const uint32_t nm = b.seg.mid_cnt[lb];
+    const uint2 co = b.seg.mid[lb];
+    const uint32_t nm = co.x;
     if (nm == 0) continue;
-    const uint32_t* __restrict__ ent = b.seg.mid_ent + b.seg.mid_off[lb];
+    const uint32_t* __restrict__ ent = b.seg.mid_ent + co.y;
     for (uint32_t q = sub_w; q < nm; q += G) {
       const uint32_t u = ent[q];
       const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
@@ -662,7 +682,7 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
 template <int L, bool FUSED, int NW>
 __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                          size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t blk,
-                                         uint32_t nblk, double& pen_acc) {
+                                         uint32_t nblk, uint32_t nb, double& pen_acc) {
   __shared__ float part[NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
   const int lane = lane_id();
   const int grp = lane / L;
@@ -671,15 +691,15 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
   const int w = threadIdx.x >> 6;
   // blocks are dealt to the list buckets like the waves of the mid role (uniform per block: the
   // barriers below are reached by all of its threads)
-  const uint32_t nb = *b.seg.nb;
   if (nb == 0) return;
   const uint32_t G = max(1u, nblk / nb), ngroups = nblk / G;
   const uint32_t grp_b = blk / G, sub_b = blk % G;
   if (grp_b >= ngroups) return;
   for (uint32_t lb = grp_b; lb < nb; lb += ngroups) {
-  const uint32_t nh = b.seg.hot_cnt[lb];
+  const uint2 co = b.seg.hot[lb];
+  const uint32_t nh = co.x;
   if (nh == 0) continue;
-  const uint32_t* __restrict__ ent = b.seg.hot_ent + b.seg.hot_off[lb];
+  const uint32_t* __restrict__ ent = b.seg.hot_ent + co.y;
   for (uint32_t q = sub_b; q < nh; q += G) {
     const uint32_t u = ent[q];
     const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
@@ -789,9 +809,17 @@ struct SmallArgs {
   dfh_updater_param p;
 };
 
+#ifndef DFH_BWD_SMALL_KEYS
+#define DFH_BWD_SMALL_KEYS 1
+#endif
+// KPG keys per lane group and iteration, all of their loads in flight together: the role is a chain
+// of dependent round trips (segment bounds + row id -> model row + occurrence list -> slopes + XV
+// rows), and with the register file capping the waves per SIMD, more independent chains per wave
+// are the only way to more requests in flight.
 template <int L, bool EXACT>
 __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wave, uint32_t nwaves, double& pen_acc) {
   constexpr int G = 64 / L;
+  constexpr int KPG = DFH_BWD_SMALL_KEYS;
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
@@ -800,83 +828,130 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
   const bool sub_ok = EXACT ? true : (sub * 4 < kp);
   const uint32_t U = *a.d_U;
   float pen = 0.f;
-  for (uint32_t u0 = wave * G; u0 < U; u0 += nwaves * G) {
-    const uint32_t u = min(u0 + grp, U - 1);
-    const uint32_t beg = a.col_ptr[u], end_all = a.col_ptr[u + 1];
-    const uint32_t r = a.urow[u];
-    const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL;
-    const uint32_t end = mine ? end_all : beg;
-    // every independent load of the key, back to back
-    RowHdr* hp = a.hdr + r;
-    float* va = a.va + (size_t)r * (2 * kp);
-    const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
-    const float fea_cnt = hp->fea_cnt;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), acc = v;
-    if (k > 0 && sub_ok) {
-      v = ld4_nt(va + sub * 4);
-      acc = ld4_nt(va + kp + sub * 4);
+  for (uint32_t u0 = wave * (G * KPG); u0 < U; u0 += nwaves * (G * KPG)) {
+    uint32_t u[KPG], beg[KPG], end[KPG], r[KPG];
+    bool mine[KPG];
+#pragma unroll
+    for (int h = 0; h < KPG; ++h) {  // round trip 1: segment bounds + row id
+      const uint32_t uu = u0 + h * G + grp;
+      u[h] = min(uu, U - 1);
+      beg[h] = a.col_ptr[u[h]];
+      end[h] = a.col_ptr[u[h] + 1];
+      r[h] = a.urow[u[h]];
     }
-    float gw = 0.f, xxp = 0.f;
-    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t j0 = beg; j0 < end; j0 += 2) {
-      const bool ok1 = j0 + 1 < end;
-      const uint32_t row0 = a.s_row[j0], row1 = ok1 ? a.s_row[j0 + 1] : 0;
-      const float x0 = a.s_val ? a.s_val[j0] : 1.0f;
-      const float x1 = ok1 ? (a.s_val ? a.s_val[j0 + 1] : 1.0f) : 0.f;
-      const float p0 = a.slope[row0], p1 = ok1 ? a.slope[row1] : 0.f;
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float4 h0[KPG], v[KPG], acc[KPG], gv[KPG];
+    float fea_cnt[KPG], gw[KPG], xxp[KPG];
+    uint32_t rows[KPG][BWD_SMALL_DEPTH];
+    float xs[KPG][BWD_SMALL_DEPTH];
+#pragma unroll
+    for (int h = 0; h < KPG; ++h) {  // round trip 2: the model row and the first occurrences, back to back
+      mine[h] = (u0 + h * G + grp) < U && end[h] - beg[h] <= BWD_SMALL;
+      if (!mine[h]) end[h] = beg[h];
+      const RowHdr* hp = a.hdr + r[h];
+      const float* va = a.va + (size_t)r[h] * (2 * kp);
+      h0[h] = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+      fea_cnt[h] = hp->fea_cnt;
+      v[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[h] = v[h];
       if (k > 0 && sub_ok) {
-        a0 = ld4(a.xv + (size_t)row0 * kp + sub * 4);
-        if (ok1) a1 = ld4(a.xv + (size_t)row1 * kp + sub * 4);
+        v[h] = ld4_nt(va + sub * 4);
+        acc[h] = ld4_nt(va + kp + sub * 4);
       }
-      // ascending rows: the reference's order (spmm.h:137-156)
-      gw += p0 * x0; xxp += p0 * (x0 * x0);
-      gv.x += (a0.x * p0) * x0; gv.y += (a0.y * p0) * x0; gv.z += (a0.z * p0) * x0; gv.w += (a0.w * p0) * x0;
-      gw += p1 * x1; xxp += p1 * (x1 * x1);
-      gv.x += (a1.x * p1) * x1; gv.y += (a1.y * p1) * x1; gv.z += (a1.z * p1) * x1; gv.w += (a1.w * p1) * x1;
+#pragma unroll
+      for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {
+        const bool ok = beg[h] + q < end[h];
+        rows[h][q] = ok ? a.s_row[beg[h] + q] : 0u;
+        xs[h][q] = ok ? (a.s_val ? a.s_val[beg[h] + q] : 1.0f) : 0.f;
+      }
+      gw[h] = 0.f;
+      xxp[h] = 0.f;
+      gv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (!mine) continue;
-    const float w_old = h0.x;
-    const bool has_v = k > 0 && __float_as_uint(h0.y) != 0;
-    if (has_v) {
-      // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198); rows without V hold zeros
-      gv.x -= v.x * xxp; gv.y -= v.y * xxp; gv.z -= v.z * xxp; gv.w -= v.w * xxp;
-      if (sub_ok) pen += 0.5f * a.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-    }
-    if (sub == 0) {
-      pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
-      float sqrt_g = h0.z, z = h0.w;
-      const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, a.p);
-      uint32_t hv = has_v ? 1u : 0u;
-      if (w_old == 0 && w_new != 0 && k > 0 && !has_v && fea_cnt > (float)a.p.V_threshold) {  // sgd_updater.cc:122-126
-        if (a.p.init_mode == DFH_INIT_HASH) {
-          const uint64_t key = a.feaids[u];
-          for (int j = 0; j < kp; ++j) {
-            va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
-            va[kp + j] = 0.0f;
-          }
-          hv = 1u;
-        } else {
-          a.need_init[u] = 1;
+    uint32_t longest = 0;
+#pragma unroll
+    for (int h = 0; h < KPG; ++h) longest = max(longest, end[h] - beg[h]);
+    for (uint32_t j0 = 0; j0 < longest; j0 += BWD_SMALL_DEPTH) {
+      float ps[KPG][BWD_SMALL_DEPTH];
+      float4 av[KPG][BWD_SMALL_DEPTH];
+#pragma unroll
+      for (int h = 0; h < KPG; ++h) {  // round trip 3 (+): slopes and XV rows of these occurrences
+#pragma unroll
+        for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {
+          const bool ok = beg[h] + j0 + q < end[h];
+          ps[h][q] = ok ? a.slope[rows[h][q]] : 0.f;
+          av[h][q] = (ok && k > 0 && sub_ok) ? ld4(a.xv + (size_t)rows[h][q] * kp + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));
-    }
-    if (has_v && sub_ok) {
-      float4 nv = v;
-      adagrad_update_v(gv.x, nv.x, acc.x, a.p);
-      adagrad_update_v(gv.y, nv.y, acc.y, a.p);
-      adagrad_update_v(gv.z, nv.z, acc.z, a.p);
-      adagrad_update_v(gv.w, nv.w, acc.w, a.p);
-      if (!EXACT || k != kp) {
-        const int d0 = sub * 4;
-        if (d0 + 0 >= k) { nv.x = 0.f; acc.x = 0.f; }
-        if (d0 + 1 >= k) { nv.y = 0.f; acc.y = 0.f; }
-        if (d0 + 2 >= k) { nv.z = 0.f; acc.z = 0.f; }
-        if (d0 + 3 >= k) { nv.w = 0.f; acc.w = 0.f; }
+      const bool more = j0 + BWD_SMALL_DEPTH < longest;
+#pragma unroll
+      for (int h = 0; h < KPG; ++h) {
+#pragma unroll
+        for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
+          const float pp = ps[h][q], xx = xs[h][q];
+          gw[h] += pp * xx; xxp[h] += pp * (xx * xx);
+          gv[h].x += (av[h][q].x * pp) * xx; gv[h].y += (av[h][q].y * pp) * xx;
+          gv[h].z += (av[h][q].z * pp) * xx; gv[h].w += (av[h][q].w * pp) * xx;
+        }
+        if (more) {  // the next occurrences of the longer segments
+#pragma unroll
+          for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {
+            const uint32_t j = beg[h] + j0 + BWD_SMALL_DEPTH + q;
+            const bool ok = j < end[h];
+            rows[h][q] = ok ? a.s_row[j] : 0u;
+            xs[h][q] = ok ? (a.s_val ? a.s_val[j] : 1.0f) : 0.f;
+          }
+        }
       }
-      st4_nt(va + sub * 4, nv);
-      st4_nt(va + kp + sub * 4, acc);
+    }
+#pragma unroll
+    for (int h = 0; h < KPG; ++h) {
+      if (!mine[h]) continue;
+      RowHdr* hp = a.hdr + r[h];
+      float* va = a.va + (size_t)r[h] * (2 * kp);
+      const float w_old = h0[h].x;
+      const bool has_v = k > 0 && __float_as_uint(h0[h].y) != 0;
+      float4 g4 = gv[h];
+      const float4 vv = v[h];
+      if (has_v) {
+        // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198); rows without V hold zeros
+        g4.x -= vv.x * xxp[h]; g4.y -= vv.y * xxp[h]; g4.z -= vv.z * xxp[h]; g4.w -= vv.w * xxp[h];
+        if (sub_ok) pen += 0.5f * a.p.V_l2 * (vv.x * vv.x + vv.y * vv.y + vv.z * vv.z + vv.w * vv.w);
+      }
+      if (sub == 0) {
+        pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
+        float sqrt_g = h0[h].z, z = h0[h].w;
+        const float w_new = ftrl_update_w(gw[h], w_old, sqrt_g, z, a.p);
+        uint32_t hv = has_v ? 1u : 0u;
+        if (w_old == 0 && w_new != 0 && k > 0 && !has_v && fea_cnt[h] > (float)a.p.V_threshold) {  // sgd_updater.cc:122-126
+          if (a.p.init_mode == DFH_INIT_HASH) {
+            const uint64_t key = a.feaids[u[h]];
+            for (int j = 0; j < kp; ++j) {
+              va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
+              va[kp + j] = 0.0f;
+            }
+            hv = 1u;
+          } else {
+            a.need_init[u[h]] = 1;
+          }
+        }
+        st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));
+      }
+      if (has_v && sub_ok) {
+        float4 nv = vv, na = acc[h];
+        adagrad_update_v(g4.x, nv.x, na.x, a.p);
+        adagrad_update_v(g4.y, nv.y, na.y, a.p);
+        adagrad_update_v(g4.z, nv.z, na.z, a.p);
+        adagrad_update_v(g4.w, nv.w, na.w, a.p);
+        if (!EXACT || k != kp) {
+          const int d0 = sub * 4;
+          if (d0 + 0 >= k) { nv.x = 0.f; na.x = 0.f; }
+          if (d0 + 1 >= k) { nv.y = 0.f; na.y = 0.f; }
+          if (d0 + 2 >= k) { nv.z = 0.f; na.z = 0.f; }
+          if (d0 + 3 >= k) { nv.w = 0.f; na.w = 0.f; }
+        }
+        st4_nt(va + sub * 4, nv);
+        st4_nt(va + kp + sub * 4, na);
+      }
     }
   }
   pen_acc += (double)pen;  // penalty of the pulled weights (sgd_learner.cc:249-273); flushed once per block
@@ -888,20 +963,38 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
 // longest), the others the short-segment role.  LEAN selects the table-specialised
 // short-segment code (fused update on the resident table).
 // ---------------------------------------------------------------------------
+#ifndef DFH_BWD_WAVES
+#define DFH_BWD_WAVES 6
+#endif
 template <int L, bool FUSED, bool LEAN, bool EXACT>
-__global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
+__global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
                                                                 size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
-                                                                uint32_t nb_hot, uint32_t nb_mid) {
+                                                                uint32_t nb_hot, uint32_t nb_mid, uint32_t nlist) {
   constexpr int NW = BWD_THREADS / 64;
   double pen_acc = 0.0;
-  if (blockIdx.x < nb_hot) {
-    hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, blockIdx.x, nb_hot, pen_acc);
-  } else if (blockIdx.x < nb_hot + nb_mid) {
-    mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (blockIdx.x - nb_hot) * NW + (threadIdx.x >> 6),
-                           nb_mid * NW, pen_acc);
+#ifdef DFH_BWD_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
+  // block -> role.  The long-segment blocks come first in dispatch order (their chains are the
+  // longest), optionally interleaved 1 : (R - 1) with short-segment blocks so that the first
+  // resident set is not long-segment blocks only
+  const uint32_t nb_big = nb_hot + nb_mid;
+  uint32_t big_id = blockIdx.x, small_id = blockIdx.x - min(blockIdx.x, nb_big);
+  bool is_big = blockIdx.x < nb_big;
+  if (DFH_BWD_INTERLEAVE > 1) {
+    constexpr uint32_t R = DFH_BWD_INTERLEAVE > 1 ? DFH_BWD_INTERLEAVE : 2;
+    const uint32_t before = min(nb_big, (blockIdx.x + R - 1) / R);  // long-segment blocks with a smaller id
+    is_big = blockIdx.x % R == 0 && blockIdx.x / R < nb_big;
+    big_id = blockIdx.x / R;
+    small_id = blockIdx.x - before;
+  }
+  if (is_big && big_id < nb_hot) {
+    hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, big_id, nb_hot, nlist, pen_acc);
+  } else if (is_big) {
+    mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (big_id - nb_hot) * NW + (threadIdx.x >> 6),
+                           nb_mid * NW, nlist, pen_acc);
   } else {
-    const uint32_t nb_big = nb_hot + nb_mid;
-    const uint32_t wave = (blockIdx.x - nb_big) * NW + (threadIdx.x >> 6);
+    const uint32_t wave = small_id * NW + (threadIdx.x >> 6);
     const uint32_t nwaves = (gridDim.x - nb_big) * NW;
     if (LEAN) {
       SmallArgs sa;
@@ -914,6 +1007,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, Ro
     }
   }
   if (FUSED) flush_penalty(b, pen_acc);
+#ifdef DFH_BWD_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {  // measurement build only (tools/): per-block role and wall-clock span
+    g_bwd_trace[blockIdx.x * 3 + 0] = is_big ? (big_id < nb_hot ? 0ull : 1ull) : 2ull;
+    g_bwd_trace[blockIdx.x * 3 + 1] = trace_t0;
+    g_bwd_trace[blockIdx.x * 3 + 2] = wall_clock64();
+  }
+#endif
 }
 
 // k_seg_lists: one pass over the unique keys of a localized minibatch, compacting the keys with
@@ -921,7 +1021,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 6) k_backward_all(BatchView b, Ro
 // before).  Used where the minibatch did not come out of k_rdx_emit (library-sort Localizer for
 // very large batches, batches localized on the host).
 __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U,
-                                                    uint32_t* __restrict__ mid_cnt0, uint32_t* __restrict__ hot_cnt0,
+                                                    uint2* __restrict__ mid0, uint2* __restrict__ hot0,
                                                     uint32_t* __restrict__ mid_ent, uint32_t* __restrict__ hot_ent) {
   __shared__ uint32_t cnt[2], base[2];
   const uint32_t U = *d_U;
@@ -934,8 +1034,8 @@ __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__
     const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : -1);
     if (which >= 0) slot = atomicAdd(&cnt[which], 1u);
     __syncthreads();
-    if (threadIdx.x == 0 && cnt[0]) base[0] = atomicAdd(mid_cnt0, cnt[0]);
-    if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(hot_cnt0, cnt[1]);
+    if (threadIdx.x == 0 && cnt[0]) base[0] = atomicAdd(&mid0->x, cnt[0]);
+    if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(&hot0->x, cnt[1]);
     __syncthreads();
     if (which == 0) mid_ent[base[0] + slot] = u;
     if (which == 1) hot_ent[base[1] + slot] = u;
@@ -944,13 +1044,10 @@ __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__
 }
 
 // one list bucket at offset 0, empty: what k_seg_lists adds to
-__global__ void k_seg_lists_reset(uint32_t* nb, uint32_t* mid_cnt, uint32_t* mid_off, uint32_t* hot_cnt, uint32_t* hot_off) {
+__global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    *nb = 1;
-    mid_cnt[0] = 0;
-    mid_off[0] = 0;
-    hot_cnt[0] = 0;
-    hot_off[0] = 0;
+    *mid0 = make_uint2(0u, 0u);
+    *hot0 = make_uint2(0u, 0u);
   }
 }
 

@@ -54,9 +54,16 @@ constexpr int LOC_AVG_BUCKET = 384;    // target pairs per bucket
 constexpr int LOC_MIN_AVG = 48;        // stored splitters are reused while N / P stays in [MIN, MAX]
 constexpr int LOC_MAX_AVG = 700;
 constexpr int LOC_LDS_CAP = 1024;      // pairs a bucket may hold to be sorted in LDS
-constexpr int LOC_TILE = 2048;         // pairs per block in count / scatter
-constexpr int LOC_TILE_THREADS = 1024;
+#ifndef DFH_LOC_TILE
+#define DFH_LOC_TILE 2048
+#endif
+#ifndef DFH_LOC_TILE_THREADS
+#define DFH_LOC_TILE_THREADS 1024
+#endif
+constexpr int LOC_TILE = DFH_LOC_TILE;         // pairs per block in count / scatter
+constexpr int LOC_TILE_THREADS = DFH_LOC_TILE_THREADS;
 constexpr int LOC_PER_THREAD = LOC_TILE / LOC_TILE_THREADS;
+constexpr int LOC_BPT = LOC_MAX_BUCKETS / LOC_TILE_THREADS;  // buckets per thread in k_loc_scatter's scan
 constexpr int LOC_SORT_THREADS = 256;
 constexpr int LOC_EMIT_THREADS = 256;
 
@@ -91,12 +98,9 @@ struct LocView {
 
 // long-segment lists for k_backward_all, one slot range per list bucket (dfh_internal.h: SegLists)
 struct SegListsOut {
-  uint32_t* nb;
-  uint32_t* mid_cnt;
-  uint32_t* mid_off;
+  uint2* mid;  // [P] {cnt, off}
   uint32_t* mid_ent;
-  uint32_t* hot_cnt;
-  uint32_t* hot_off;
+  uint2* hot;
   uint32_t* hot_ent;
 };
 
@@ -284,16 +288,60 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
   // result does not.
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     const uint32_t h = hist[b];
+#ifdef DFH_LOC_USE_SCAN
+    v.run_off[blockIdx.x * P + b] = h;  // per-tile histogram; k_loc_scan turns it into offsets
+#else
     v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[b], h) : 0u;
+#endif
   }
 }
+
+#ifdef DFH_LOC_USE_SCAN
+// experiment: the deterministic alternative to the atomics — run_off[tile][b] = pairs of bucket b in
+// earlier tiles; btotal[b].  One block per 64 buckets; the block's 4 waves split the tiles.
+__global__ void __launch_bounds__(256) k_loc_scan(LocView v) {
+  __shared__ uint32_t wtot[4][64];
+  const int P = v.P;
+  const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int per = (v.ntiles + 3) / 4;
+  const int t_beg = w * per, t_end = min(v.ntiles, t_beg + per);
+  uint32_t* __restrict__ ro = v.run_off;
+  uint32_t sum = 0;
+  if (b < P) {
+    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
+      uint32_t h[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? ro[(t0 + q) * P + b] : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += h[q];
+    }
+  }
+  wtot[w][threadIdx.x & 63] = sum;
+  __syncthreads();
+  uint32_t run = 0;
+  for (int q = 0; q < w; ++q) run += wtot[q][threadIdx.x & 63];
+  if (b < P) {
+    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
+      uint32_t h[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? ro[(t0 + q) * P + b] : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (t0 + q < t_end) ro[(t0 + q) * P + b] = run;
+        run += h[q];
+      }
+    }
+    if (w == 3) v.btotal[b] = run;
+  }
+}
+#endif
 
 // ---- scatter into bucket-major order; every block derives the bucket starts from the totals
 // (block 0 publishes them)
 __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
   __shared__ uint32_t off[LOC_MAX_BUCKETS];
   __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
-  static_assert(LOC_MAX_BUCKETS == LOC_TILE_THREADS, "one bucket per thread in the scan");
   const int P = v.P;
   const uint32_t base = blockIdx.x * LOC_TILE;
   uint64_t raw[LOC_PER_THREAD];
@@ -304,14 +352,25 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
     raw[e] = i < v.n ? v.raw[i] : 0;
     pk[e] = i < v.n ? v.packed[i] : 0;
   }
-  const int b0 = threadIdx.x;
-  const uint32_t tot = b0 < P ? v.btotal[b0] : 0u;
-  const uint32_t ro = b0 < P ? v.run_off[blockIdx.x * P + b0] : 0u;
+  // exclusive scan of the bucket totals: LOC_BPT consecutive buckets per thread
+  const int b0 = threadIdx.x * LOC_BPT;
+  uint32_t tt[LOC_BPT], ro[LOC_BPT];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int q = 0; q < LOC_BPT; ++q) {
+    tt[q] = b0 + q < P ? v.btotal[b0 + q] : 0u;
+    ro[q] = b0 + q < P ? v.run_off[blockIdx.x * P + b0 + q] : 0u;
+    sum += tt[q];
+  }
   uint32_t total;
-  const uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(tot, wsum, &total);
-  if (b0 < P) {
-    off[b0] = ex + ro;
-    if (blockIdx.x == 0) v.bstart[b0] = ex;
+  uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(sum, wsum, &total);
+#pragma unroll
+  for (int q = 0; q < LOC_BPT; ++q) {
+    if (b0 + q < P) {
+      off[b0 + q] = ex + ro[q];
+      if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
+    }
+    ex += tt[q];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
   __syncthreads();
@@ -333,7 +392,10 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
   __shared__ uint64_t bk[LOC_LDS_CAP];
   __shared__ uint32_t bp[LOC_LDS_CAP];
   __shared__ uint32_t red[3][LOC_SORT_THREADS / 64];
-  const uint32_t b = blockIdx.x;
+  // the grid may be smaller than the number of buckets (a capped grid leaves more of the chip to
+  // the training step this preparation work runs beside)
+  for (uint32_t b = blockIdx.x; b < (uint32_t)v.P; b += gridDim.x) {
+  __syncthreads();  // LDS of the previous bucket is done with
   const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
   const uint32_t n = end - beg;
   if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_scatter: ready for the next call
@@ -344,7 +406,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
       v.first_key[b] = 0;
       v.last_key[b] = 0;
     }
-    return;
+    continue;
   }
   const uint64_t* gk = v.bkeys + beg;
   const uint32_t* gp = v.bpos + beg;
@@ -486,6 +548,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     v.first_key[b] = in_lds ? sk[0] : v.skeys[beg];
     v.last_key[b] = in_lds ? sk[n - 1] : v.skeys[beg + n - 1];
   }
+  }
 }
 
 // ---- emit: one block per bucket stitches itself to its predecessors (unique keys before the
@@ -505,21 +568,21 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
   constexpr int NW = LOC_EMIT_THREADS / 64;
   __shared__ uint32_t wsum[NW], wmax[NW];
   __shared__ uint32_t sh_cont, n_mid, n_hot;
-  const uint32_t b = blockIdx.x;
   const uint32_t P = (uint32_t)v.P;
+  for (uint32_t b = blockIdx.x; b < P; b += gridDim.x) {
+  __syncthreads();  // the shared counters of the previous bucket have been published
   const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
   const uint32_t n = end - beg;
   const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b;
   if (threadIdx.x == 0) {
     n_mid = 0;
     n_hot = 0;
-    if (b == 0) *sl.nb = P;
     if (n == 0) {
-      sl.mid_cnt[b] = 0;
-      sl.hot_cnt[b] = 0;
+      sl.mid[b] = make_uint2(0u, 0u);
+      sl.hot[b] = make_uint2(0u, 0u);
     }
   }
-  if (n == 0) return;
+  if (n == 0) continue;
   // over the buckets q < b: unique keys (nheads[q] - cont[q], cont[q]: first_key[q] equals the last key of the
   // previous NON-EMPTY bucket) and the position of the last run head that opens a new key
   uint32_t part = 0, carry1 = 0;  // carry1: position + 1 (0: none)
@@ -596,10 +659,9 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    sl.mid_cnt[b] = n_mid;
-    sl.mid_off[b] = moff;
-    sl.hot_cnt[b] = n_hot;
-    sl.hot_off[b] = hoff;
+    sl.mid[b] = make_uint2(n_mid, moff);
+    sl.hot[b] = make_uint2(n_hot, hoff);
+  }
   }
 }
 
