@@ -5,6 +5,8 @@
  *   Localizer.Base / BaseHash       tests/cpp/localizer_test.cc:12-49
  *   SGDLearner.Basic                tests/cpp/sgd_learner_test.cc:9-49  (fused and literal worker loops)
  *   BatchReader.Read / RandRead / PartRead   tests/cpp/batch_reader_test.cc:9-57
+ *   LBFGSLearner.Basic / WithV      tests/cpp/lbfgs_learner_test.cc:8-146 (objective trajectories of an
+ *                                   L-BFGS loop over Loss::Predict / CalcGrad / Evaluate — lbfgs_mini.h)
  * plus Store Pull/Push and Updater Save/Load round trips.  Needs a GPU, except the reader cases.
  * usage: difacto_host_tests <path to rcv1_100.libsvm> [reader]     ("reader": only the host-only cases)
  */
@@ -14,6 +16,7 @@
 #include "./device_store.h"
 #include "./hip_fm_loss.h"
 #include "./host_localizer.h"
+#include "./lbfgs_mini.h"
 #include "./libsvm_reader.h"
 #include "./sgd_learner.h"
 #include "dmlc/memory_io.h"
@@ -161,6 +164,59 @@ static void TestFMLossHasV() {
   EXPECT(std::fabs(norm2(grad) - 1.2378e3) < 1e-1);
 }
 
+// tests/cpp/lbfgs_learner_test.cc: the FM loss (with and without V) driven by L-BFGS through the Loss interface
+static void TestLBFGSTrajectory(bool with_v) {
+  dmlc::data::RowBlockContainer<unsigned> rowblk;
+  std::vector<feaid_t> uidx;
+  load_data(&rowblk, &uidx);
+  auto data = rowblk.GetBlock();
+  lbfgs_mini::Param P;
+  P.m = 5;
+  P.max_num_epochs = 19;
+  P.init_alpha = 1;
+  std::unique_ptr<Loss> loss(Loss::Create("fm"));
+  if (!with_v) {
+    const std::vector<real_t> objv = {34.603421, 12.655075, 5.224232, 2.713903, 1.290586, 0.645131, 0.317889,
+                                      0.156723,  0.075331,  0.032091, 0.018044, 0.008562, 0.004336, 0.002132,
+                                      0.001051,  0.000506,  0.000227, 0.000119, 0.000059};
+    P.V_dim = 0;
+    P.l2 = 0;
+    loss->Init({{"V_dim", "0"}});
+    auto got = lbfgs_mini::Run(loss.get(), data, uidx.size(), P);
+    EXPECT(got.size() == objv.size());
+    for (size_t i = 0; i < got.size() && i < objv.size(); ++i) EXPECT(std::fabs(got[i] - objv[i]) < 1e-5);
+  } else {
+    const std::vector<real_t> objv = {35.224265, 21.631514, 18.394319, 16.077692, 12.389012, 8.888516, 8.446880,
+                                      8.146090,  8.023501,  7.981967,  7.955119,  7.937092,  7.922456, 7.880596,
+                                      7.861660,  7.838057,  7.807892,  7.784401,  7.756756};
+    P.V_dim = 5;
+    P.l2 = .1f;
+    P.V_l2 = .01f;
+    P.rho = .5f;
+    loss->Init({{"V_dim", "5"}});
+    auto init = [](const std::vector<int>& lens, lbfgs_mini::Vec* vals) {  // lbfgs_learner_test.cc:130-141
+      int n = 0;
+      for (int l : lens) {
+        for (int i = 0; i < l; ++i) {
+          if (i > 0) {
+            real_t v = l - 1;
+            (*vals)[n] = (i - v / 2) * .01;
+          }
+          ++n;
+        }
+      }
+    };
+    auto got = lbfgs_mini::Run(loss.get(), data, uidx.size(), P, init);
+    EXPECT(got.size() == objv.size());
+    double worst = 0;
+    for (size_t i = 0; i < got.size() && i < objv.size(); ++i) {
+      worst = std::max(worst, std::fabs((double)got[i] - objv[i]));
+      EXPECT(std::fabs(got[i] - objv[i]) < 1e-4);
+    }
+    printf("        LBFGS WithV: worst |objv - golden| = %.2e over %zu epochs\n", worst, got.size());
+  }
+}
+
 static void TestSGDLearnerBasic(const char* path) {
   std::vector<real_t> objv = {69.314718, 69.314718, 67.151912, 61.414778, 56.244989, 53.218700, 51.248737,
                               49.846688, 48.650164, 47.698351, 46.924038, 46.388223, 45.970721, 45.499307,
@@ -248,6 +304,8 @@ int main(int argc, char** argv) {
       {"SGDLearner.Basic[fused]", [] { TestSGDLearnerBasic("fused"); }},
       {"SGDLearner.Basic[literal]", [] { TestSGDLearnerBasic("literal"); }},
       {"Store+ModelIO", TestStoreAndModelIO},
+      {"LBFGSLearner.Basic (HipFMLoss, V_dim 0)", [] { TestLBFGSTrajectory(false); }},
+      {"LBFGSLearner.WithV (HipFMLoss, V_dim 5)", [] { TestLBFGSTrajectory(true); }},
   };
   for (auto& t : tests) {
     int before = g_fail;

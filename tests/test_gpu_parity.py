@@ -982,3 +982,28 @@ def test_attach_device_zero_copy(capi, ctx, oracle):
     assert np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], oracle.localize(b["offset"], b["index"])["feaids"])
+
+
+# ------------------------------------------------------------------ L-BFGS as a second customer of the FM loss
+@pytest.mark.parametrize("case", ["basic", "withv"])
+def test_golden_lbfgs_trajectories_on_device(capi, ctx, oracle, rcv1, case):
+    """tests/cpp/lbfgs_learner_test.cc:8-146 — the device's FMLoss (dfh_fm_predict / dfh_fm_calcgrad /
+    dfh_loss_evaluate, what HipFMLoss::Predict / CalcGrad / Evaluate call) driven through the reference's
+    golden L-BFGS objective trajectories: 19 epochs with V_dim 0 to 1e-5, FM with V_dim 5 to 1e-4
+    (the C++ twin runs in build/difacto_host_tests through the Loss interface itself)"""
+    from oracle import lbfgs_driver as LB
+    loc = oracle.localize(rcv1["offset"], rcv1["index"])
+    V_dim = 0 if case == "basic" else 5
+
+    def loss_grad(w, lens):
+        wp, vp = oracle.get_pos(lens) if V_dim else (None, None)
+        pred = ctx.fm_predict(V_dim, loc["offset"], loc["index"], rcv1["value"], w, wp, vp)
+        g = ctx.fm_calcgrad(V_dim, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], w, pred, wp, vp)
+        return np.float32(ctx.loss_evaluate(rcv1["label"], pred)), g
+
+    if case == "basic":
+        got = LB.run(loss_grad, loc["U"], 0, 0.0, 0.01, 5, 19)
+        assert np.max(np.abs(np.array(got) - np.array(LB.BASIC_OBJV))) < 1e-5
+    else:
+        got = LB.run(loss_grad, loc["U"], 5, 0.1, 0.01, 5, 19, init=LB.withv_initializer)
+        assert np.max(np.abs(np.array(got) - np.array(LB.WITHV_OBJV))) < 1e-4

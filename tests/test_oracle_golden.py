@@ -239,3 +239,31 @@ def test_penalty_and_getpos(oracle):
     ws = [1, -2, 0.5, -1]
     exp = sum(0.5 * abs(w) + 0.5 * 2 * w * w for w in ws) + 0.5 * 4 * (9 + 16 + 1 + 1)
     assert got == pytest.approx(exp, rel=1e-6)
+
+
+# ---- tests/cpp/lbfgs_learner_test.cc: the FM loss with V driven by L-BFGS ("indirectly ... FM with V
+# over 23 iterations"): pins fm_predict / fm_calcgrad / loss_evaluate with V_dim > 0 against the reference's numbers
+@pytest.mark.parametrize("impl", ["oracle", "ref"])
+@pytest.mark.parametrize("case", ["basic", "withv"])
+def test_golden_lbfgs_trajectories(request, rcv1, impl, case):
+    from oracle import lbfgs_driver as LB
+    P = request.getfixturevalue(impl)
+    oracle = request.getfixturevalue("oracle")
+    loc = oracle.localize(rcv1["offset"], rcv1["index"])
+    V_dim = 0 if case == "basic" else 5
+
+    def loss_grad(w, lens):
+        wp, vp = oracle.get_pos(lens) if V_dim else (None, None)
+        if impl == "ref":
+            pred, g = P.fm_predict_calcgrad(V_dim, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], w, wp, vp)
+        else:
+            pred = P.fm_predict(V_dim, loc["offset"], loc["index"], rcv1["value"], w, wp, vp)
+            g = P.fm_calcgrad(V_dim, loc["offset"], loc["index"], rcv1["value"], rcv1["label"], w, pred, wp, vp)
+        return np.float32(P.loss_evaluate(rcv1["label"], pred)), g
+
+    if case == "basic":
+        got = LB.run(loss_grad, loc["U"], 0, 0.0, 0.01, 5, 19)
+        assert np.max(np.abs(np.array(got) - np.array(LB.BASIC_OBJV))) < 1e-5
+    else:
+        got = LB.run(loss_grad, loc["U"], 5, 0.1, 0.01, 5, 19, init=LB.withv_initializer)
+        assert np.max(np.abs(np.array(got) - np.array(LB.WITHV_OBJV))) < 1e-4
