@@ -27,6 +27,8 @@ SYMBOLS = [
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
+    "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
+    "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step",
 ]
 K_COUNT = 7
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
@@ -44,6 +46,11 @@ class Progress(C.Structure):
     """sgd::Progress (src/sgd/sgd_utils.h:40-75)"""
     _fields_ = [("loss", C.c_float), ("penalty", C.c_float), ("auc", C.c_float),
                 ("nnz_w", C.c_float), ("nrows", C.c_float)]
+
+
+# dfh_alltoallv_fn: int (*)(void* user, const void* send, const size_t* send_bytes, void* recv, const size_t* recv_bytes)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t))
+COMM_ID_BYTES = 128
 
 
 class DfhError(RuntimeError):
@@ -151,6 +158,17 @@ def lib():
     L.dfh_ctx_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_table_set_has_aux.argtypes = [vp, i32]
     L.dfh_table_has_aux.argtypes = [vp]
+    L.dfh_comm_unique_id.argtypes = [vp]
+    L.dfh_comm_create_rccl.argtypes = [vp, i32, i32, vp, PP(vp)]
+    L.dfh_comm_create_callback.argtypes = [vp, i32, i32, ALLTOALLV_FN, vp, PP(vp)]
+    L.dfh_comm_destroy.argtypes = [vp]
+    L.dfh_comm_rank.argtypes = [vp]
+    L.dfh_comm_world.argtypes = [vp]
+    L.dfh_comm_allreduce_sum.argtypes = [vp, vp, i32]
+    L.dfh_shard_create.argtypes = [vp, vp, vp, PP(vp)]
+    L.dfh_shard_destroy.argtypes = [vp]
+    L.dfh_shard_owned_range.argtypes = [vp, vp, PP(u64), PP(u64)]
+    L.dfh_shard_step.argtypes = [vp, vp, i32, i32, PP(i32)]
     _lib = L
     return L
 
@@ -547,3 +565,80 @@ class DeviceBuffer:
 
 def row_stride(V_dim):
     return int(lib().dfh_row_stride(V_dim))
+
+
+class Comm:
+    """dfh_comm: the transport of the sharded store — RCCL (product) or a host callback (tests)"""
+
+    def __init__(self, handle, keep=None):
+        self.h, self._keep = handle, keep
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * COMM_ID_BYTES)()
+        _ck(lib().dfh_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, ctx, rank, world, unique_id):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, COMM_ID_BYTES)
+        _ck(lib().dfh_comm_create_rccl(ctx.h, rank, world, C.cast(buf, C.c_void_p), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def callback(cls, ctx, rank, world, fn):
+        """fn(send: np.uint8[...], send_bytes: list, recv: np.uint8[...] (to fill), recv_bytes: list)"""
+        def tramp(_user, p_send, p_sb, p_recv, p_rb):
+            try:
+                sb = [int(p_sb[i]) for i in range(world)]
+                rb = [int(p_rb[i]) for i in range(world)]
+                send = np.ctypeslib.as_array(C.cast(p_send, C.POINTER(C.c_uint8)), shape=(max(sum(sb), 1),))[:sum(sb)]
+                recv = np.ctypeslib.as_array(C.cast(p_recv, C.POINTER(C.c_uint8)), shape=(max(sum(rb), 1),))[:sum(rb)]
+                fn(send, sb, recv, rb)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the C return code
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLTOALLV_FN(tramp)
+        h = C.c_void_p()
+        _ck(lib().dfh_comm_create_callback(ctx.h, rank, world, cb, None, C.byref(h)))
+        return cls(h, keep=cb)
+
+    def allreduce_sum(self, vals):
+        a = np.ascontiguousarray(vals, np.float64).copy()
+        _ck(lib().dfh_comm_allreduce_sum(self.h, _p(a), len(a)))
+        return a
+
+    def close(self):
+        if self.h:
+            lib().dfh_comm_destroy(self.h)
+            self.h = None
+
+
+class Shard:
+    """dfh_shard: this rank's part of the key-range-sharded model + the per-step exchange"""
+
+    def __init__(self, table, comm, splits=None):
+        self.h = C.c_void_p()
+        self.table, self.comm = table, comm
+        self.splits = None if splits is None else np.ascontiguousarray(splits, np.uint64)
+        _ck(lib().dfh_shard_create(table.h, comm.h, _p(self.splits), C.byref(self.h)))
+
+    def step(self, batch, is_train=True, push_cnt=False):
+        """collective; batch = None when this rank's data is exhausted.  -> True while any rank had a minibatch"""
+        act = C.c_int(0)
+        _ck(lib().dfh_shard_step(self.h, batch.h if batch is not None else None, 1 if is_train else 0, 1 if push_cnt else 0,
+                                 C.byref(act)))
+        return bool(act.value)
+
+    def owned_range(self):
+        lo, hi = C.c_uint64(0), C.c_uint64(0)
+        _ck(lib().dfh_shard_owned_range(self.h, _p(self.splits), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def close(self):
+        if self.h:
+            lib().dfh_shard_destroy(self.h)
+            self.h = None

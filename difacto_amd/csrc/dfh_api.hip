@@ -2140,3 +2140,5 @@ int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n,
 }
 
 }  // extern "C"
+
+#include "dfh_shard.hip"

@@ -294,6 +294,47 @@ int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_
  * with V for a row without V); synchronises */
 int dfh_table_check(dfh_table* t);
 
+/* ------------------------------------------------------ sharded store (multi-GPU) */
+/* The ps-lite Push / Pull of the reference (include/difacto/store.h:53-93, src/store) for the ranks
+ * of one node, one process per GPU: rank r owns a contiguous range of the reversed keys (uniform:
+ * [r*span, (r+1)*span), span = ceil(2^64/world); or the explicit split keys given to
+ * dfh_shard_create) and trains its own minibatches.  Nothing here is a collective on host data:
+ * all traffic is device buffers over the communicator. */
+typedef struct dfh_comm dfh_comm;
+typedef struct dfh_shard dfh_shard;
+#define DFH_COMM_ID_BYTES 128
+/* RCCL transport (ncclSend / ncclRecv over xGMI).  Rank 0 obtains an id and hands it to the other
+ * ranks out of band (a file, an env var, MPI ...); every rank then creates its communicator. */
+int dfh_comm_unique_id(void* id128);
+int dfh_comm_create_rccl(dfh_ctx* ctx, int rank, int world, const void* id128, dfh_comm** out);
+/* Host-callback transport: the library stages every exchange through host memory and calls
+ * fn(user, send, send_bytes[world], recv, recv_bytes[world]) — an all-to-all-v of bytes, contiguous in peer
+ * order on both sides; 0 = ok.  For process groups RCCL cannot serve (several ranks sharing one GPU in
+ * a test, a gloo / MPI / socket fabric of the host). */
+typedef int (*dfh_alltoallv_fn)(void* user, const void* send, const size_t* send_bytes, void* recv, const size_t* recv_bytes);
+int dfh_comm_create_callback(dfh_ctx* ctx, int rank, int world, dfh_alltoallv_fn fn, void* user, dfh_comm** out);
+int dfh_comm_destroy(dfh_comm* c);
+int dfh_comm_rank(dfh_comm* c);
+int dfh_comm_world(dfh_comm* c);
+/* sum of n <= 64 host doubles over the ranks (same result on every rank): progress merging, votes */
+int dfh_comm_allreduce_sum(dfh_comm* c, double* vals, int n);
+
+/* this rank's shard of the model + the exchange buffers.  splits: world-1 ascending first keys of
+ * shards 1.., identical on every rank, or NULL for the uniform ranges.  The table must use
+ * DFH_INIT_HASH (order- and sharding-independent V init). */
+int dfh_shard_create(dfh_table* t, dfh_comm* c, const uint64_t* splits, dfh_shard** out);
+int dfh_shard_destroy(dfh_shard* s);
+/* [key_lo, key_hi) owned by this rank (key_hi = 0: no upper bound) — the range to hand dfh_table_load */
+int dfh_shard_owned_range(dfh_shard* s, const uint64_t* splits, uint64_t* key_lo, uint64_t* key_hi);
+/* One step of SGDLearner::IterateData (src/sgd/sgd_learner.cc:131-178) against the sharded model:
+ * keys -> owners, rows back, Predict / Evaluate / CalcGrad on the pulled rows, gradients -> owners,
+ * applied in ascending source-rank order (zero staleness).  COLLECTIVE: every rank calls it the same
+ * number of times with the same is_train / push_cnt; a rank whose data is exhausted passes
+ * b = NULL and keeps serving its shard.  *any_active = 0 when no rank had a minibatch (the step was a
+ * no-op: the epoch is over).  Asynchronous apart from one small host wait; progress accumulates in
+ * the batch as in dfh_sgd_step. */
+int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* any_active);
+
 /* raw device memory for hosts without a HIP runtime of their own */
 int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);
 int dfh_free(dfh_ctx* ctx, void* dptr);

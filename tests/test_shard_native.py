@@ -1,0 +1,189 @@
+"""The sharded store behind the C ABI (dfh_comm / dfh_shard / dfh_shard_step, csrc/dfh_shard.hip):
+the exchange runs inside libdifacto_hip.so — RCCL ncclSend / ncclRecv in production — and every rank
+calls one entry point per minibatch.
+
+  * world 1 over the real RCCL transport: the step must equal the fused single-GPU step;
+  * 2 and 4 ranks sharing the one GPU of the test box through the host-callback transport (gloo
+    carries the bytes; RCCL cannot put two ranks on one device), with UNEVEN numbers of minibatches
+    per rank (a rank whose data is exhausted keeps serving its shard), uniform and balanced key
+    ranges: per-rank logits, loss, penalty and the union of the shards against ONE oracle store that
+    receives the same requests in the documented order (count pushes, pulls, then gradient pushes,
+    each in ascending source-rank order).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HYPER = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=1, V_init_scale=0.2, seed=5)
+V_DIM = 8
+ROWS = 300
+PUSH_CNT_STEPS = 2
+
+
+def nsteps(rank):
+    return 5 - (rank % 2) * 2  # ranks 0, 2: five minibatches; ranks 1, 3: three
+
+
+def make_batches(rank):
+    from conftest import random_batch
+    rng = np.random.default_rng(900 + rank)
+    return [random_batch(rng, ROWS, 2 ** 64 - 1 if i % 2 else 3000, 30, binary=(i % 2 == 0)) for i in range(nsteps(rank))]
+
+
+def emulate(oracle, batches, V_dim, hyper):
+    """ONE store receiving the ranks' requests of every step in ascending rank order"""
+    from oracle import bindings as ob
+    world = len(batches)
+    steps = max(len(b) for b in batches)
+    store = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
+    preds = [[] for _ in range(world)]
+    loss = [0.0] * world
+    for i in range(steps):
+        act = [r for r in range(world) if i < len(batches[r])]
+        locs = {r: oracle.localize(batches[r][i]["offset"], batches[r][i]["index"]) for r in act}
+        if i < PUSH_CNT_STEPS:
+            for r in act:
+                store.push(locs[r]["feaids"], ob.FEA_COUNT, locs[r]["feacnt"])
+        pulled = {r: store.pull(locs[r]["feaids"]) for r in act}
+        grads = {}
+        for r in act:
+            b, loc = batches[r][i], locs[r]
+            vals, lens = pulled[r]
+            wp, vp = oracle.get_pos(lens)
+            p = oracle.fm_predict(V_dim, loc["offset"], loc["index"], b["value"], vals, wp, vp)
+            preds[r].append(p)
+            loss[r] += oracle.loss_evaluate(b["label"], p)
+            grads[r] = oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp)
+        for r in act:
+            store.push(locs[r]["feaids"], ob.GRADIENT, grads[r], pulled[r][1])
+    return store, preds, loss
+
+
+def _worker(rank, world, port, out_dir, balanced):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from difacto_amd import capi, sharded
+    from difacto_amd.synth import reverse_bytes_np
+    ctx = capi.Context(0)
+
+    def exchange(send, sb, recv, rb):  # bytes in, bytes out: gloo all_to_all_v on the host
+        out = torch.empty(sum(rb), dtype=torch.uint8)
+        dist.all_to_all_single(out, torch.from_numpy(np.array(send, copy=True)), output_split_sizes=rb, input_split_sizes=sb)
+        recv[:] = out.numpy()
+
+    comm = capi.Comm.callback(ctx, rank, world, exchange)
+    splits = None
+    if balanced:
+        ids = np.concatenate([b["index"] for r in range(world) for b in make_batches(r)])
+        splits = sharded.balanced_splits(reverse_bytes_np(ids), world)
+    tb = capi.Table(ctx, 1 << 16, V_dim=V_DIM, init_mode=capi.INIT_HASH, **HYPER)
+    sh = capi.Shard(tb, comm, splits)
+    batches = make_batches(rank)
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    bt = capi.Batch(ctx, ROWS, max_nnz)
+    preds, i = [], 0
+    while True:
+        b = batches[i] if i < len(batches) else None
+        if b is not None:
+            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bt.localize()
+        active = sh.step(bt if b is not None else None, is_train=True, push_cnt=i < PUSH_CNT_STEPS)
+        if not active:
+            break
+        if b is not None:
+            preds.append(bt.pred().copy())
+        i += 1
+    assert i == max(nsteps(r) for r in range(world))
+    tb.check()
+    prog = bt.progress()
+    tot = comm.allreduce_sum([prog.loss, prog.nrows, 1.0])
+    assert tot[2] == world
+    from oracle import bindings as ob
+    o = ob.Oracle()
+    allkeys = np.unique(np.concatenate([o.localize(b["offset"], b["index"])["feaids"]
+                                        for r in range(world) for b in make_batches(r)]))
+    sp = sharded.uniform_splits(world) if splits is None else splits
+    mine = allkeys[sharded.owner_of(allkeys, sp) == rank]
+    lo, hi = sh.owned_range()
+    assert (len(mine) == 0 or int(mine.min()) >= lo) and (hi == 0 or len(mine) == 0 or int(mine.max()) < hi)
+    vals, lens = tb.pull(mine)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=prog.loss, penalty=prog.penalty,
+             nrows=prog.nrows, total_loss=tot[0], total_rows=tot[1], nkeys=tb.size(), keys=mine, vals=vals, lens=lens)
+    dist.barrier()
+    for o_ in (sh, bt, tb, comm):
+        o_.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("WORLD,balanced", [(2, False), (4, True)])
+def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced):
+    port = 29700 + (os.getpid() % 80) + WORLD
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), balanced), nprocs=WORLD, join=True)
+    batches = [make_batches(r) for r in range(WORLD)]
+    store, preds, loss = emulate(oracle, batches, V_DIM, HYPER)
+    total, total_loss = 0, 0.0
+    for r in range(WORLD):
+        got = np.load(os.path.join(tmp_path, "rank%d.npz" % r))
+        np.testing.assert_allclose(got["preds"], np.concatenate(preds[r]), rtol=1e-5, atol=1e-6, err_msg="rank %d preds" % r)
+        assert float(got["loss"]) == pytest.approx(loss[r], rel=1e-5)
+        assert float(got["nrows"]) == ROWS * nsteps(r)
+        assert float(got["penalty"]) > 0
+        vals, lens = store.pull(got["keys"])
+        assert np.array_equal(got["lens"], lens)
+        np.testing.assert_allclose(got["vals"], vals, rtol=2e-5, atol=1e-6, err_msg="rank %d owned model" % r)
+        assert np.any(lens > 1)
+        total += int(got["nkeys"])
+        total_loss += loss[r]
+        assert float(got["total_rows"]) == sum(ROWS * nsteps(q) for q in range(WORLD))
+    assert float(got["total_loss"]) == pytest.approx(total_loss, rel=1e-5)
+    assert total == store.size()
+
+
+@pytest.mark.gpu
+def test_shard_step_world1_over_rccl_matches_fused():
+    """one rank over the real transport (RCCL loaded at run time, self send / recv): pull -> packed rows
+    -> k_forward / k_backward_all<.., false, ..> -> push must give what the fused step gives"""
+    from conftest import random_batch
+    from difacto_amd import capi
+    ctx = capi.Context(0)
+    comm = capi.Comm.rccl(ctx, 0, 1, capi.Comm.unique_id())
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
+    rng = np.random.default_rng(77)
+    batches = [random_batch(rng, 200, 4000, 25, binary=(i == 1)) for i in range(3)]
+    ta = capi.Table(ctx, 1 << 15, V_dim=16, **kw)
+    tb = capi.Table(ctx, 1 << 15, V_dim=16, **kw)
+    sh = capi.Shard(tb, comm)
+    max_nnz = max(int(b["offset"][-1]) for b in batches)
+    ba, bb = capi.Batch(ctx, 200, max_nnz), capi.Batch(ctx, 200, max_nnz)
+    for epoch in range(2):
+        for b in batches:
+            for bt in (ba, bb):
+                bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+                bt.localize()
+            ba.sgd_step(ta, is_train=True, push_cnt=(epoch == 0))
+            assert sh.step(bb, is_train=True, push_cnt=(epoch == 0))
+            np.testing.assert_allclose(bb.pred(), ba.pred(), rtol=1e-5, atol=1e-6)
+            pa, pb = ba.progress(), bb.progress()
+            assert pb.loss == pytest.approx(pa.loss, rel=1e-6) and pb.penalty == pytest.approx(pa.penalty, rel=1e-5)
+    assert not sh.step(None)  # nobody has data: the epoch is over
+    ea, eb = ta.export(), tb.export()
+    oa, ob_ = np.argsort(ea["keys"]), np.argsort(eb["keys"])
+    assert np.array_equal(ea["keys"][oa], eb["keys"][ob_]) and np.array_equal(ea["has_V"][oa], eb["has_V"][ob_])
+    np.testing.assert_allclose(eb["scal"][ob_], ea["scal"][oa], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(eb["V"][ob_], ea["V"][oa], rtol=2e-5, atol=1e-6)
+    assert comm.allreduce_sum([1.5, 2.0]).tolist() == [1.5, 2.0]
+    for o in (sh, ba, bb, ta, tb, comm):
+        o.close()
+    ctx.close()
