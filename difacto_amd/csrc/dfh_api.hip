@@ -1668,6 +1668,7 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
   DFH_ARG(max_index != 0, "max_index must be nonzero");
   dfh_ctx* c = b->ctx;
+  DFH_HIP(hipSetDevice(c->device));
   const uint32_t N = (uint32_t)b->nnz;
   {
     int rc = prep_begin(b);
@@ -1805,6 +1806,7 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   }
   dfh_ctx* c = b->ctx;
   if (b->nnz == 0) return DFH_OK;
+  DFH_HIP(hipSetDevice(c->device));
   int rc = prep_begin(b);
   if (rc) return rc;
   {
@@ -1986,6 +1988,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     if (int rca = require_aux(t, "dfh_sgd_step(is_train)")) return rca;
   }
   dfh_ctx* c = t->ctx;
+  DFH_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   const int k = t->v.k, kp = t->v.kp;
   DFH_ARG(kp <= 256, "V_dim > 256 is not supported by the fused step");

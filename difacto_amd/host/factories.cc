@@ -7,6 +7,7 @@
 #include "./hip_fm_loss.h"
 #include "./local_tracker.h"
 #include "./sgd_learner.h"
+#include "./sharded_store.h"
 #include "difacto/learner.h"
 #include "difacto/loss.h"
 #include "difacto/store.h"
@@ -27,21 +28,16 @@ Loss* Loss::Create(const std::string& type, int nthreads) {
   return loss;
 }
 
+// The reference's distributed store is a TODO (store.cc:9-10: LOG(FATAL) << "not implemented"); here
+// DMLC_ROLE selects the key-range-sharded multi-GPU store (one process per GPU, sharded_store.h).
 Store* Store::Create() {
-  if (IsDistributed()) {
-    LOG(FATAL) << "not implemented";  // as the reference (store.cc:9-10); multi-GPU runs go through difacto_amd/sharded.py
-    return nullptr;
-  }
+  if (IsDistributed()) return new ShardedDeviceStore();
   return new DeviceStore();
 }
 
-Tracker* Tracker::Create() {
-  if (IsDistributed()) {
-    LOG(FATAL) << "not implemented";
-    return nullptr;
-  }
-  return new LocalTracker();
-}
+// Every rank runs the scheduler loop itself (same data split, same merged progress, hence the same
+// decisions) and executes its own share of the jobs in-process: no DistTracker is needed.
+Tracker* Tracker::Create() { return new LocalTracker(); }
 
 Learner* Learner::Create(const std::string& type) {
   if (type == "sgd") return new SGDLearner();

@@ -10,6 +10,7 @@
 #include "./hip_fm_loss.h"
 #include "./host_localizer.h"
 #include "./libsvm_reader.h"
+#include "./sharded_store.h"
 #include "data/row_block.h"
 
 namespace difacto {
@@ -79,22 +80,41 @@ void SGDLearner::RunScheduler() {
   if (param_.model_out.size()) SaveModel();
 }
 
-// reference: SGDLearner::RunEpoch, sgd_learner.cc:70-94
+// reference: SGDLearner::RunEpoch, sgd_learner.cc:70-94.  The data is cut into NumWorkers() x
+// num_jobs_per_epoch parts; in a sharded run every rank is its own scheduler and takes the parts
+// j * NumWorkers() + Rank(), then the ranks' progress records are summed so that all of them see the
+// same epoch result (and take the same stopping decision).
 void SGDLearner::RunEpoch(int epoch, int job_type, sgd::Progress* prog) {
   tracker_->SetMonitor([prog](int node_id, const std::string& rets) { prog->Merge(rets); });
-  const int n = store_->NumWorkers() * param_.num_jobs_per_epoch;
-  std::vector<std::pair<int, std::string>> jobs(n);
+  const int nworkers = store_->NumWorkers();
+  const int n = nworkers * param_.num_jobs_per_epoch;
+  const bool sharded = dynamic_cast<ShardedDeviceStore*>(store_) != nullptr;
+  std::vector<std::pair<int, std::string>> jobs;
   for (int i = 0; i < n; ++i) {
-    jobs[i].first = 0;
+    if (sharded && i % nworkers != store_->Rank()) continue;
     sgd::Job job;
     job.type = job_type;
     job.epoch = epoch;
     job.num_parts = n;
     job.part_idx = i;
-    job.SerializeToString(&jobs[i].second);
+    jobs.emplace_back(0, std::string());
+    job.SerializeToString(&jobs.back().second);
   }
   tracker_->Issue(jobs);
   while (tracker_->NumRemains()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+  if (sharded) MergeAcrossRanks(prog);
+}
+
+void SGDLearner::MergeAcrossRanks(sgd::Progress* prog) {
+  auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
+  if (!ss) return;
+  double v[5] = {prog->loss, prog->penalty, prog->auc, prog->nnz_w, prog->nrows};
+  DFH_CALL(dfh_comm_allreduce_sum(ss->comm(), v, 5));
+  prog->loss = static_cast<real_t>(v[0]);
+  prog->penalty = static_cast<real_t>(v[1]);
+  prog->auc = static_cast<real_t>(v[2]);
+  prog->nnz_w = static_cast<real_t>(v[3]);
+  prog->nrows = static_cast<real_t>(v[4]);
 }
 
 // reference: SGDLearner::Process, sgd_learner.h:42-53
@@ -107,7 +127,10 @@ void SGDLearner::Process(const std::string& args, std::string* rets) {
 }
 
 void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
-  if (GetUpdater()->device_param().device_path == "literal") {
+  if (dynamic_cast<ShardedDeviceStore*>(store_)) {
+    CHECK(GetUpdater()->device_param().device_path != "literal") << "the sharded store has no one-sided Push / Pull";
+    IterateDataSharded(job, prog);
+  } else if (GetUpdater()->device_param().device_path == "literal") {
     IterateDataLiteral(job, prog);
   } else {
     IterateDataFused(job, prog);
@@ -194,6 +217,53 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   DFH_CALL(dfh_table_size(table, &nkeys));  // surfaces a full table as an error
 }
 
+// ---- the sharded worker loop: sgd_learner.cc:129-227 with Store::Pull / Push turned into the exchange of
+// dfh_shard_step.  The ranks step together; a rank whose part of the data is exhausted keeps serving
+// its shard (b = NULL) until nobody has a minibatch left.
+void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress) {
+  const bool train = job.type == sgd::Job::kTraining;
+  const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
+  auto* ss = CHECK_NOTNULL(dynamic_cast<ShardedDeviceStore*>(store_));
+  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
+                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  dfh_ctx* ctx = DeviceContext::Get();
+  DFH_CALL(dfh_ctx_set_pipeline(ctx, 0));
+  auto drain = [&](dfh_batch* b) {
+    dfh_progress p;
+    DFH_CALL(dfh_batch_progress(b, &p, 1));
+    sgd::Progress q;
+    q.loss = p.loss; q.penalty = p.penalty; q.auc = p.auc; q.nrows = p.nrows;
+    progress->Merge(q);
+  };
+  int active = 1;
+  while (active) {
+    dfh_batch* b = nullptr;
+    if (reader.Next()) {
+      const auto& blk = reader.Value();
+      const size_t nnz = blk.offset[blk.size] - blk.offset[0];
+      if (!batch_[0] || blk.size > batch_rows_ || nnz > batch_nnz_) {
+        if (batch_[0]) {
+          drain(batch_[0]);
+          dfh_batch_destroy(batch_[0]);
+        }
+        batch_rows_ = std::max<size_t>(blk.size, batch_rows_);
+        batch_nnz_ = std::max(nnz * 2, batch_nnz_);
+        DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &batch_[0]));
+        DFH_CALL(dfh_batch_set_option(batch_[0], "compute_auc", 1));  // sgd_learner.cc:153-155
+      }
+      b = batch_[0];
+      DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
+      DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
+    }
+    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step: batch " << (b ? "yes" : "none");
+    DFH_CALL(dfh_shard_step(ss->shard(), b, train ? 1 : 0, push_cnt ? 1 : 0, &active));
+    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step done: active " << active;
+  }
+  if (batch_[0]) drain(batch_[0]);
+  uint64_t nkeys;
+  DFH_CALL(dfh_table_size(GetUpdater()->table(), &nkeys));  // surfaces a full shard as an error
+}
+
 // reference: SGDLearner::GetPos, sgd_learner.cc:113-127
 void SGDLearner::GetPos(const SArray<int>& len, SArray<int>* w_pos, SArray<int>* V_pos) {
   const size_t n = len.size();
@@ -272,17 +342,39 @@ void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress
   }
 }
 
+// Updater::Save / Load.  A sharded run writes one part per rank (<model_out>.part-<rank>) and reads
+// every part it finds, keeping the keys of its own range: a model can be re-loaded under any number
+// of ranks.
 void SGDLearner::SaveModel() {
-  std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(param_.model_out.c_str(), "w"));
+  auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
+  const std::string path = ss ? param_.model_out + ".part-" + std::to_string(store_->Rank()) : param_.model_out;
+  std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(path.c_str(), "w"));
   GetUpdater()->Save(true, fo.get());
-  LOG(INFO) << "model saved to " << param_.model_out;
+  LOG(INFO) << "model saved to " << path;
 }
 
 void SGDLearner::LoadModel() {
-  std::unique_ptr<dmlc::Stream> fi(dmlc::Stream::Create(param_.model_in.c_str(), "r"));
-  bool has_aux = false;
-  GetUpdater()->Load(fi.get(), &has_aux);
-  LOG(INFO) << "model loaded from " << param_.model_in << (has_aux ? " (with optimiser state)" : "");
+  auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
+  if (!ss) {
+    std::unique_ptr<dmlc::Stream> fi(dmlc::Stream::Create(param_.model_in.c_str(), "r"));
+    bool has_aux = false;
+    GetUpdater()->Load(fi.get(), &has_aux);
+    LOG(INFO) << "model loaded from " << param_.model_in << (has_aux ? " (with optimiser state)" : "");
+    return;
+  }
+  uint64_t lo = 0, hi = 0, total = 0;
+  DFH_CALL(dfh_shard_owned_range(ss->shard(), nullptr, &lo, &hi));
+  int parts = 0;
+  for (;; ++parts) {
+    const std::string path = param_.model_in + ".part-" + std::to_string(parts);
+    if (access(path.c_str(), R_OK) != 0) break;
+    uint64_t n = 0;
+    int aux = 0;
+    DFH_CALL(dfh_table_load(GetUpdater()->table(), path.c_str(), lo, hi, &aux, &n));
+    total += n;
+  }
+  CHECK_GT(parts, 0) << "no model part files " << param_.model_in << ".part-<n>";
+  LOG(INFO) << "rank " << store_->Rank() << ": " << total << " entries of its key range loaded from " << parts << " part files";
 }
 
 }  // namespace difacto

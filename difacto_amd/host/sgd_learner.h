@@ -54,6 +54,9 @@ class SGDLearner : public Learner {
   void IterateData(const sgd::Job& job, sgd::Progress* prog);
   void IterateDataFused(const sgd::Job& job, sgd::Progress* prog);
   void IterateDataLiteral(const sgd::Job& job, sgd::Progress* prog);
+  void IterateDataSharded(const sgd::Job& job, sgd::Progress* prog);
+  /*! \brief sums the record over the ranks of a sharded run (identity for one process) */
+  void MergeAcrossRanks(sgd::Progress* prog);
   real_t EvaluatePenalty(const SArray<real_t>& weights, const SArray<int>& w_pos, const SArray<int>& V_pos);
   void GetPos(const SArray<int>& len, SArray<int>* w_pos, SArray<int>* V_pos);
   void SaveModel();

@@ -1,0 +1,159 @@
+/**
+ * sharded_store.h — ShardedDeviceStore : Store, the model row-sharded by key range over the GPUs
+ * of one node, one process per GPU.  It takes the place of the reference's distributed store
+ * (Store::Create() under DMLC_ROLE, src/store/store.cc:8-15 — KVStoreDist over ps-lite there):
+ * every process is a worker AND the server of one key range; NumWorkers() is the number of ranks, so
+ * SGDLearner::RunEpoch cuts the data into NumWorkers() x num_jobs_per_epoch parts as the reference
+ * does (src/sgd/sgd_learner.cc:78-89).
+ *
+ * The exchange lives inside libdifacto_hip.so (dfh_shard_step: RCCL ncclSend / ncclRecv over xGMI);
+ * this class owns the communicator and the shard handle and exposes them to the learner's sharded
+ * worker loop.  The store is COLLECTIVE — every rank takes part in every step — so the literal,
+ * one-sided Push / Pull of the interface is not offered here: use device_path = fused (the default).
+ *
+ * Process environment (one process per GPU; example/run_local_gpus.sh):
+ *   DMLC_ROLE=worker            distributed mode (include/difacto/base.h: IsDistributed())
+ *   DMLC_NUM_WORKER=<G>         ranks
+ *   DIFACTO_RANK=<r>            this rank, 0 .. G-1 (also the default DIFACTO_DEVICE)
+ *   DIFACTO_RENDEZVOUS=<path>   rank 0 writes the RCCL unique id there, the others read it
+ *   DIFACTO_COMM=rccl|file      transport; "file" (exchange through files in the directory
+ *                               DIFACTO_RENDEZVOUS) exists for tests with several ranks on one GPU
+ */
+#ifndef DIFACTO_HOST_SHARDED_STORE_H_
+#define DIFACTO_HOST_SHARDED_STORE_H_
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <vector>
+#include "./device_store.h"
+
+namespace difacto {
+
+/*! \brief test transport: an all-to-all-v through files in a shared directory */
+class FileExchange {
+ public:
+  FileExchange(const std::string& dir, int rank, int world) : dir_(dir), rank_(rank), world_(world) {}
+  static int Call(void* user, const void* send, const size_t* sb, void* recv, const size_t* rb) {
+    return static_cast<FileExchange*>(user)->Run(static_cast<const char*>(send), sb, static_cast<char*>(recv), rb);
+  }
+
+ private:
+  std::string Name(uint64_t seq, int src, int dst) const {
+    return dir_ + "/ex" + std::to_string(seq) + "." + std::to_string(src) + "." + std::to_string(dst);
+  }
+  int Run(const char* send, const size_t* sb, char* recv, const size_t* rb) {
+    const uint64_t seq = seq_++;
+    size_t off = 0;
+    for (int d = 0; d < world_; ++d) {
+      const std::string fin = Name(seq, rank_, d), tmp = fin + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "wb");
+      if (!f) return 1;
+      if (sb[d] && fwrite(send + off, 1, sb[d], f) != sb[d]) return 1;
+      fclose(f);
+      if (rename(tmp.c_str(), fin.c_str()) != 0) return 1;
+      off += sb[d];
+    }
+    off = 0;
+    for (int s = 0; s < world_; ++s) {
+      const std::string fin = Name(seq, s, rank_);
+      FILE* f = nullptr;
+      for (int tries = 0; tries < 600000 && !(f = fopen(fin.c_str(), "rb")); ++tries)
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+      if (!f) return 1;
+      if (rb[s] && fread(recv + off, 1, rb[s], f) != rb[s]) return 1;
+      fclose(f);
+      unlink(fin.c_str());
+      off += rb[s];
+    }
+    return 0;
+  }
+  std::string dir_;
+  int rank_, world_;
+  uint64_t seq_ = 0;
+};
+
+class ShardedDeviceStore : public Store {
+ public:
+  ShardedDeviceStore() {
+    const char* w = getenv("DMLC_NUM_WORKER");
+    const char* r = getenv("DIFACTO_RANK");
+    world_ = w ? atoi(w) : 1;
+    rank_ = r ? atoi(r) : 0;
+    CHECK(world_ >= 1 && world_ <= 32 && rank_ >= 0 && rank_ < world_)
+        << "DMLC_NUM_WORKER (1..32) / DIFACTO_RANK (0..DMLC_NUM_WORKER-1) are not consistent";
+    // one GPU per rank, unless the launcher already narrowed the visible devices to this rank's
+    if (!getenv("DIFACTO_DEVICE") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("ROCR_VISIBLE_DEVICES"))
+      setenv("DIFACTO_DEVICE", std::to_string(rank_).c_str(), 0);
+  }
+  virtual ~ShardedDeviceStore() {
+    if (shard_) dfh_shard_destroy(shard_);
+    if (comm_) dfh_comm_destroy(comm_);
+  }
+
+  /*! \brief connects the ranks; called after SetUpdater (sgd_learner.cc:234-240), so the shard's table exists */
+  KWArgs Init(const KWArgs& kwargs) override {
+    auto* up = CHECK_NOTNULL(dynamic_cast<DeviceSGDUpdater*>(CHECK_NOTNULL(updater_.get())));
+    CHECK(up->device_param().V_init == "hash" || up->param().V_dim == 0)
+        << "the sharded store needs V_init=hash: the rand_r chain of the reference depends on the global order of allocations";
+    const char* rv = getenv("DIFACTO_RENDEZVOUS");
+    const char* kind = getenv("DIFACTO_COMM");
+    CHECK(rv || world_ == 1) << "DIFACTO_RENDEZVOUS must name the rendezvous file (rccl) or directory (file transport)";
+    dfh_ctx* ctx = DeviceContext::Get();
+    if (kind && std::string(kind) == "file") {
+      files_.reset(new FileExchange(rv ? rv : "/tmp", rank_, world_));
+      DFH_CALL(dfh_comm_create_callback(ctx, rank_, world_, &FileExchange::Call, files_.get(), &comm_));
+    } else {
+      char id[DFH_COMM_ID_BYTES];
+      if (rank_ == 0) {
+        DFH_CALL(dfh_comm_unique_id(id));
+        if (world_ > 1) {
+          const std::string tmp = std::string(rv) + ".tmp";
+          FILE* f = CHECK_NOTNULL(fopen(tmp.c_str(), "wb"));
+          CHECK_EQ(fwrite(id, 1, sizeof(id), f), sizeof(id));
+          fclose(f);
+          CHECK_EQ(rename(tmp.c_str(), rv), 0);
+        }
+      } else {
+        FILE* f = nullptr;
+        for (int tries = 0; tries < 120000 && !(f = fopen(rv, "rb")); ++tries)
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        CHECK(f) << "rank 0 never wrote the rendezvous file " << rv;
+        CHECK_EQ(fread(id, 1, sizeof(id), f), sizeof(id));
+        fclose(f);
+      }
+      DFH_CALL(dfh_comm_create_rccl(ctx, rank_, world_, id, &comm_));
+    }
+    DFH_CALL(dfh_shard_create(up->table(), comm_, nullptr, &shard_));
+    LOG(INFO) << "sharded store: rank " << rank_ << " of " << world_ << " connected ("
+              << (files_ ? "file transport" : "RCCL") << ")";
+    return kwargs;
+  }
+
+  int Push(const SArray<feaid_t>&, int, const SArray<real_t>&, const SArray<int>&, const std::function<void()>&) override {
+    LOG(FATAL) << "the sharded store is collective: one-sided Push is not available (use device_path=fused)";
+    return 0;
+  }
+  int Pull(const SArray<feaid_t>&, int, SArray<real_t>*, SArray<int>*, const std::function<void()>&) override {
+    LOG(FATAL) << "the sharded store is collective: one-sided Pull is not available (use device_path=fused)";
+    return 0;
+  }
+  void Wait(int time) override {}
+  int Rank() override { return rank_; }
+  int NumWorkers() override { return world_; }
+  int NumServers() override { return world_; }
+
+  dfh_shard* shard() { return shard_; }
+  dfh_comm* comm() { return comm_; }
+
+ private:
+  int rank_ = 0, world_ = 1;
+  dfh_comm* comm_ = nullptr;
+  dfh_shard* shard_ = nullptr;
+  std::unique_ptr<FileExchange> files_;
+};
+
+}  // namespace difacto
+#endif  // DIFACTO_HOST_SHARDED_STORE_H_

@@ -25,13 +25,13 @@ class Learner {
 
   virtual KWArgs Init(const KWArgs& kwargs);
 
-  void Run() {
-    if (!IsDistributed() || !strcmp(getenv("DMLC_ROLE"), "scheduler")) {
-      RunScheduler();
-    } else {
-      tracker_->Wait();
-    }
-  }
+  /**
+   * \brief the reference runs the scheduler loop on the scheduler node and parks the other roles in
+   * the tracker (learner.h:38-45).  The multi-GPU build has no separate scheduler process: every rank
+   * runs the (deterministic) loop itself on the same merged progress, and executes its own share of
+   * the jobs — see Tracker::Create and SGDLearner::RunEpoch.
+   */
+  void Run() { RunScheduler(); }
   void Stop() { tracker_->Stop(); }
 
  protected:

@@ -75,3 +75,66 @@ def test_cli_trains_from_conf(built, tmp_path):
     assert r2.returncode == 0 and "model loaded from" in r2.stderr
     first = [float(l.split("loss = ")[1].split(",")[0]) for l in r2.stderr.splitlines() if "Training: loss" in l][0]
     assert first < losses[0]
+
+
+def _hash_conf(tmp_path, epochs, batch_size=100):
+    """example/rcv1_fm.conf with the order-independent V init the sharded store needs (the text of an
+    argfile is parsed after the command line, so its keys win: edit the file, not the arguments)"""
+    text = open(os.path.join(ROOT, "example", "rcv1_fm.conf")).read().replace("V_init = refrand", "V_init = hash")
+    text = text.replace("max_num_epochs = 10", "max_num_epochs = %d" % epochs).replace("batch_size = 100", "batch_size = %d" % batch_size)
+    assert "V_init = hash" in text and "max_num_epochs = %d" % epochs in text
+    path = os.path.join(tmp_path, "rcv1_fm_hash_%d_%d.conf" % (epochs, batch_size))
+    open(path, "w").write(text)
+    return path
+
+
+def _losses(stderr):
+    return [float(l.split("loss = ")[1].split(",")[0]) for l in stderr.splitlines() if "Training: loss" in l]
+
+
+@pytest.mark.gpu
+def test_cli_sharded_store_one_rank_matches_plain_run(built, tmp_path):
+    """DMLC_ROLE selects the sharded store (Store::Create, factories.cc): with one rank over RCCL the
+    worker loop through dfh_shard_step must train exactly like the plain fused loop"""
+    args = [os.path.join(built, "difacto"), "argfile=" + _hash_conf(tmp_path, 4)]
+    plain = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env = dict(os.environ, DMLC_ROLE="worker", DMLC_NUM_WORKER="1", DIFACTO_RANK="0", DIFACTO_DEVICE="0")
+    shard = subprocess.run(args + ["model_out=" + os.path.join(tmp_path, "m")], capture_output=True, text=True, timeout=600,
+                           cwd=ROOT, env=env)
+    print(shard.stderr[-3000:])
+    assert plain.returncode == 0 and shard.returncode == 0
+    a, b = _losses(plain.stderr), _losses(shard.stderr)
+    assert len(a) == len(b) and len(a) >= 2  # the validation-AUC criterion may stop both runs early
+    assert all(abs(x - y) <= 2e-4 * abs(x) for x, y in zip(a, b)), (a, b)
+    assert os.path.getsize(os.path.join(tmp_path, "m.part-0")) > 100
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_share_the_gpu_over_files(built, tmp_path):
+    """build/difacto as TWO processes (DMLC_NUM_WORKER=2) on the one GPU of the test box, the exchange of
+    dfh_shard_step carried by the file transport (RCCL cannot put two ranks on one device): both ranks
+    must report the same merged progress, the loss must fall, every rank writes its model part, and a
+    single process can load the union of the parts"""
+    rv = os.path.join(tmp_path, "rv")
+    os.makedirs(rv)
+    model = os.path.join(tmp_path, "model")
+    args = [os.path.join(built, "difacto"), "argfile=" + _hash_conf(tmp_path, 5, 25), "model_out=" + model]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, DMLC_ROLE="worker", DMLC_NUM_WORKER="2", DIFACTO_RANK=str(r), DIFACTO_DEVICE="0",
+                   DIFACTO_COMM="file", DIFACTO_RENDEZVOUS=rv)
+        procs.append(subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        print(err[-2500:])
+        assert p.returncode == 0
+    l0, l1 = _losses(outs[0][1]), _losses(outs[1][1])
+    assert len(l0) >= 2 and l0 == l1, (l0, l1)          # the merged record is identical on both ranks
+    assert l0[-1] < l0[0]
+    from difacto_amd import capi
+    ctx = capi.Context(0)
+    tb = capi.Table(ctx, 1 << 17, V_dim=8, init_mode=capi.INIT_HASH)
+    n = sum(tb.load(model + ".part-%d" % r)[0] for r in range(2))
+    assert n > 1000 and tb.size() == n
+    tb.close()
+    ctx.close()
