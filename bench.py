@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--exchange", choices=["sync", "overlap"], default="sync",
                     help="N>1: one minibatch at a time (zero staleness, the headline), or two in flight with the exchange "
                          "hidden behind compute (staleness 1, what the reference's batch tracker does, sgd_learner.cc:219-223)")
+    ap.add_argument("--transport", choices=["native", "torch"], default="native",
+                    help="N>1: the exchange inside libdifacto_hip.so (dfh_shard_step, RCCL ncclSend/ncclRecv; the product path) or "
+                         "the Python harness over torch.distributed (difacto_amd/sharded.py; also offers --exchange overlap)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     args = ap.parse_args()
@@ -221,6 +224,8 @@ def main():
         return subprocess.call(cmd)
     if args.gpus > 1 or world > 1 or args.force_sharded:
         from difacto_amd import sharded
+        if args.transport == "native" and args.exchange == "sync":
+            return sharded.bench_main_native(args, rank, world, local_rank, args.hyper)
         return sharded.bench_main(args, rank, world, local_rank, args.hyper)
 
     import torch  # device plumbing only: barrier-equivalent sync + sanity that a GPU exists
