@@ -1,0 +1,495 @@
+/**
+ * batch_reader.h — the data side of the worker loop: Reader + BatchReader of the reference
+ * (src/reader/reader.h:27-58, src/reader/batch_reader.{h,cc}) over this build's own file splitting
+ * and parsers (dmlc-core's InputSplit / LibSVMParser / RecordIO are an absent submodule):
+ *
+ *   format      source                                   parser here
+ *   libsvm      "label idx:val ..." text                 LibsvmChunkParser   (ids taken as they are)
+ *   criteo      criteo CTR text, label + 13 + 26         CriteoChunkParser   src/reader/criteo_parser.h:40-94
+ *   criteo_test the same without the label column        CriteoChunkParser(is_train = false)
+ *   rec         RecordIO of LZ4 CompressedRowBlocks      CrbRecordParser     src/reader/crb_parser.h:30-40,
+ *                                                                            src/data/compressed_row_block.h:56-75
+ *
+ * A file is cut into num_parts byte ranges; text parts start at the first line start at or after
+ * their first byte and end with the line crossing their last; RecordIO parts at record heads (the
+ * magic word at a 4-byte-aligned position followed by a head or whole-record flag).  Rows come in
+ * chunks (a chunk of text / one record), parsed by a background thread one chunk ahead of the
+ * consumer — the overlap the reference gets from dmlc's ThreadedParser (reader.h:44).
+ *
+ * BatchReader::Next() fills minibatches of batch_size rows across chunk borders, with the optional
+ * shuffle buffer (a nested reader of shuffle_buf_size rows whose order is permuted) and negative
+ * down-sampling of batch_reader.cc:32-77, and drops an all-ones value array (:71-73).
+ */
+#ifndef DIFACTO_HOST_BATCH_READER_H_
+#define DIFACTO_HOST_BATCH_READER_H_
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "./cityhash.h"
+#include "./lz4_block.h"
+#include "data/row_block.h"
+#include "difacto/base.h"
+
+namespace difacto {
+
+typedef dmlc::data::RowBlockContainer<feaid_t> RowChunk;
+
+/*! \brief a parser yields the rows of its part of the file chunk by chunk */
+class ChunkParser {
+ public:
+  virtual ~ChunkParser() {}
+  /*! \brief fills *out (cleared first) with the next chunk of rows; false at the end of the part */
+  virtual bool ParseNext(RowChunk* out) = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// text: byte range [beg, end) of the file, whole lines, ~chunk_bytes at a time
+// ---------------------------------------------------------------------------------------------
+class TextChunks {
+ public:
+  TextChunks(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes) : chunk_bytes_(chunk_bytes) {
+    fp_ = fopen(uri.c_str(), "rb");
+    CHECK(fp_ != nullptr) << "cannot open " << uri;
+    fseek(fp_, 0, SEEK_END);
+    const long size = ftell(fp_);
+    long beg = size / nparts * part;
+    end_ = (part + 1 == nparts) ? size : size / nparts * (part + 1);
+    if (beg > 0) {  // the part starts at the first line start at or after beg
+      fseek(fp_, beg - 1, SEEK_SET);
+      int c;
+      while ((c = fgetc(fp_)) != EOF && c != '\n') {}
+    } else {
+      fseek(fp_, 0, SEEK_SET);
+    }
+  }
+  ~TextChunks() { if (fp_) fclose(fp_); }
+  /*! \brief next run of whole lines (no trailing partial line); false when the part is exhausted */
+  bool Next(std::string* buf) {
+    buf->clear();
+    long pos = ftell(fp_);
+    if (pos >= end_) return false;
+    const size_t want = std::min<size_t>(chunk_bytes_, static_cast<size_t>(end_ - pos));
+    buf->resize(want);
+    const size_t got = fread(&(*buf)[0], 1, want, fp_);
+    buf->resize(got);
+    if (got == 0) return false;
+    if (buf->back() != '\n') {  // finish the line that crosses the chunk (or the part) border
+      int c;
+      while ((c = fgetc(fp_)) != EOF) {
+        buf->push_back(static_cast<char>(c));
+        if (c == '\n') break;
+      }
+    }
+    return true;
+  }
+
+ private:
+  FILE* fp_ = nullptr;
+  long end_ = 0;
+  size_t chunk_bytes_;
+};
+
+/*! \brief "label idx[:val] idx[:val] ..." per line; '#' starts a comment line */
+class LibsvmChunkParser : public ChunkParser {
+ public:
+  LibsvmChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes)
+      : src_(uri, part, nparts, chunk_bytes) {}
+  bool ParseNext(RowChunk* out) override {
+    out->Clear();
+    while (out->Size() == 0) {
+      if (!src_.Next(&buf_)) return false;
+      const char* p = buf_.c_str();
+      const char* const end = p + buf_.size();
+      while (p < end) {
+        const char* eol = static_cast<const char*>(memchr(p, '\n', end - p));
+        if (!eol) eol = end;
+        ParseLine(p, eol, out);
+        p = eol + 1;
+      }
+    }
+    return true;
+  }
+
+ private:
+  static void ParseLine(const char* p, const char* eol, RowChunk* out) {
+    while (p < eol && (*p == ' ' || *p == '\t')) ++p;
+    if (p >= eol || *p == '#' || *p == '\r') return;
+    char* e;
+    const float label = strtof(p, &e);  // the buffer is NUL-terminated past eol; numbers never span lines
+    CHECK(e != p) << "bad libsvm line: " << std::string(p, eol - p);
+    p = e;
+    out->label.push_back(label);
+    for (;;) {
+      while (p < eol && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+      if (p >= eol) break;
+      const feaid_t id = strtoull(p, &e, 10);
+      CHECK(e != p) << "bad libsvm token in: " << std::string(p, eol - p);
+      p = e;
+      float v = 1.0f;
+      if (p < eol && *p == ':') {
+        ++p;
+        v = strtof(p, &e);
+        p = e;
+      }
+      out->index.push_back(id);
+      out->value.push_back(v);
+    }
+    out->offset.push_back(out->index.size());
+  }
+  TextChunks src_;
+  std::string buf_;
+};
+
+/**
+ * \brief criteo CTR text (src/reader/criteo_parser.h:40-94): tab-separated
+ *   <label> <13 integer features> <26 categorical features of 8 hex characters>
+ * an empty field is a missing feature; feature i of a row becomes the id
+ *   EncodeFeaGrpID(CityHash64(token), i, 12) = (hash << 12) | i     (:72, :84; base.h:60-63)
+ * and the row has no values (binary).
+ */
+class CriteoChunkParser : public ChunkParser {
+ public:
+  CriteoChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes, bool is_train)
+      : src_(uri, part, nparts, chunk_bytes), is_train_(is_train) {}
+  bool ParseNext(RowChunk* out) override {
+    out->Clear();
+    while (out->Size() == 0) {
+      if (!src_.Next(&buf_)) return false;
+      Parse(&buf_[0], &buf_[0] + buf_.size(), is_train_, out);
+    }
+    return true;
+  }
+  /*! \brief the reference's parse loop over one chunk of text */
+  static void Parse(const char* p, const char* end, bool is_train, RowChunk* blk) {
+    while (p != end) {
+      while (p != end && (*p == '\r' || *p == '\n')) ++p;
+      if (p == end) break;
+      const char* pp;
+      if (is_train) {  // :59-66
+        pp = Find(p, end, '\t');
+        CHECK(p != pp) << "no label.., try criteo_test";
+        blk->label.push_back(static_cast<float>(atof(p)));
+        p = pp == end ? end : pp + 1;
+      } else {
+        blk->label.push_back(0);
+      }
+      for (feaid_t i = 0; i < 13 && p != end; ++i) {  // :69-76 integer features
+        pp = Find(p, end, '\t');
+        if (pp > p) blk->index.push_back(EncodeFeaGrpID(CityHash64(p, pp - p), static_cast<int>(i), 12));
+        p = pp == end ? end : pp + 1;
+      }
+      for (int i = 0; i < 26; ++i) {  // :79-90 categorical features
+        if (p == end) break;
+        if (*p == '\n' || *p == '\r') break;  // short row
+        if (isspace(static_cast<unsigned char>(*p))) { ++p; continue; }  // missing feature
+        CHECK_GE(end - p, 8) << "truncated categorical feature";
+        pp = p + 8;
+        CHECK(pp == end || isspace(static_cast<unsigned char>(*pp))) << "categorical feature " << i << " is not 8 characters";
+        blk->index.push_back(EncodeFeaGrpID(CityHash64(p, 8), i + 13, 12));
+        if (pp == end) { p = end; break; }
+        p = pp + 1;
+        if (*pp == '\n' || *pp == '\r') break;
+      }
+      blk->offset.push_back(blk->index.size());
+    }
+  }
+
+ private:
+  static const char* Find(const char* p, const char* end, int c) {
+    while (p != end && *p != c) ++p;
+    return p;
+  }
+  TextChunks src_;
+  bool is_train_;
+  std::string buf_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// RecordIO (dmlc-core include/dmlc/recordio.h, restated from its published format): records are
+//   [magic 0xced7230a][lrec = cflag << 29 | length][payload padded to 4 bytes]
+// cflag 0: whole record; 1 / 2 / 3: first / middle / last part of a record whose payload contained
+// the magic word at an aligned position (the writer cuts there and drops the word; the reader puts
+// it back between the parts).
+// ---------------------------------------------------------------------------------------------
+class RecordIOPart {
+ public:
+  static const uint32_t kMagic = 0xced7230a;
+  RecordIOPart(const std::string& uri, unsigned part, unsigned nparts) {
+    fp_ = fopen(uri.c_str(), "rb");
+    CHECK(fp_ != nullptr) << "cannot open " << uri;
+    fseek(fp_, 0, SEEK_END);
+    const long size = ftell(fp_);
+    long beg = size / nparts * part;
+    end_ = (part + 1 == nparts) ? size : size / nparts * (part + 1);
+    beg = (beg + 3) & ~3L;
+    // the part starts at the first record head at or after beg
+    fseek(fp_, beg, SEEK_SET);
+    uint32_t w[2];
+    long pos = beg;
+    while (pos + 8 <= size) {
+      fseek(fp_, pos, SEEK_SET);
+      if (fread(w, 4, 2, fp_) != 2) break;
+      const uint32_t flag = (w[1] >> 29U) & 7U;
+      if (w[0] == kMagic && (flag == 0 || flag == 1)) break;
+      pos += 4;
+    }
+    pos_ = pos;
+    fseek(fp_, pos_, SEEK_SET);
+  }
+  ~RecordIOPart() { if (fp_) fclose(fp_); }
+  /*! \brief next whole record whose head lies inside the part */
+  bool NextRecord(std::string* rec) {
+    rec->clear();
+    if (pos_ >= end_) return false;
+    for (;;) {
+      uint32_t h[2];
+      if (fread(h, 4, 2, fp_) != 2) {
+        CHECK(rec->empty()) << "truncated RecordIO file";
+        return false;
+      }
+      CHECK_EQ(h[0], kMagic) << "invalid RecordIO file";
+      const uint32_t flag = (h[1] >> 29U) & 7U, len = h[1] & ((1U << 29U) - 1U);
+      const uint32_t padded = (len + 3U) & ~3U;
+      const size_t at = rec->size();
+      rec->resize(at + padded);
+      if (padded) CHECK_EQ(fread(&(*rec)[at], 1, padded, fp_), padded) << "truncated RecordIO file";
+      rec->resize(at + len);
+      pos_ += 8 + padded;
+      if (flag == 0 || flag == 3) break;
+      const uint32_t m = kMagic;
+      rec->append(reinterpret_cast<const char*>(&m), 4);
+    }
+    return true;
+  }
+
+ private:
+  FILE* fp_ = nullptr;
+  long pos_ = 0, end_ = 0;
+};
+
+/*! \brief CompressedRowBlock::Decompress (src/data/compressed_row_block.h:56-75, :120-133) */
+inline void DecompressRowBlock(const char* data, size_t size, RowChunk* blk) {
+  static const int kCrbMagic = 1196140743;
+  size_t cur = 0;
+  auto read_int = [&]() {
+    CHECK_LE(cur + sizeof(int), size) << "truncated compressed row block";
+    int v;
+    memcpy(&v, data + cur, sizeof(int));
+    cur += sizeof(int);
+    return v;
+  };
+  auto inflate = [&](void* dst, size_t bytes) {
+    const int cp = read_int();
+    if (cp <= 0) return false;  // array absent
+    CHECK_LE(cur + cp, size) << "truncated compressed row block";
+    CHECK_EQ(Lz4DecompressBlock(data + cur, cp, static_cast<char*>(dst), bytes), static_cast<long>(bytes))
+        << "corrupt LZ4 block in a compressed row block";
+    cur += cp;
+    return true;
+  };
+  blk->Clear();
+  CHECK_EQ(read_int(), kCrbMagic) << "wrong data format";
+  CHECK_EQ(read_int(), static_cast<int>(sizeof(feaid_t))) << "wrong indextype";
+  const int nrows = read_int();
+  CHECK_GE(nrows, 0);
+  blk->label.resize(nrows);
+  if (!inflate(blk->label.data(), nrows * sizeof(real_t))) blk->label.clear();
+  blk->offset.resize(nrows + 1);
+  CHECK(inflate(blk->offset.data(), (nrows + 1) * sizeof(size_t))) << "compressed row block without offsets";
+  const size_t nnz = blk->offset[nrows] - blk->offset[0];
+  if (blk->offset[0] != 0) for (auto& o : blk->offset) o -= blk->offset[0];
+  blk->index.resize(nnz);
+  if (!inflate(blk->index.data(), nnz * sizeof(feaid_t))) blk->index.clear();
+  blk->value.resize(nnz);
+  if (!inflate(blk->value.data(), nnz * sizeof(real_t))) blk->value.clear();
+  blk->weight.resize(nrows);
+  if (!inflate(blk->weight.data(), nrows * sizeof(real_t))) blk->weight.clear();
+  if (blk->label.empty()) blk->label.assign(nrows, 0);
+}
+
+/*! \brief one RecordIO record = one compressed row block (src/reader/crb_parser.h:30-40) */
+class CrbRecordParser : public ChunkParser {
+ public:
+  CrbRecordParser(const std::string& uri, unsigned part, unsigned nparts) : src_(uri, part, nparts) {}
+  bool ParseNext(RowChunk* out) override {
+    out->Clear();
+    while (out->Size() == 0) {
+      if (!src_.NextRecord(&rec_)) return false;
+      CHECK_NE(rec_.size(), 0u);
+      DecompressRowBlock(rec_.data(), rec_.size(), out);
+    }
+    return true;
+  }
+
+ private:
+  RecordIOPart src_;
+  std::string rec_;
+};
+
+/*! \brief Reader (src/reader/reader.h:27-58): format -> parser, one chunk parsed ahead on a thread */
+class Reader {
+ public:
+  Reader(const std::string& uri, const std::string& format, unsigned part, unsigned nparts, size_t chunk_bytes = 1 << 24) {
+    if (format == "libsvm") {
+      parser_.reset(new LibsvmChunkParser(uri, part, nparts, chunk_bytes));
+    } else if (format == "criteo") {
+      parser_.reset(new CriteoChunkParser(uri, part, nparts, chunk_bytes, true));
+    } else if (format == "criteo_test") {
+      parser_.reset(new CriteoChunkParser(uri, part, nparts, chunk_bytes, false));
+    } else if (format == "rec") {
+      parser_.reset(new CrbRecordParser(uri, part, nparts));
+    } else {
+      LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test and rec)";
+    }
+    worker_ = std::thread([this] { Produce(); });
+  }
+  ~Reader() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (worker_.joinable()) worker_.join();
+  }
+  bool Next() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return ready_ || done_; });
+    if (!ready_) return false;
+    std::swap(cur_, next_);
+    ready_ = false;
+    lk.unlock();
+    cv_.notify_all();
+    blk_ = cur_.GetBlock();
+    return true;
+  }
+  const dmlc::RowBlock<feaid_t>& Value() const { return blk_; }
+
+ private:
+  void Produce() {
+    RowChunk tmp;
+    for (;;) {
+      const bool ok = parser_->ParseNext(&tmp);
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [this] { return !ready_ || stop_; });
+      if (stop_) return;
+      if (!ok) {
+        done_ = true;
+        lk.unlock();
+        cv_.notify_all();
+        return;
+      }
+      next_.Clear();
+      std::swap(next_, tmp);
+      ready_ = true;
+      lk.unlock();
+      cv_.notify_all();
+    }
+  }
+  std::unique_ptr<ChunkParser> parser_;
+  std::thread worker_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool ready_ = false, done_ = false, stop_ = false;
+  RowChunk cur_, next_;
+  dmlc::RowBlock<feaid_t> blk_;
+};
+
+/*! \brief BatchReader (src/reader/batch_reader.{h,cc}) */
+class BatchReader {
+ public:
+  BatchReader(const std::string& uri, const std::string& format, unsigned part_index, unsigned num_parts, unsigned batch_size,
+              unsigned shuffle_buf_size = 0, float neg_sampling = 1.0f)
+      : batch_size_(batch_size), shuf_buf_(shuffle_buf_size), neg_sampling_(neg_sampling) {
+    CHECK_GT(batch_size, 0u);
+    if (shuf_buf_) {
+      CHECK_GE(shuf_buf_, batch_size_);
+      buf_reader_.reset(new BatchReader(uri, format, part_index, num_parts, shuf_buf_));
+    } else {
+      reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 24));
+    }
+  }
+
+  /*! \brief next minibatch; false when the part is exhausted (batch_reader.cc:32-77) */
+  bool Next() {
+    batch_.Clear();
+    while (batch_.offset.size() < batch_size_ + 1) {
+      if (start_ == end_) {
+        if (shuf_buf_ == 0) {
+          if (!reader_->Next()) break;
+          in_blk_ = reader_->Value();
+        } else {
+          if (!buf_reader_->Next()) break;
+          in_blk_ = buf_reader_->Value();
+          if (rdp_.size() != in_blk_.size) {
+            rdp_.resize(in_blk_.size);
+            for (size_t i = 0; i < in_blk_.size; ++i) rdp_[i] = static_cast<unsigned>(i);
+          }
+          std::random_shuffle(rdp_.begin(), rdp_.end());  // as the reference: libstdc++'s rand()-driven shuffle
+        }
+        start_ = 0;
+        end_ = in_blk_.size;
+      }
+      const size_t len = std::min(end_ - start_, batch_size_ + 1 - batch_.offset.size());
+      if (shuf_buf_ == 0 && neg_sampling_ == 1.0f) {
+        Push(start_, len);
+      } else {
+        for (size_t i = start_; i < start_ + len; ++i) {
+          const size_t j = shuf_buf_ ? rdp_[i] : i;  // (the reference reads an unset rdp_ here when only sampling)
+          const float p = static_cast<float>(rand_r(&seed_)) / static_cast<float>(RAND_MAX);
+          if (neg_sampling_ < 1.0f && in_blk_.label[j] <= 0 && p > 1 - neg_sampling_) continue;
+          Push(j, 1);
+        }
+      }
+      start_ += len;
+    }
+    bool binary = true;
+    for (auto f : batch_.value)
+      if (f != 1) { binary = false; break; }
+    if (binary) batch_.value.clear();
+    out_blk_ = batch_.GetBlock();
+    return out_blk_.size > 0;
+  }
+  const dmlc::RowBlock<feaid_t>& Value() const { return out_blk_; }
+
+ private:
+  void Push(size_t pos, size_t len) {  // batch_reader.cc:80-96
+    if (!len) return;
+    CHECK_LE(pos + len, in_blk_.size);
+    dmlc::RowBlock<feaid_t> slice;
+    slice.weight = nullptr;
+    slice.size = len;
+    slice.offset = in_blk_.offset + pos;
+    slice.label = in_blk_.label + pos;
+    slice.index = in_blk_.index + in_blk_.offset[pos];
+    slice.value = in_blk_.value ? in_blk_.value + in_blk_.offset[pos] : nullptr;
+    PushSlice(slice);
+  }
+  // a file may mix blocks with and without a value array (binary blocks drop it,
+  // compressed_row_block.h:36-44): inside one minibatch a missing array means ones
+  void PushSlice(const dmlc::RowBlock<feaid_t>& slice) {
+    const size_t nnz_before = batch_.index.size();
+    const size_t nnz = slice.offset[slice.size] - slice.offset[0];
+    if (slice.value && batch_.value.size() < nnz_before) batch_.value.resize(nnz_before, 1.0f);
+    batch_.Push(slice);
+    if (!slice.value && !batch_.value.empty()) batch_.value.resize(nnz_before + nnz, 1.0f);
+  }
+  unsigned batch_size_, shuf_buf_;
+  float neg_sampling_;
+  std::unique_ptr<Reader> reader_;
+  std::unique_ptr<BatchReader> buf_reader_;
+  size_t start_ = 0, end_ = 0;
+  dmlc::RowBlock<feaid_t> in_blk_, out_blk_;
+  RowChunk batch_;
+  std::vector<unsigned> rdp_;
+  unsigned int seed_ = 0;
+};
+
+}  // namespace difacto
+#endif  // DIFACTO_HOST_BATCH_READER_H_

@@ -32,8 +32,9 @@ SGDLearner::~SGDLearner() {
 KWArgs SGDLearner::Init(const KWArgs& kwargs) {
   auto remain = Learner::Init(kwargs);
   remain = param_.InitAllowUnknown(remain);
-  CHECK(param_.data_format == "libsvm") << "data_format " << param_.data_format
-                                         << " is not supported by this build (libsvm text only)";
+  CHECK(param_.data_format == "libsvm" || param_.data_format == "criteo" || param_.data_format == "criteo_test" ||
+        param_.data_format == "rec")
+      << "data_format " << param_.data_format << " is not supported by this build (libsvm, criteo, criteo_test, rec)";
   auto updater = new DeviceSGDUpdater();
   remain = updater->Init(remain);
   remain.push_back(std::make_pair("V_dim", std::to_string(updater->param().V_dim)));
@@ -141,8 +142,8 @@ void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
 void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
-  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
-                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   dfh_ctx* ctx = DeviceContext::Get();
   dfh_table* table = GetUpdater()->table();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
@@ -224,8 +225,8 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
   const bool train = job.type == sgd::Job::kTraining;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
   auto* ss = CHECK_NOTNULL(dynamic_cast<ShardedDeviceStore*>(store_));
-  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
-                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   dfh_ctx* ctx = DeviceContext::Get();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 0));
   auto drain = [&](dfh_batch* b) {
@@ -308,8 +309,8 @@ real_t SGDLearner::EvaluatePenalty(const SArray<real_t>& weights, const SArray<i
 void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool push_cnt = train && job.epoch == 0;
-  LibsvmBatchReader reader(train ? param_.data_in : param_.data_val, job.part_idx, job.num_parts, param_.batch_size,
-                           train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   while (reader.Next()) {
     dmlc::data::RowBlockContainer<unsigned> data;
     auto feaids = std::make_shared<std::vector<feaid_t>>();

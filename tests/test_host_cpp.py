@@ -138,3 +138,35 @@ def test_cli_two_ranks_share_the_gpu_over_files(built, tmp_path):
     assert n > 1000 and tb.size() == n
     tb.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
+    """data_format = criteo (CityHash64 + slot tag) and data_format = rec (RecordIO of LZ4 compressed row
+    blocks): the formats of the reference's example/criteo_sgd.conf.  The same rows in both formats
+    must give the same training trajectory."""
+    import numpy as np
+    from oracle import ingest as oi
+    from test_ingest import _criteo_text
+    rng = np.random.default_rng(21)
+    text = _criteo_text(rng, 3000)
+    txt = os.path.join(tmp_path, "train.criteo")
+    open(txt, "wb").write(text)
+    off, lab, idx = oi.parse_criteo(text)
+    recs = []
+    for a in range(0, 3000, 500):   # six compressed row blocks of 500 rows
+        o = off[a:a + 501] - off[a]
+        recs.append(oi.write_crb_record(o, lab[a:a + 500], idx[int(off[a]):int(off[a + 500])]))
+    rec = os.path.join(tmp_path, "train.rec")
+    open(rec, "wb").write(oi.write_recordio(recs))
+    common = ["task=train", "learner=sgd", "batch_size=500", "max_num_epochs=3", "V_dim=4", "V_threshold=0", "l1=.01", "lr=.1",
+              "V_lr=.05", "V_init=hash", "table_capacity=262144", "stop_rel_objv=0"]
+    runs = []
+    for fmt, path in (("criteo", txt), ("rec", rec)):
+        r = subprocess.run([os.path.join(built, "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
+                           capture_output=True, text=True, timeout=180, cwd=ROOT)
+        print(r.stderr[-1500:])
+        assert r.returncode == 0
+        runs.append(_losses(r.stderr))
+    assert len(runs[0]) == 3 and runs[0] == runs[1], runs
+    assert runs[0][-1] < runs[0][0]

@@ -1,0 +1,201 @@
+"""CPU tests of the data formats either side of the path, host code only:
+difacto_amd/host/{cityhash,lz4_block,batch_reader}.h through build/libdifacto_ingest.so (ctypes) against
+oracle/ingest.py — criteo text (CityHash64 + slot tag, src/reader/criteo_parser.h:40-94), RecordIO files of
+LZ4 compressed row blocks (src/data/compressed_row_block.h, src/reader/crb_parser.h) and libsvm, each
+also read in several parts (the data split of SGDLearner::RunEpoch)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ing():
+    from difacto_amd import build
+    build.build_host()
+    L = C.CDLL(os.path.join(ROOT, "build", "libdifacto_ingest.so"))
+    L.ingest_cityhash64.restype = C.c_uint64
+    L.ingest_cityhash64.argtypes = [C.c_char_p, C.c_size_t]
+    L.ingest_lz4_decompress.restype = C.c_long
+    L.ingest_lz4_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.ingest_read.restype = C.c_long
+    L.ingest_read.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_size_t, C.c_size_t,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    return L
+
+
+def read_all(L, path, fmt, part=0, nparts=1, batch=64, shuffle=0, neg=1.0, cap_rows=200000, cap_nnz=4000000):
+    off = np.zeros(cap_rows + 1, np.uint64)
+    lab = np.zeros(cap_rows, np.float32)
+    idx = np.zeros(cap_nnz, np.uint64)
+    val = np.zeros(cap_nnz, np.float32)
+    hv, nb = C.c_int(0), C.c_long(0)
+    n = L.ingest_read(str(path).encode(), fmt.encode(), part, nparts, batch, shuffle, neg, cap_rows, cap_nnz,
+                      off.ctypes.data, lab.ctypes.data, idx.ctypes.data, val.ctypes.data, C.byref(hv), C.byref(nb))
+    assert n >= 0
+    nnz = int(off[n])
+    return dict(offset=off[:n + 1], label=lab[:n], index=idx[:nnz], value=val[:nnz], has_value=bool(hv.value), nbatches=nb.value)
+
+
+def test_cityhash64_known_answer_and_transcription(ing):
+    from oracle import ingest as oi
+    assert ing.ingest_cityhash64(b"", 0) == 0x9ae16a3b2f90404f == oi.cityhash64(b"")   # the published constant k2
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 70)) + [127, 128, 129, 191, 192, 193, 255, 256, 1000]:
+        for _ in range(3):
+            s = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+            assert ing.ingest_cityhash64(s, n) == oi.cityhash64(s), n
+    # what the criteo parser feeds it: decimal integers and 8 hex characters
+    for tok in (b"0", b"1", b"-1", b"4", b"1382", b"123456789", b"68fd1e64", b"80e26c9b", b"fb936136", b"ffffffff"):
+        assert ing.ingest_cityhash64(tok, len(tok)) == oi.cityhash64(tok)
+
+
+def test_lz4_block_decoder_against_liblz4(ing):
+    from oracle import ingest as oi
+    rng = np.random.default_rng(5)
+    cases = [b"", b"a", b"abcd" * 3, b"\0" * 100000, bytes(range(256)) * 40, rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+             rng.integers(0, 4, 300000, dtype=np.uint8).tobytes(), np.arange(50000, dtype=np.uint64).tobytes(),
+             (b"x" * 17 + b"yz") * 5000, np.repeat(rng.normal(size=3000).astype(np.float32), 7).tobytes()]
+    for raw in cases:
+        if not raw:
+            continue
+        cp = oi.lz4_compress(raw)
+        dst = C.create_string_buffer(max(len(raw), 1))
+        assert ing.ingest_lz4_decompress(cp, len(cp), dst, len(raw)) == len(raw)
+        assert dst.raw[:len(raw)] == raw
+        # a destination that is too small, and truncated / corrupted input: an error, never an overrun
+        if len(raw) > 8:
+            assert ing.ingest_lz4_decompress(cp, len(cp), dst, len(raw) - 1) == -1
+            assert ing.ingest_lz4_decompress(cp, len(cp) - 1, dst, len(raw)) in (-1, len(raw) - 1, len(raw))
+        bad = bytearray(cp)
+        if len(bad) > 4:
+            bad[len(bad) // 2] ^= 0xFF
+            r = ing.ingest_lz4_decompress(bytes(bad), len(bad), dst, len(raw))
+            assert -1 <= r <= len(raw)
+
+
+def _criteo_text(rng, nrows):
+    lines = []
+    for _ in range(nrows):
+        f = [str(int(rng.random() < 0.25))]
+        for _ in range(13):
+            f.append("" if rng.random() < 0.2 else str(int(rng.integers(-2, 5000))))
+        for _ in range(26):
+            f.append("" if rng.random() < 0.1 else "%08x" % int(rng.integers(0, 1 << 32)))
+        lines.append("\t".join(f))
+    return ("\n".join(lines) + "\n").encode()
+
+
+def test_criteo_text_reader(ing, tmp_path):
+    from oracle import ingest as oi
+    rng = np.random.default_rng(7)
+    text = _criteo_text(rng, 700)
+    path = tmp_path / "criteo.txt"
+    path.write_bytes(text)
+    off, lab, idx = oi.parse_criteo(text)
+    got = read_all(ing, path, "criteo", batch=100)
+    assert got["nbatches"] == 7 and not got["has_value"]
+    assert np.array_equal(got["offset"], off) and np.array_equal(got["label"], lab) and np.array_equal(got["index"], idx)
+    assert np.all((idx & np.uint64(0xFFF)) < 39)   # the slot tag in the low 12 bits (EncodeFeaGrpID, base.h:60-63)
+    # three parts: every row exactly once
+    parts = [read_all(ing, path, "criteo", part=p, nparts=3, batch=64) for p in range(3)]
+    assert sum(len(p["label"]) for p in parts) == 700
+    assert np.array_equal(np.concatenate([p["index"] for p in parts]), idx)
+    # criteo_test: no label column
+    text2 = b"\n".join(l.split(b"\t", 1)[1] for l in text.split(b"\n") if l) + b"\n"
+    p2 = tmp_path / "criteo_test.txt"
+    p2.write_bytes(text2)
+    got2 = read_all(ing, p2, "criteo_test", batch=100)
+    assert np.array_equal(got2["index"], idx) and not got2["label"].any()
+
+
+def test_rec_reader_recordio_of_compressed_row_blocks(ing, tmp_path):
+    from oracle import ingest as oi
+    rng = np.random.default_rng(9)
+    blocks, recs = [], []
+    for b in range(9):
+        nrows = int(rng.integers(1, 400))
+        lens = rng.integers(0, 40, size=nrows)
+        off = np.zeros(nrows + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        nnz = int(off[-1])
+        idx = rng.integers(0, 2 ** 63, size=nnz, dtype=np.uint64)
+        val = None if b % 2 == 0 else rng.normal(size=nnz).astype(np.float32)
+        lab = np.where(rng.random(nrows) < 0.3, 1.0, 0.0).astype(np.float32)
+        if b == 3 and nnz >= 4:   # a payload word equal to the RecordIO magic: the writer must cut the record there
+            idx[:] = np.uint64(oi.REC_MAGIC) | (np.uint64(oi.REC_MAGIC) << np.uint64(32))
+        blocks.append((off, lab, idx, val))
+        recs.append(oi.write_crb_record(off, lab, idx, val))
+    # a record that certainly contains the magic word at an aligned position (uncompressible by construction is not
+    # needed: RecordIO frames the COMPRESSED bytes): append the word to one record's tail region via a raw record test
+    data = oi.write_recordio(recs)
+    path = tmp_path / "data.rec"
+    path.write_bytes(data)
+    got = read_all(ing, path, "rec", batch=50)
+    want_idx = np.concatenate([b[2] for b in blocks])
+    want_lab = np.concatenate([b[1] for b in blocks])
+    assert np.array_equal(got["label"], want_lab) and np.array_equal(got["index"], want_idx)
+    want_val = np.concatenate([np.ones(len(b[2]), np.float32) if b[3] is None else b[3] for b in blocks])
+    assert got["has_value"] and np.array_equal(got["value"], want_val)
+    parts = [read_all(ing, path, "rec", part=p, nparts=4, batch=33) for p in range(4)]
+    assert sum(len(p["label"]) for p in parts) == len(want_lab)
+    assert np.array_equal(np.concatenate([p["index"] for p in parts]), want_idx)
+
+
+def test_recordio_records_cut_at_the_magic_word(ing, tmp_path):
+    """a compressed row block whose BYTES contain 0xced7230a at an aligned offset: written as a multi-part
+    record (cflag 1 .. 3), read back whole"""
+    from oracle import ingest as oi
+    magic = struct.pack("<I", oi.REC_MAGIC)
+    nrows = 6
+    off = np.arange(nrows + 1, dtype=np.uint64) * np.uint64(2)
+    idx = np.arange(2 * nrows, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    lab = np.ones(nrows, np.float32)
+    rec = oi.write_crb_record(off, lab, idx)
+    # the 12-byte header of a compressed row block is {magic, 8, nrows}; find an aligned spot inside an LZ4 literal run
+    framed = oi.write_recordio([rec, rec])
+    assert framed.count(magic) == 2
+    # now a record with the word inside: labels whose float bits are the magic, left uncompressed by LZ4 (too short to match)
+    lab2 = np.frombuffer(magic * nrows, np.float32).copy()
+    rec2 = oi.write_crb_record(off, lab2, idx)
+    framed2 = oi.write_recordio([rec, rec2, rec])
+    if rec2.find(magic) % 4 == 0:
+        assert framed2.count(magic) > 3   # the writer had to cut
+    path = tmp_path / "cut.rec"
+    path.write_bytes(framed2)
+    got = read_all(ing, path, "rec", batch=4)
+    assert len(got["label"]) == 3 * nrows
+    assert got["label"][nrows:2 * nrows].tobytes() == lab2.tobytes()
+    assert np.array_equal(got["index"], np.concatenate([idx, idx, idx]))
+
+
+def test_libsvm_reader_parts_and_sampling(ing, tmp_path):
+    rng = np.random.default_rng(11)
+    lines, rows = [], []
+    for i in range(1000):
+        n = int(rng.integers(0, 12))
+        ids = rng.integers(1, 10 ** 12, size=n)
+        vals = np.round(rng.normal(size=n), 3)
+        lab = 1 if rng.random() < 0.3 else -1
+        rows.append((lab, ids, vals))
+        lines.append(" ".join([str(lab)] + ["%d:%g" % (a, b) for a, b in zip(ids, vals)]))
+    path = tmp_path / "d.libsvm"
+    path.write_text("\n".join(lines) + "\n")
+    got = read_all(ing, path, "libsvm", batch=128)
+    assert len(got["label"]) == 1000 and got["nbatches"] == 8
+    assert np.array_equal(got["index"], np.concatenate([r[1] for r in rows]).astype(np.uint64))
+    assert np.allclose(got["value"], np.concatenate([r[2] for r in rows]).astype(np.float32))
+    parts = [read_all(ing, path, "libsvm", part=p, nparts=5, batch=77) for p in range(5)]
+    assert np.array_equal(np.concatenate([p["index"] for p in parts]), got["index"])
+    # negative down-sampling keeps every positive and about half of the negatives
+    s = read_all(ing, path, "libsvm", batch=100, neg=0.5)
+    npos = int((got["label"] > 0).sum())
+    assert int((s["label"] > 0).sum()) == npos and 0.3 * (1000 - npos) < (s["label"] <= 0).sum() < 0.7 * (1000 - npos)
+    # the shuffle buffer permutes rows inside the buffer: the same multiset of rows
+    sh = read_all(ing, path, "libsvm", batch=50, shuffle=200)
+    assert len(sh["label"]) == 1000 and sorted(sh["index"].tolist()) == sorted(got["index"].tolist())
+    assert not np.array_equal(sh["index"], got["index"])
