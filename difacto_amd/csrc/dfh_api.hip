@@ -108,6 +108,10 @@ struct dfh_batch {
   uint32_t* o_offset = nullptr;
   float* o_value = nullptr;
   float* o_label = nullptr;
+  // pinned staging of dfh_batch_load_host (one block: offsets | labels | ids | values), allocated on first use
+  char* h_stage = nullptr;
+  hipEvent_t ev_staged = nullptr;  // the copies out of h_stage have completed
+  bool staged_pending = false;
   // localizer workspace
   uint64_t *d_keys = nullptr, *d_skeys = nullptr;   // bucket-major / sorted keys
   uint32_t *d_pos = nullptr, *d_spos = nullptr;     // row of every nnz position (d_pos) / sorted positions
@@ -1576,6 +1580,8 @@ int dfh_batch_destroy(dfh_batch* b) {
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
   if (b->ev_free) hipEventDestroy(b->ev_free);
+  if (b->ev_staged) hipEventDestroy(b->ev_staged);
+  if (b->h_stage) hipHostFree(b->h_stage);
   void* ptrs[] = {b->o_raw,    b->o_offset,  b->o_value,    b->o_label,    b->d_keys,     b->d_skeys,     b->d_pos,     b->d_spos,
                   b->d_bpos,   b->d_head,    b->d_uid,      b->d_temp,     b->d_feaids,   b->d_feacnt,    b->d_col_ptr, b->d_index,
                   b->d_s_row,  b->d_s_val,   b->d_U,        b->d_urow,     b->d_need,     b->d_rank,      b->d_pred,    b->d_slope,
@@ -1604,11 +1610,30 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   if (rc) return rc;
   hipStream_t s = prep_of(b);
   b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
-  DFH_HIP(hipMemcpyAsync(b->d_offset, off32.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, s));
-  if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, index + base, nnz * 8, hipMemcpyHostToDevice, s));
-  if (nnz && value) DFH_HIP(hipMemcpyAsync(b->d_value, value + base, nnz * 4, hipMemcpyHostToDevice, s));
-  DFH_HIP(hipMemcpyAsync(b->d_label, label, nrows * 4, hipMemcpyHostToDevice, s));
-  DFH_HIP(hipStreamSynchronize(s));  // off32 is a temporary
+  // Pinned staging: the caller's (pageable) arrays are copied into page-locked memory owned by the
+  // batch object and sent with asynchronous copies on the preparation stream — the call returns as
+  // soon as the bytes are staged, the caller may reuse its arrays, and with two batch objects used
+  // alternately the transfer of minibatch t+1 overlaps the training of minibatch t.
+  const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
+               o_val = o_idx + b->max_nnz * 8, total = o_val + b->max_nnz * 4;
+  if (!b->h_stage) {
+    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), total, hipHostMallocDefault));
+    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
+  }
+  if (b->staged_pending) {  // the previous minibatch staged here has long left; this wait is a formality
+    DFH_HIP(hipEventSynchronize(b->ev_staged));
+    b->staged_pending = false;
+  }
+  memcpy(b->h_stage + o_off, off32.data(), (nrows + 1) * 4);
+  memcpy(b->h_stage + o_lab, label, nrows * 4);
+  if (nnz) memcpy(b->h_stage + o_idx, index + base, nnz * 8);
+  if (nnz && value) memcpy(b->h_stage + o_val, value + base, nnz * 4);
+  DFH_HIP(hipMemcpyAsync(b->d_offset, b->h_stage + o_off, (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_label, b->h_stage + o_lab, nrows * 4, hipMemcpyHostToDevice, s));
+  if (nnz) DFH_HIP(hipMemcpyAsync(b->d_raw, b->h_stage + o_idx, nnz * 8, hipMemcpyHostToDevice, s));
+  if (nnz && value) DFH_HIP(hipMemcpyAsync(b->d_value, b->h_stage + o_val, nnz * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipEventRecord(b->ev_staged, s));
+  b->staged_pending = true;
   b->nrows = nrows;
   b->nnz = nnz;
   b->has_value = value != nullptr;

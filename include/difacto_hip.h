@@ -182,7 +182,9 @@ int dfh_batch_create(dfh_ctx* ctx, size_t max_rows, size_t max_nnz, dfh_batch** 
 int dfh_batch_destroy(dfh_batch* b);
 
 /* raw minibatch = what Reader::Value() hands the worker (dmlc::RowBlock<feaid_t>,
- * src/reader/reader.h:49-51): CSR with u64 feature ids.  value may be NULL (binary). */
+ * src/reader/reader.h:49-51): CSR with u64 feature ids.  value may be NULL (binary).  The arrays
+ * are staged in page-locked memory of the batch object and copied asynchronously: on return the
+ * caller may reuse them, and nothing has waited for the device. */
 int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint64_t* index,
                         const float* value, const float* label);
 /* same, from DEVICE pointers (u32 offsets); copies into the batch's own buffers */

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""End-to-end rate of build/difacto from files (PCIe and parsing included): Criteo-shaped rows written
+as criteo text, libsvm text and .rec (RecordIO of LZ4 compressed row blocks), one training epoch each
+with the C3 hyper-parameters.  usage: e2e_cli.py [rows] -> one JSON object per format on stdout"""
+import json, os, subprocess, sys, tempfile, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from oracle import ingest as oi
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+rng = np.random.default_rng(1)
+d = tempfile.mkdtemp(prefix="e2e_")
+# tokens: 13 integer slots (10 000 values each), 26 categorical slots (8 hex chars, Zipf-ish)
+ints = rng.zipf(1.3, size=(rows, 13)) % 10000
+cats = (rng.zipf(1.1, size=(rows, 26)) % 1000000).astype(np.uint64) * np.uint64(2654435761) % np.uint64(1 << 32)
+lab = (rng.random(rows) < 0.25).astype(np.int32)
+t0 = time.time()
+lines = ["%d\t%s\t%s" % (lab[i], "\t".join(map(str, ints[i])), "\t".join("%08x" % c for c in cats[i])) for i in range(rows)]
+text = ("\n".join(lines) + "\n").encode()
+open(os.path.join(d, "train.criteo"), "wb").write(text)
+off, labf, idx = oi.parse_criteo(text)
+with open(os.path.join(d, "train.libsvm"), "w") as f:
+    for i in range(rows):
+        f.write("%d %s\n" % (lab[i], " ".join("%d:1" % v for v in idx[int(off[i]):int(off[i + 1])])))
+recs = []
+for a in range(0, rows, 10000):
+    b = min(rows, a + 10000)
+    recs.append(oi.write_crb_record(off[a:b + 1] - off[a], labf[a:b], idx[int(off[a]):int(off[b])]))
+open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
+sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
+common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
+          "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0"]
+for fmt in ("criteo", "libsvm", "rec"):
+    path = os.path.join(d, "train." + fmt)
+    t0 = time.time()
+    r = subprocess.run([os.path.join(R, "build", "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
+                       capture_output=True, text=True, timeout=600)
+    dt = time.time() - t0
+    loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
+    print(json.dumps(dict(format=fmt, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt, rows_per_s=rows / dt, rc=r.returncode,
+                          line=loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])))
