@@ -182,6 +182,14 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       ensure(blk.size, blk.offset[blk.size] - blk.offset[0]);
     }
     dfh_batch* b = batch_[slot];
+    if (getenv("DIFACTO_TRACE")) {
+      uint64_t cs = 0;
+      double ls = 0;
+      for (size_t i = blk.offset[0]; i < blk.offset[blk.size]; ++i) cs += blk.index[i] * (i - blk.offset[0] + 1);
+      for (size_t i = 0; i < blk.size; ++i) ls += blk.label[i] * (i + 1);
+      LOG(INFO) << "batch rows " << blk.size << " nnz " << blk.offset[blk.size] - blk.offset[0] << " off0 " << blk.offset[0]
+                << " idxsum " << cs << " labsum " << ls << " value " << (blk.value != nullptr);
+    }
     DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
     DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
     DFH_CALL(dfh_batch_lookup(table, b));

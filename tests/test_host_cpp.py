@@ -160,7 +160,9 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
     rec = os.path.join(tmp_path, "train.rec")
     open(rec, "wb").write(oi.write_recordio(recs))
     common = ["task=train", "learner=sgd", "batch_size=500", "max_num_epochs=3", "V_dim=4", "V_threshold=0", "l1=.01", "lr=.1",
-              "V_lr=.05", "V_init=hash", "table_capacity=262144", "stop_rel_objv=0"]
+              "V_lr=.05", "V_init=hash", "table_capacity=262144", "stop_rel_objv=0",
+              "num_jobs_per_epoch=1",   # one data part: byte-range parts of a text file and of a RecordIO file hold different rows
+              "shuffle=0"]              # file order (the shuffle buffer draws from the process-wide rand(), as the reference's)
     runs = []
     for fmt, path in (("criteo", txt), ("rec", rec)):
         r = subprocess.run([os.path.join(built, "difacto"), "data_in=" + path, "data_format=" + fmt] + common,

@@ -30,7 +30,7 @@ for a in range(0, rows, 10000):
 open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
 sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
 common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
-          "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0"]
+          "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
 for fmt in ("criteo", "libsvm", "rec"):
     path = os.path.join(d, "train." + fmt)
     t0 = time.time()
