@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round 2, GPU call S: state of the tree after the four-launch Localizer / packed backward lists /
+# native sharded step / ingest: parity suite, default bench, kernel stats (pipelined + serial),
+# HBM traffic counters, the sharded path on one rank.
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+O=$R/gpurun_out/r02s; mkdir -p $O; cd $R
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1
+tail -4 $O/pytest_gpu.log | cut -c1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 300 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o kt -- python $R/bench.py --cpu-batches 0 > $O/prof_c3.log 2>&1
+python $R/tools/rocpd_stats.py $(ls $O/prof_c3/*.db $O/prof_c3/*/*.db 2>/dev/null | head -1) $O/kernel_stats_c3_pipelined.txt > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3_np -o kt -- python $R/bench.py --steps 100 --warmup 20 --cpu-batches 0 --no-pipeline --min-time 0.05 > $O/prof_c3_np.log 2>&1
+python $R/tools/rocpd_stats.py $(ls $O/prof_c3_np/*.db $O/prof_c3_np/*/*.db 2>/dev/null | head -1) $O/kernel_stats_c3_serial.txt > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o pmc -- python $R/bench.py --steps 20 --warmup 5 --cpu-batches 0 --no-pipeline --no-timing --min-time 0.001 --max-reps 1 > $O/pmc_$c.log 2>&1
+done
+python $R/tools/pmc_summary.py $(ls $O/pmc_FETCH_SIZE/*.db $O/pmc_FETCH_SIZE/*/*.db 2>/dev/null | head -1) $(ls $O/pmc_WRITE_SIZE/*.db $O/pmc_WRITE_SIZE/*/*.db 2>/dev/null | head -1) $O/pmc_hbm_traffic.json $O/pmc_hbm_traffic.txt > /dev/null 2>&1
+cd $R
+timeout 200 python bench.py --force-sharded --steps 100 --warmup 10 > $O/w1_native.json 2> $O/w1_native.err
+timeout 200 python bench.py --no-pipeline --cpu-batches 0 > $O/bench_c3_serial.json 2> $O/bench_c3_serial.err
+for f in bench_c3 bench_c3_serial w1_native; do
+  python -c "
+import json
+try:
+  d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1])
+  print('$f', round(d['value']/1e6,2), round(d['ms_per_step'],4), {k:round(x,4) for k,x in (d.get('kernel_ms_per_step') or {}).items()}, 'live fwd/bwd', (d.get('roofline') or {}).get('avg_launch_ms'), (d.get('roofline_backward') or {}).get('avg_launch_ms'))
+except Exception as e: print('$f ERR', e); print(open('$O/$f.err').read()[-800:])"
+done
+cat $O/kernel_stats_c3_serial.txt | cut -c1-60,90-150 | head -14
+cat $O/pmc_hbm_traffic.txt | head -12
+rm -rf $O/prof_c3*/*.db.tmp $O/pmc_*/*.tmp 2>/dev/null
+find $O -name "*.db" -size +20M -delete
+du -sh $O
