@@ -297,7 +297,7 @@ def main():
         b = bts[i % len(bts)]
         b.attach_device(nr, nz, o.ptr, x.ptr, None if v is None else v.ptr, l.ptr)  # inputs are resident in HBM: no copy
         b.localize()
-        if args.prep_lookup:
+        if args.prep_lookup and depth:   # one stream: the step's own lookup probes and pushes in one pass
             b.lookup(table)
 
     def step(i):

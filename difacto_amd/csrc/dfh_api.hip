@@ -125,6 +125,12 @@ struct dfh_batch {
            *d_bstart = nullptr, *d_btotal = nullptr, *d_nheads = nullptr, *d_lh = nullptr;
   size_t max_tiles = 0;
   int spl_P = 0;                   // number of buckets the stored splitters partition into (0: none yet)
+  // hand-offs of the two-launch Localizer (LocSync): [0] barrier arrivals, [1] tickets | flags | words
+  uint32_t* d_loc_ctr = nullptr;
+  uint32_t* d_loc_flag = nullptr;
+  uint64_t* d_loc_word = nullptr;
+  uint32_t loc_bar_total = 0, loc_ticket_total = 0, loc_seq = 0;
+  int loc_launches = 2;            // 2: k_loc_partition + k_loc_sort_emit where the minibatch allows; 4: the four-launch form
   // localized view
   uint64_t* d_feaids = nullptr;
   float* d_feacnt = nullptr;
@@ -148,6 +154,7 @@ struct dfh_batch {
   hipStream_t prep = nullptr;      // stream of the current preparation phase (load .. localize .. lookup)
   bool compute_auc = false;        // dfh_sgd_step also accumulates BinClassMetric::AUC per batch
   uint32_t *d_auc_keys = nullptr, *d_auc_skeys = nullptr, *d_auc_lab = nullptr, *d_auc_slab = nullptr;
+  unsigned long long* d_auc_acc = nullptr;  // k_auc_pairs: {area, positives, finished blocks}, zero between launches
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
   bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
@@ -433,6 +440,13 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* 
 int launch_auc(dfh_batch* b) {
   hipStream_t s = b->ctx->stream;
   const uint32_t n = (uint32_t)b->nrows;
+  if (n <= AUC_PAIRS_MAX_N) {
+    // minibatch-sized: pair counting, one hand-written launch (k_auc_pairs)
+    hipLaunchKernelGGL(k_auc_pairs, dim3((n + 255) / 256, (n + AUC_TILE - 1) / AUC_TILE), dim3(256), 0, s, b->d_pred, b->d_label, n,
+                       b->d_auc_acc, b->d_prog + PROG_AUC * PROG_SLOTS);
+    DFH_HIP(hipGetLastError());
+    return DFH_OK;
+  }
   hipLaunchKernelGGL(k_auc_keys, dim3(grid_for_threads(n, b->ctx)), dim3(256), 0, s, b->d_pred, b->d_label, n, b->d_auc_keys,
                      b->d_auc_lab);
   size_t tb = b->temp_bytes;
@@ -1539,6 +1553,9 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_btotal, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_nheads, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_lh, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_loc_ctr, 64, uint32_t);
+  DFH_ALLOC(b->d_loc_flag, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_loc_word, LOC_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
   DFH_ALLOC(b->d_feacnt, N, float);
   DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
@@ -1562,6 +1579,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_skeys, B, uint32_t);
   DFH_ALLOC(b->d_auc_lab, B, uint32_t);
   DFH_ALLOC(b->d_auc_slab, B, uint32_t);
+  DFH_ALLOC(b->d_auc_acc, 8, unsigned long long);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
   DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
@@ -1569,6 +1587,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
+  DFH_HIP(hipMemsetAsync(b->d_loc_ctr, 0, 64 * sizeof(uint32_t), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_auc_acc, 0, 8 * sizeof(unsigned long long), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_loc_flag, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_loc_word, 0, LOC_MAX_BUCKETS * sizeof(uint64_t), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
   return DFH_OK;
@@ -1587,7 +1609,8 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_s_row,  b->d_s_val,   b->d_U,        b->d_urow,     b->d_need,     b->d_rank,      b->d_pred,    b->d_slope,
                   b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
                   b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
-                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw};
+                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw,
+                  b->d_loc_ctr, b->d_loc_flag, b->d_loc_word, b->d_auc_acc};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1762,19 +1785,46 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-#ifdef DFH_LOC_USE_SCAN
-    hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
-#endif
-    hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    // two launches when every tile can be resident at once (the partition kernel meets at a grid
+    // barrier; two blocks of 1024 threads fit a compute unit, and every preparation stream may be
+    // running one such kernel) and positions fit the hand-off words; else the four-launch form
+    const bool fused = b->loc_launches == 2 && (size_t)v.ntiles * std::max(1u, c->nprep) <= 2 * (size_t)c->num_cu && N < LOC_WORD_MASK;
 #ifndef DFH_LOC_GRID_CAP
 #define DFH_LOC_GRID_CAP 1024
 #endif
     const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
-    hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
-                       b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                       b->d_s_val, b->d_U, sl);
+    if (fused) {
+      LocSync y;
+      y.bar = b->d_loc_ctr;
+      y.ticket = b->d_loc_ctr + 16;
+      y.err = b->d_loc_ctr + 32;
+      y.flag_a = b->d_loc_flag;
+      y.word = b->d_loc_word;
+      if (b->loc_seq >= LOC_SEQ_MAX) {  // the sequence tag wraps: forget every old tag first
+        DFH_HIP(hipMemsetAsync(b->d_loc_flag, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), s));
+        DFH_HIP(hipMemsetAsync(b->d_loc_word, 0, LOC_MAX_BUCKETS * sizeof(uint64_t), s));
+        b->loc_seq = 0;
+      }
+      y.seq = ++b->loc_seq;
+      b->loc_bar_total += (uint32_t)v.ntiles;
+      y.bar_target = b->loc_bar_total;
+      y.ticket_base = b->loc_ticket_total;
+      b->loc_ticket_total += (uint32_t)P + gsort;  // every block draws one ticket past the last bucket
+      hipLaunchKernelGGL(k_loc_partition, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos, y);
+      hipLaunchKernelGGL(k_loc_sort_emit, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v, y, b->d_pos,
+                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                         b->d_s_val, b->d_U, sl);
+    } else {
+      hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+#ifdef DFH_LOC_USE_SCAN
+      hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
+#endif
+      hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
+      hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
+                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                         b->d_s_val, b->d_U, sl);
+    }
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
   } else {
@@ -1813,6 +1863,14 @@ int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
   }
   if (std::string(name) == "force_sort_fallback") {
     b->force_sort_fallback = value != 0;
+    return DFH_OK;
+  }
+  if (std::string(name) == "localizer_launches") {
+    if (value != 2 && value != 4) {
+      set_error("localizer_launches: 2 (fused kernels, the default) or 4");
+      return DFH_ERR_ARG;
+    }
+    b->loc_launches = value;
     return DFH_OK;
   }
   if (std::string(name) == "reset_splitters") {
@@ -1923,8 +1981,16 @@ int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
     uint32_t u = 0;
     int rc = sync_all(b->ctx);
     if (rc) return rc;
+    uint32_t loc_err = 0;
     DFH_HIP(hipMemcpyAsync(&u, b->d_U, 4, hipMemcpyDeviceToHost, b->ctx->stream));
+    DFH_HIP(hipMemcpyAsync(&loc_err, b->d_loc_ctr + 32, 4, hipMemcpyDeviceToHost, b->ctx->stream));
     DFH_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (loc_err) {
+      DFH_HIP(hipMemsetAsync(b->d_loc_ctr + 32, 0, 4, b->ctx->stream));
+      set_error("the Localizer gave up waiting for its own blocks (is the GPU shared with other processes running full-size "
+                "minibatches?  batch option localizer_launches = 4 needs no resident grid); this minibatch is invalid");
+      return DFH_ERR_STATE;
+    }
     *U = u;
   }
   return DFH_OK;
@@ -2138,27 +2204,36 @@ int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n,
   if (n == 0) return DFH_OK;
   DFH_ARG(label && pred && n < 0xFFFFFFF0ULL, "dfh_auc_times_n: bad argument");
   DFH_HIP(hipSetDevice(c->device));
+  const bool pairs = n <= AUC_PAIRS_MAX_N;
   size_t tb = 0;
-  rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
-                            c->stream);
-  int rc = ensure_scratch(c, 2 * padded<float>(n) + 4 * padded<uint32_t>(n) + tb + 1024);
+  if (!pairs)
+    rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
+                              c->stream);
+  int rc = ensure_scratch(c, 2 * padded<float>(n) + (pairs ? 0 : 4 * padded<uint32_t>(n)) + tb + 2048);
   if (rc) return rc;
   Carver cv(c->scratch);
   float* d_l = cv.take<float>(n);
   float* d_p = cv.take<float>(n);
-  uint32_t* k0 = cv.take<uint32_t>(n);
-  uint32_t* k1 = cv.take<uint32_t>(n);
-  uint32_t* l0 = cv.take<uint32_t>(n);
-  uint32_t* l1 = cv.take<uint32_t>(n);
   double* d_o = cv.take<double>(1);
-  char* temp = cv.take<char>(tb + 16);
+  unsigned long long* d_acc = cv.take<unsigned long long>(8);
   hipStream_t s = c->stream;
   DFH_HIP(hipMemcpyAsync(d_l, label, n * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(d_p, pred, n * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemsetAsync(d_o, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_auc_keys, dim3(grid_for_threads(n, c)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, k0, l0);
-  DFH_HIP(rocprim::radix_sort_pairs(temp, tb, k0, k1, l0, l1, n, 0, 32, s));
-  hipLaunchKernelGGL(k_auc_area, dim3(1), dim3(1024), 0, s, l1, (uint32_t)n, d_o);
+  if (pairs) {
+    DFH_HIP(hipMemsetAsync(d_acc, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_auc_pairs, dim3((unsigned)((n + 255) / 256), (unsigned)((n + AUC_TILE - 1) / AUC_TILE)), dim3(256), 0, s, d_p,
+                       d_l, (uint32_t)n, d_acc, d_o);
+  } else {
+    uint32_t* k0 = cv.take<uint32_t>(n);
+    uint32_t* k1 = cv.take<uint32_t>(n);
+    uint32_t* l0 = cv.take<uint32_t>(n);
+    uint32_t* l1 = cv.take<uint32_t>(n);
+    char* temp = cv.take<char>(tb + 16);
+    hipLaunchKernelGGL(k_auc_keys, dim3(grid_for_threads(n, c)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, k0, l0);
+    DFH_HIP(rocprim::radix_sort_pairs(temp, tb, k0, k1, l0, l1, n, 0, 32, s));
+    hipLaunchKernelGGL(k_auc_area, dim3(1), dim3(1024), 0, s, l1, (uint32_t)n, d_o);
+  }
   DFH_HIP(hipGetLastError());
   double o = 0;
   DFH_HIP(hipMemcpyAsync(&o, d_o, sizeof(double), hipMemcpyDeviceToHost, s));

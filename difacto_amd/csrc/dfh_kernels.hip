@@ -12,7 +12,8 @@
 //                         owner side of the sharded store
 //   k_refrand_*           rand_r-compatible lazy InitV (parity mode)
 //   k_predict_generic / k_calcgrad_generic / k_logloss   literal Loss API
-//   k_auc_keys / k_auc_area   BinClassMetric::AUC
+//   k_auc_pairs           BinClassMetric::AUC by pair counting (minibatch-sized n); k_auc_keys / k_auc_area
+//                         around a library radix sort beyond
 //   k_rdx_*               Localizer::Compact around a library radix sort (very large batches);
 //                         the sample-sort Localizer (k_loc_*) lives in dfh_localize.hip
 //
@@ -1694,6 +1695,81 @@ __global__ void __launch_bounds__(1024) k_auc_area(const uint32_t* __restrict__ 
       auc_n = (a < 0.5 ? 1.0 - a : a) * nn;
     }
     *out_slot += auc_n;
+  }
+}
+
+// BinClassMetric::AUC without a sort, for minibatch-sized n: the reference's area is the number of
+// (positive j, negative i) pairs in which j comes before i in the sorted order (bin_class_metric.h:44-50),
+// and "before" can be decided pair by pair: pred_j < pred_i, ties by index (the order a stable sort gives;
+// std::sort leaves the order of ties unspecified).  n^2 comparisons, 1e8 for a 10 000-row minibatch: a few
+// microseconds of VALU work spread over the chip, no passes over memory, one launch.  Block (bx, by)
+// compares 256 rows i (registers) with AUC_TILE columns j (LDS broadcast reads); the count is an
+// integer, so the result does not depend on the order of the atomics.  The last block to finish
+// turns {area, positives} into AUC * n (:51-53), adds it to *out_slot and zeroes acc for the next call.
+constexpr int AUC_TILE = 1024;
+constexpr uint32_t AUC_PAIRS_MAX_N = 32768;   // beyond: the radix-sort path (n^2 would pass the cost of sorting)
+__global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
+                                                   unsigned long long* __restrict__ acc /* area, positives, finished blocks */,
+                                                   double* __restrict__ out_slot) {
+  __shared__ uint2 col[AUC_TILE];  // {order-preserving image of pred_j, label_j > 0}
+  __shared__ uint32_t red[4];
+  const uint32_t j0 = blockIdx.y * AUC_TILE;
+  const uint32_t lim = min((uint32_t)AUC_TILE, n - j0);
+  for (uint32_t t = threadIdx.x; t < lim; t += blockDim.x) {
+    const uint32_t bits = __float_as_uint(pred[j0 + t]);
+    col[t] = make_uint2((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u), label[j0 + t] > 0 ? 1u : 0u);
+  }
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t ki = 0;
+  bool neg = false, pos = false;
+  if (i < n) {
+    const uint32_t bits = __float_as_uint(pred[i]);
+    ki = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    pos = label[i] > 0;
+    neg = !pos;
+  }
+  __syncthreads();
+  uint32_t cnt = 0;
+#pragma unroll 8
+  for (uint32_t t = 0; t < lim; ++t) {
+    const uint2 c = col[t];
+    const bool before = c.x < ki || (c.x == ki && j0 + t < i);
+    cnt += (c.y != 0u && before) ? 1u : 0u;
+  }
+  if (!neg) cnt = 0;
+  uint32_t npos = (blockIdx.y == 0 && pos) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    npos += __shfl_xor(npos, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t c = red[0] + red[1] + red[2] + red[3];
+    if (c) atomicAdd(&acc[0], (unsigned long long)c);
+  }
+  if ((threadIdx.x & 63) == 0 && npos) atomicAdd(&acc[1], (unsigned long long)npos);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+    if (atomicAdd(&acc[2], 1ULL) + 1 == total) {
+      const double area = (double)__hip_atomic_load(&acc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const double tp = (double)__hip_atomic_load(&acc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const double nn = (double)n;
+      double auc_n;
+      if (tp == 0.0 || tp == nn) {
+        auc_n = 1.0;  // :51 (the reference returns 1, not n)
+      } else {
+        const double a = area / (tp * (nn - tp));
+        auc_n = (a < 0.5 ? 1.0 - a : a) * nn;
+      }
+      *out_slot += auc_n;
+      acc[0] = 0;
+      acc[1] = 0;
+      acc[2] = 0;
+    }
   }
 }
 

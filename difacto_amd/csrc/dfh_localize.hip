@@ -6,7 +6,9 @@
 // counts (:35-48) and maps every nnz to the rank of its key (:63-77).  A
 // minibatch is small for a GPU (N ~ 4e5 pairs of 12 B: the whole thing lives
 // in L2 / the memory-side cache), so the job is launch- and latency-bound; the
-// design minimises dependent passes.  Steady state = FOUR launches:
+// design minimises dependent passes.  Steady state = TWO launches (k_loc_partition, k_loc_sort_emit:
+// the four passes below fused pairwise, the hand-offs between blocks done inside the launch); the
+// four-launch form is kept for minibatches with more tiles than the chip has compute units:
 //
 //   k_loc_count    per tile of 2048 pairs: bucket of every pair (binary search over <= 1023
 //                  splitters in LDS) + LDS histogram, whose atomic's return value is the pair's
@@ -103,6 +105,33 @@ struct SegListsOut {
   uint2* hot;
   uint32_t* hot_ent;
 };
+
+// cross-block hand-offs of the fused kernels: per batch object, zero at creation.  Counters only ever
+// grow (the host passes the value that ends this call), flags carry the call's sequence number, so
+// nothing has to be reset between calls.
+struct LocSync {
+  uint32_t* bar;         // k_loc_partition: tiles that have reserved their runs
+  uint32_t* ticket;      // k_loc_sort_emit: buckets handed out
+  uint32_t* err;         // bit 0 / 1: a wait in k_loc_partition / k_loc_sort_emit gave up (see LOC_SPIN_TICKS)
+  uint32_t* flag_a;      // [P] == seq: last_key[b] of this call is published
+  uint64_t* word;        // [P] seq << 42 | (unique keys the bucket adds) << 21 | (last run head + 1, 0: none)
+  uint32_t bar_target;
+  uint32_t ticket_base;
+  uint32_t seq;          // 1 .. LOC_SEQ_MAX
+};
+constexpr uint32_t LOC_SEQ_MAX = (1u << 22) - 2;
+// Every wait between blocks is bounded: after 20 ms of the 100 MHz wall clock (the kernels take tens of
+// microseconds) the waiter records an error and goes on with whatever it has — the minibatch is then
+// reported as failed by the host (DFH_ERR_STATE) instead of the GPU hanging.  The only way there is a
+// grid that cannot become resident: several processes running full-size Localizers on one GPU (use
+// the batch option localizer_launches = 4 for that).
+constexpr uint64_t LOC_SPIN_TICKS = 2000000;
+__device__ __forceinline__ bool loc_wait_expired(uint64_t t0, uint32_t* err, uint32_t bit) {
+  if (wall_clock64() - t0 <= LOC_SPIN_TICKS) return false;
+  atomicOr(err, bit);
+  return true;
+}
+constexpr uint32_t LOC_WORD_MASK = (1u << 21) - 1;   // the fused path serves N < 2^21 - 1 pairs
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
 // default max_index = 2^64-1 (x % (2^64-1) is x, except the all-ones id which maps to 0)
@@ -385,29 +414,116 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
   }
 }
 
-// ---- sort one bucket; summary of its runs of equal keys
-__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
-  __shared__ uint64_t ak[LOC_LDS_CAP];
-  __shared__ uint32_t ap[LOC_LDS_CAP];
-  __shared__ uint64_t bk[LOC_LDS_CAP];
-  __shared__ uint32_t bp[LOC_LDS_CAP];
-  __shared__ uint32_t red[3][LOC_SORT_THREADS / 64];
-  // the grid may be smaller than the number of buckets (a capped grid leaves more of the chip to
-  // the training step this preparation work runs beside)
-  for (uint32_t b = blockIdx.x; b < (uint32_t)v.P; b += gridDim.x) {
-  __syncthreads();  // LDS of the previous bucket is done with
-  const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
-  const uint32_t n = end - beg;
-  if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_scatter: ready for the next call
-  if (n == 0) {
-    if (threadIdx.x == 0) {
-      v.nheads[b] = 0;
-      v.lh[b] = 0;
-      v.first_key[b] = 0;
-      v.last_key[b] = 0;
-    }
-    continue;
+// ---- count + scatter in ONE launch: the tiles count, reserve their runs, meet at a grid-wide
+// barrier (every tile is resident: the host takes this kernel only when ntiles <= compute units),
+// derive the bucket starts from the totals and write their pairs — keys, buckets and ranks never
+// leave the registers, the raw ids are read once.  The totals are written by device-scope atomics
+// and read back, after the barrier, by device-scope atomic loads: nothing else crosses between blocks.
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_partition(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
+                                                                    uint32_t* __restrict__ rowid, LocSync y) {
+  __shared__ uint64_t sk[LOC_MAX_BUCKETS];
+  __shared__ uint32_t sp[LOC_MAX_BUCKETS];
+  __shared__ uint32_t hist[LOC_MAX_BUCKETS];  // pairs per bucket of this tile, then the tile's destination per bucket
+  __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
+  const int P = v.P;
+  for (int b = threadIdx.x; b < LOC_MAX_BUCKETS; b += blockDim.x) {
+    hist[b] = 0;
+    sk[b] = b < P - 1 ? v.spl_key[b] : ~0ULL;  // spl[P-1] = +inf
+    sp[b] = b < P - 1 ? v.spl_pos[b] : ~0u;
   }
+  const uint32_t base = blockIdx.x * LOC_TILE;
+  uint64_t key[LOC_PER_THREAD];
+#pragma unroll
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+    key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
+  }
+  {  // side job (see k_loc_count): rowid[pos] = row of nnz position pos
+    const uint32_t rpb = (nrows + gridDim.x - 1) / gridDim.x;
+    const uint32_t r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+      const uint32_t e = offset[r + 1];
+      for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
+    }
+  }
+  __syncthreads();
+  int lo[LOC_PER_THREAD], hi[LOC_PER_THREAD];
+#pragma unroll
+  for (int e = 0; e < LOC_PER_THREAD; ++e) { lo[e] = 0; hi[e] = P - 1; }
+  for (int step = P; step > 1; step = (step + 1) >> 1) {
+#pragma unroll
+    for (int e = 0; e < LOC_PER_THREAD; ++e) {
+      if (lo[e] < hi[e]) {
+        const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+        const int mid = (lo[e] + hi[e]) >> 1;
+        if (comp_less(key[e], i, sk[mid], sp[mid])) hi[e] = mid; else lo[e] = mid + 1;
+      }
+    }
+  }
+  uint32_t rk[LOC_PER_THREAD];
+#pragma unroll
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+    rk[e] = i < v.n ? atomicAdd(&hist[lo[e]], 1u) : 0u;
+  }
+  __syncthreads();
+  // this thread's LOC_BPT consecutive buckets: reserve the tile's runs (see k_loc_count)
+  const int b0 = threadIdx.x * LOC_BPT;
+  uint32_t ro[LOC_BPT];
+#pragma unroll
+  for (int q = 0; q < LOC_BPT; ++q) {
+    const uint32_t h = b0 + q < P ? hist[b0 + q] : 0u;
+    ro[q] = h ? atomicAdd(&v.btotal[b0 + q], h) : 0u;
+  }
+  // grid barrier
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(y.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(y.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - y.bar_target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (loc_wait_expired(t0, y.err, 1u)) break;
+    }
+  }
+  __syncthreads();
+  // bucket starts = exclusive scan of the totals; every tile derives them, tile 0 publishes them
+  uint32_t tt[LOC_BPT];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int q = 0; q < LOC_BPT; ++q) {
+    tt[q] = b0 + q < P ? __hip_atomic_load(&v.btotal[b0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    sum += tt[q];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(sum, wsum, &total);
+#pragma unroll
+  for (int q = 0; q < LOC_BPT; ++q) {
+    if (b0 + q < P) {
+      hist[b0 + q] = ex + ro[q];  // each entry is read (above) and written by its owner thread only
+      if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
+    }
+    ex += tt[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+    if (i < v.n) {
+      const uint32_t dst = hist[lo[e]] + rk[e];
+      v.bkeys[dst] = key[e];
+      v.bpos[dst] = i;
+    }
+  }
+}
+
+// ---- sort of one bucket [beg, beg + n) of the bucket-major arrays by (key, pos).  Buckets of up to
+// LOC_LDS_CAP pairs are sorted in LDS and STAY there (*sk / *sp point into ak/ap or bk/bp); larger
+// ones (stale or unlucky splitters; kept for correctness and bounded at n log n) go through the same
+// rounds on the global arrays and end up in v.skeys / v.spos.  All threads of the block call it.
+__device__ __forceinline__ bool loc_sort_bucket(const LocView& v, uint32_t beg, uint32_t n, uint64_t* ak, uint32_t* ap,
+                                                uint64_t* bk, uint32_t* bp, const uint64_t** sk_out, const uint32_t** sp_out) {
   const uint64_t* gk = v.bkeys + beg;
   const uint32_t* gp = v.bpos + beg;
   const bool in_lds = n <= LOC_LDS_CAP && !v.force_global;
@@ -459,10 +575,8 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
       uint64_t* tk = sk; sk = dk; dk = tk;
       uint32_t* tp = sp; sp = dp; dp = tp;
     }
-    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
-      v.skeys[beg + t] = sk[t];
-      v.spos[beg + t] = sp[t];
-    }
+    *sk_out = sk;
+    *sp_out = sp;
   } else {
     // oversize bucket (stale or unlucky splitters; kept for correctness and bounded at n log n):
     // the same run-ranking + merge rounds on the global arrays, ping-ponging between the
@@ -517,12 +631,23 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     }
     __syncthreads();
   }
-  // bucket summary: number of runs of equal keys, local index of the last run head
+  if (!in_lds) {
+    *sk_out = v.skeys + beg;
+    *sp_out = v.spos + beg;
+  }
+  return in_lds;
+}
+
+// bucket summary: {runs of equal keys, local index of the last run head, first key, last key}; valid in
+// thread 0 only.  red: [2][LOC_SORT_THREADS / 64] shared words.
+struct BucketSummary {
+  uint32_t nheads, lh;
+  uint64_t first_key, last_key;
+};
+__device__ __forceinline__ BucketSummary loc_bucket_summary(const uint64_t* sk, uint32_t n, uint32_t (*red)[LOC_SORT_THREADS / 64]) {
   uint32_t cnt = 0, last = 0;
   for (uint32_t t = 1 + threadIdx.x; t < n; t += blockDim.x) {
-    const uint64_t k1 = in_lds ? sk[t] : v.skeys[beg + t];
-    const uint64_t k0 = in_lds ? sk[t - 1] : v.skeys[beg + t - 1];
-    if (k1 != k0) {
+    if (sk[t] != sk[t - 1]) {
       ++cnt;
       last = t;  // ascending t per thread
     }
@@ -537,17 +662,60 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     red[1][threadIdx.x >> 6] = last;
   }
   __syncthreads();
+  BucketSummary r;
+  r.nheads = 1;  // position 0 opens the first run
+  r.lh = 0;
+  r.first_key = 0;
+  r.last_key = 0;
   if (threadIdx.x == 0) {
-    uint32_t c = 1, l = 0;  // position 0 opens the first run
     for (int w = 0; w < LOC_SORT_THREADS / 64; ++w) {
-      c += red[0][w];
-      l = max(l, red[1][w]);
+      r.nheads += red[0][w];
+      r.lh = max(r.lh, red[1][w]);
     }
-    v.nheads[b] = c;
-    v.lh[b] = l;
-    v.first_key[b] = in_lds ? sk[0] : v.skeys[beg];
-    v.last_key[b] = in_lds ? sk[n - 1] : v.skeys[beg + n - 1];
+    r.first_key = sk[0];
+    r.last_key = sk[n - 1];
   }
+  return r;
+}
+
+// ---- sort one bucket; summary of its runs of equal keys (four-launch form)
+__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
+  __shared__ uint64_t ak[LOC_LDS_CAP];
+  __shared__ uint32_t ap[LOC_LDS_CAP];
+  __shared__ uint64_t bk[LOC_LDS_CAP];
+  __shared__ uint32_t bp[LOC_LDS_CAP];
+  __shared__ uint32_t red[2][LOC_SORT_THREADS / 64];
+  // the grid may be smaller than the number of buckets (a capped grid leaves more of the chip to
+  // the training step this preparation work runs beside)
+  for (uint32_t b = blockIdx.x; b < (uint32_t)v.P; b += gridDim.x) {
+    __syncthreads();  // LDS of the previous bucket is done with
+    const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
+    const uint32_t n = end - beg;
+    if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_scatter: ready for the next call
+    if (n == 0) {
+      if (threadIdx.x == 0) {
+        v.nheads[b] = 0;
+        v.lh[b] = 0;
+        v.first_key[b] = 0;
+        v.last_key[b] = 0;
+      }
+      continue;
+    }
+    const uint64_t* sk;
+    const uint32_t* sp;
+    if (loc_sort_bucket(v, beg, n, ak, ap, bk, bp, &sk, &sp)) {
+      for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+        v.skeys[beg + t] = sk[t];
+        v.spos[beg + t] = sp[t];
+      }
+    }
+    const BucketSummary sm = loc_bucket_summary(sk, n, red);
+    if (threadIdx.x == 0) {
+      v.nheads[b] = sm.nheads;
+      v.lh[b] = sm.lh;
+      v.first_key[b] = sm.first_key;
+      v.last_key[b] = sm.last_key;
+    }
   }
 }
 
@@ -560,53 +728,21 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
 // minibatch) closes it, and the closing thread knows the start from the running maximum of head
 // positions.  Every bucket lists the long segments it closes in its own slot range (at most
 // n_b / 9 + 2 mid and n_b / 257 + 2 hot ones: no atomics between blocks, no compaction pass).
-__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const uint32_t* __restrict__ rowid,
-                                                                const float* __restrict__ value, uint64_t* __restrict__ feaids,
-                                                                uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
-                                                                uint32_t* __restrict__ s_row, float* __restrict__ s_val,
-                                                                uint32_t* __restrict__ d_U, SegListsOut sl) {
-  constexpr int NW = LOC_EMIT_THREADS / 64;
-  __shared__ uint32_t wsum[NW], wmax[NW];
-  __shared__ uint32_t sh_cont, n_mid, n_hot;
+// the writing half of emit for one bucket whose sorted pairs are sk / sp [0, n) (LDS or global):
+// `cont`: the bucket's first key continues the previous non-empty bucket's last key; `ubase`: unique
+// keys before the bucket; `carry1`: position + 1 of the last run head before the bucket (0: none).
+// n_mid / n_hot: shared counters, zeroed by the caller before its last barrier.
+template <int NW>
+__device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, uint32_t beg, uint32_t n, const uint64_t* sk,
+                                                const uint32_t* sp, uint32_t cont, uint32_t ubase, uint32_t carry1,
+                                                const uint32_t* __restrict__ rowid, const float* __restrict__ value,
+                                                uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr,
+                                                uint32_t* __restrict__ index, uint32_t* __restrict__ s_row,
+                                                float* __restrict__ s_val, uint32_t* __restrict__ d_U, const SegListsOut& sl,
+                                                uint32_t* wsum, uint32_t* wmax, uint32_t* n_mid, uint32_t* n_hot) {
   const uint32_t P = (uint32_t)v.P;
-  for (uint32_t b = blockIdx.x; b < P; b += gridDim.x) {
-  __syncthreads();  // the shared counters of the previous bucket have been published
-  const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
-  const uint32_t n = end - beg;
   const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b;
-  if (threadIdx.x == 0) {
-    n_mid = 0;
-    n_hot = 0;
-    if (n == 0) {
-      sl.mid[b] = make_uint2(0u, 0u);
-      sl.hot[b] = make_uint2(0u, 0u);
-    }
-  }
-  if (n == 0) continue;
-  // over the buckets q < b: unique keys (nheads[q] - cont[q], cont[q]: first_key[q] equals the last key of the
-  // previous NON-EMPTY bucket) and the position of the last run head that opens a new key
-  uint32_t part = 0, carry1 = 0;  // carry1: position + 1 (0: none)
-  for (uint32_t q0 = threadIdx.x; q0 <= b; q0 += blockDim.x) {
-    const uint32_t bq = v.bstart[q0], nq = v.bstart[q0 + 1] - bq;
-    if (nq == 0) continue;
-    int p = (int)q0 - 1;
-    while (p >= 0 && v.bstart[p + 1] == v.bstart[p]) --p;
-    const uint32_t c = (p >= 0 && v.first_key[q0] == v.last_key[p]) ? 1u : 0u;
-    if (q0 == b) {
-      sh_cont = c;
-    } else {
-      part += v.nheads[q0] - c;
-      const uint32_t l = v.lh[q0];
-      if (l > 0) carry1 = max(carry1, bq + l + 1);
-      else if (!c) carry1 = max(carry1, bq + 1);
-    }
-  }
-  uint32_t ubase, carry_all;
-  block_exclusive_scan<NW>(part, wsum, &ubase);
-  block_exclusive_max<NW>(carry1, wmax, &carry_all);
-  __syncthreads();
-  const uint32_t cont = sh_cont;
-  uint32_t run_heads = 0, run_max1 = carry_all;
+  uint32_t run_heads = 0, run_max1 = carry1;
   for (uint32_t base = 0; base < n; base += blockDim.x) {
     const uint32_t t = base + threadIdx.x;
     const uint32_t i = beg + t;
@@ -615,9 +751,9 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     uint32_t pos = 0;
     bool head = false;
     if (valid) {
-      key = v.skeys[i];
-      pos = v.spos[i];
-      head = t == 0 ? !cont : key != v.skeys[i - 1];
+      key = sk[t];
+      pos = sp[t];
+      head = t == 0 ? !cont : key != sk[t - 1];
     }
     uint32_t nh, mx;
     const uint32_t ex = block_exclusive_scan<NW>(head ? 1u : 0u, wsum, &nh);
@@ -631,8 +767,8 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
         col_ptr[uid] = i;
         if (prev1) {  // closes segment uid - 1 = [prev1 - 1, i)
           const uint32_t len = i - (prev1 - 1);
-          if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(&n_hot, 1u)] = uid - 1;
-          else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(&n_mid, 1u)] = uid - 1;
+          if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid - 1;
+          else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid - 1;
         }
       }
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
@@ -642,8 +778,8 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
         *d_U = uid + 1;
         col_ptr[uid + 1] = v.n;
         const uint32_t len = v.n - (head ? i : prev1 - 1);
-        if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(&n_hot, 1u)] = uid;
-        else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(&n_mid, 1u)] = uid;
+        if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid;
+        else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid;
       }
       // the splitters of the next call: the exact P-quantiles of this sorted order
       if (P > 1) {
@@ -659,9 +795,149 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    sl.mid[b] = make_uint2(n_mid, moff);
-    sl.hot[b] = make_uint2(n_hot, hoff);
+    sl.mid[b] = make_uint2(*n_mid, moff);
+    sl.hot[b] = make_uint2(*n_hot, hoff);
   }
+}
+
+__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const uint32_t* __restrict__ rowid,
+                                                                const float* __restrict__ value, uint64_t* __restrict__ feaids,
+                                                                uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
+                                                                uint32_t* __restrict__ s_row, float* __restrict__ s_val,
+                                                                uint32_t* __restrict__ d_U, SegListsOut sl) {
+  constexpr int NW = LOC_EMIT_THREADS / 64;
+  __shared__ uint32_t wsum[NW], wmax[NW];
+  __shared__ uint32_t sh_cont, n_mid, n_hot;
+  const uint32_t P = (uint32_t)v.P;
+  for (uint32_t b = blockIdx.x; b < P; b += gridDim.x) {
+    __syncthreads();  // the shared counters of the previous bucket have been published
+    const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
+    const uint32_t n = end - beg;
+    if (threadIdx.x == 0) {
+      n_mid = 0;
+      n_hot = 0;
+      if (n == 0) {
+        sl.mid[b] = make_uint2(0u, 0u);
+        sl.hot[b] = make_uint2(0u, 0u);
+      }
+    }
+    if (n == 0) continue;
+    // over the buckets q < b: unique keys (nheads[q] - cont[q], cont[q]: first_key[q] equals the last key of the
+    // previous NON-EMPTY bucket) and the position of the last run head that opens a new key
+    uint32_t part = 0, carry1 = 0;  // carry1: position + 1 (0: none)
+    for (uint32_t q0 = threadIdx.x; q0 <= b; q0 += blockDim.x) {
+      const uint32_t bq = v.bstart[q0], nq = v.bstart[q0 + 1] - bq;
+      if (nq == 0) continue;
+      int p = (int)q0 - 1;
+      while (p >= 0 && v.bstart[p + 1] == v.bstart[p]) --p;
+      const uint32_t c = (p >= 0 && v.first_key[q0] == v.last_key[p]) ? 1u : 0u;
+      if (q0 == b) {
+        sh_cont = c;
+      } else {
+        part += v.nheads[q0] - c;
+        const uint32_t l = v.lh[q0];
+        if (l > 0) carry1 = max(carry1, bq + l + 1);
+        else if (!c) carry1 = max(carry1, bq + 1);
+      }
+    }
+    uint32_t ubase, carry_all;
+    block_exclusive_scan<NW>(part, wsum, &ubase);
+    block_exclusive_max<NW>(carry1, wmax, &carry_all);
+    __syncthreads();
+    loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr,
+                        index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot);
+  }
+}
+
+// ---- sort + emit in ONE launch.  A block takes the next bucket from a ticket counter (so that every
+// bucket with a smaller number is running or done: whoever waits, waits for blocks that never wait for
+// it), sorts it in LDS, and stitches itself to its predecessors through two hand-offs in global memory
+// (device-scope atomic stores / loads, tagged with the call's sequence number):
+//   A  last_key[b]                       -> the next non-empty bucket learns whether its first key continues it
+//   B  word[b] = {unique keys the bucket adds, last run head + 1}   -> every later bucket sums / maxes them
+// then writes the Localizer's outputs straight from LDS: the sorted pairs never travel through memory.
+__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort_emit(LocView v, LocSync y, const uint32_t* __restrict__ rowid,
+                                                                     const float* __restrict__ value, uint64_t* __restrict__ feaids,
+                                                                     uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
+                                                                     uint32_t* __restrict__ s_row, float* __restrict__ s_val,
+                                                                     uint32_t* __restrict__ d_U, SegListsOut sl) {
+  constexpr int NW = LOC_SORT_THREADS / 64;
+  __shared__ uint64_t ak[LOC_LDS_CAP];
+  __shared__ uint32_t ap[LOC_LDS_CAP];
+  __shared__ uint64_t bk[LOC_LDS_CAP];
+  __shared__ uint32_t bp[LOC_LDS_CAP];
+  __shared__ uint32_t red[2][NW];
+  __shared__ uint32_t wsum[NW], wmax[NW];
+  __shared__ uint32_t sh_b, sh_cont, n_mid, n_hot;
+  const uint32_t P = (uint32_t)v.P;
+  const uint32_t seq = y.seq;
+  for (;;) {
+    __syncthreads();  // LDS and the shared words of the previous bucket are done with
+    if (threadIdx.x == 0) {
+      sh_b = atomicAdd(y.ticket, 1u) - y.ticket_base;
+      n_mid = 0;
+      n_hot = 0;
+    }
+    __syncthreads();
+    const uint32_t b = sh_b;
+    if (b >= P) break;
+    const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
+    const uint32_t n = end - beg;
+    if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_partition: ready for the next call
+    if (n == 0) {
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&y.flag_a[b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&y.word[b], (uint64_t)seq << 42, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        sl.mid[b] = make_uint2(0u, 0u);
+        sl.hot[b] = make_uint2(0u, 0u);
+      }
+      continue;
+    }
+    const uint64_t* sk;
+    const uint32_t* sp;
+    loc_sort_bucket(v, beg, n, ak, ap, bk, bp, &sk, &sp);
+    const BucketSummary sm = loc_bucket_summary(sk, n, red);
+    if (threadIdx.x == 0) {
+      // hand-off A, then: does my first key continue the previous non-empty bucket?
+      __hip_atomic_store(&v.last_key[b], sm.last_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&y.flag_a[b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int p = (int)b - 1;
+      while (p >= 0 && v.bstart[p + 1] == v.bstart[p]) --p;
+      uint32_t c = 0;
+      if (p >= 0) {
+        const uint64_t t0 = wall_clock64();
+        while (__hip_atomic_load(&y.flag_a[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+          __builtin_amdgcn_s_sleep(1);
+          if (loc_wait_expired(t0, y.err, 2u)) break;
+        }
+        c = __hip_atomic_load(&v.last_key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sm.first_key ? 1u : 0u;
+      }
+      sh_cont = c;
+      // hand-off B
+      const uint32_t uniq = sm.nheads - c;
+      const uint32_t lhp = sm.lh > 0 ? sm.lh + 1 : (c ? 0u : 1u);
+      __hip_atomic_store(&y.word[b], (uint64_t)seq << 42 | (uint64_t)uniq << 21 | (uint64_t)lhp, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every earlier bucket's word: unique keys before this bucket, position + 1 of the last run head before it
+    uint32_t part = 0, carry1 = 0;
+    for (uint32_t q = threadIdx.x; q < b; q += blockDim.x) {
+      uint64_t w;
+      const uint64_t t0 = wall_clock64();
+      while (((w = __hip_atomic_load(&y.word[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 42) != seq) {
+        __builtin_amdgcn_s_sleep(1);
+        if (loc_wait_expired(t0, y.err, 2u)) break;
+      }
+      part += (uint32_t)(w >> 21) & LOC_WORD_MASK;
+      const uint32_t lhp = (uint32_t)w & LOC_WORD_MASK;
+      if (lhp) carry1 = max(carry1, v.bstart[q] + lhp);
+    }
+    uint32_t ubase, carry_all;
+    block_exclusive_scan<NW>(part, wsum, &ubase);
+    block_exclusive_max<NW>(carry1, wmax, &carry_all);
+    __syncthreads();
+    loc_emit_bucket<NW>(v, b, beg, n, sk, sp, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr, index, s_row, s_val,
+                        d_U, sl, wsum, wmax, &n_mid, &n_hot);
   }
 }
 

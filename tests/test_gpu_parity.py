@@ -115,7 +115,7 @@ def test_literal_predict_accumulates(ctx, oracle):
 
 
 # ------------------------------------------------------------------ device Localizer
-@pytest.mark.parametrize("path", ["sample_sort", "radix", "sample_sort_fallback"])
+@pytest.mark.parametrize("path", ["sample_sort", "sample_sort_4", "radix", "sample_sort_fallback", "sample_sort_fallback_4"])
 @pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same", "criteo_like",
                                   "bias_feature", "sorted_input", "clustered"])
 def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
@@ -161,7 +161,9 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     nnz = int(b["offset"][-1])
     bt = capi.Batch(ctx, len(b["label"]), max(nnz, 1))
     bt.set_option("force_radix_sort", path == "radix")
-    bt.set_option("force_sort_fallback", path == "sample_sort_fallback")
+    bt.set_option("force_sort_fallback", path.startswith("sample_sort_fallback"))
+    # two launches (k_loc_partition + k_loc_sort_emit, the default) or the four-launch form
+    bt.set_option("localizer_launches", 4 if path.endswith("_4") else 2)
     bt.load_host(b["offset"], b["index"], b["value"], b["label"])
     bt.localize(mx)
     got = bt.get_localized()
@@ -173,7 +175,8 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     bt.close()
 
 
-def test_device_localizer_stored_splitters(capi, ctx, oracle):
+@pytest.mark.parametrize("launches", [2, 4])
+def test_device_localizer_stored_splitters(capi, ctx, oracle, launches):
     """dfh_localize keeps the exact quantiles of one minibatch as the splitters of the next
     (dfh_localize.hip): a stream of minibatches through ONE batch object must stay bit-exact when
     the splitters fit (same distribution), when they are stale (another distribution: one bucket
@@ -200,6 +203,7 @@ def test_device_localizer_stored_splitters(capi, ctx, oracle):
     stream = [c1, gen.batch(2000), gen.batch(2000), c1, jammed(2000, 39), gen.batch(2000), uniform(2000, 39), same_key(2000, 39),
               gen.batch(2000), gen.batch(150), gen.batch(150), uniform(40, 3), gen.batch(2000), gen.batch(1990)]
     bt = capi.Batch(ctx, 2000, 2000 * 39)
+    bt.set_option("localizer_launches", launches)
     for n, b in enumerate(stream):
         bt.load_host(b["offset"], b["index"], b["value"], b["label"])
         bt.localize()
@@ -889,10 +893,11 @@ def test_sharded_hip_backend_world1_overlap_over_rccl(capi, oracle):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [1, 7, 1000, 10000])
+@pytest.mark.parametrize("n", [1, 7, 1000, 1025, 10000, 40000])
 def test_auc_vs_oracle(capi, ctx, oracle, n):
     """BinClassMetric::AUC on device (ties in pred are ordered arbitrarily by the
-    reference's std::sort, so the comparison uses tie-free predictions)"""
+    reference's std::sort, so the comparison uses tie-free predictions): pair counting
+    (k_auc_pairs) up to 32 768 examples, the radix-sort form beyond"""
     rng = np.random.default_rng(n)
     pred = np.unique((rng.normal(size=n) * 3).astype(np.float32))
     rng.shuffle(pred)
