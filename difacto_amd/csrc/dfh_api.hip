@@ -38,6 +38,9 @@ struct dfh_ctx {
   int fwd_blocks = 0;          // cap on the forward grid (0: one wave per example)
   int bwd_small_blocks = 2048; // cap on the short-segment blocks of the backward/update launch
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
+  int prep_gate = 0;           // 1: a Localizer's sort / emit launches wait for the step queued last to end (they cost
+                               //    a concurrent backward/update launch more than their own time; count / scatter do not)
+  hipEvent_t last_step_ev = nullptr;  // ev_free of the step queued last on the main stream
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
   struct Span { int id; hipEvent_t a, b; };
@@ -125,12 +128,6 @@ struct dfh_batch {
            *d_bstart = nullptr, *d_btotal = nullptr, *d_nheads = nullptr, *d_lh = nullptr;
   size_t max_tiles = 0;
   int spl_P = 0;                   // number of buckets the stored splitters partition into (0: none yet)
-  // hand-offs of the two-launch Localizer (LocSync): [0] barrier arrivals, [1] tickets | flags | words
-  uint32_t* d_loc_ctr = nullptr;
-  uint32_t* d_loc_flag = nullptr;
-  uint64_t* d_loc_word = nullptr;
-  uint32_t loc_bar_total = 0, loc_ticket_total = 0, loc_seq = 0;
-  int loc_launches = 2;            // 2: k_loc_partition + k_loc_sort_emit where the minibatch allows; 4: the four-launch form
   // localized view
   uint64_t* d_feaids = nullptr;
   float* d_feacnt = nullptr;
@@ -207,6 +204,7 @@ int main_end(dfh_batch* b) {
   if (c->pipeline) {
     DFH_HIP(hipEventRecord(b->ev_free, c->stream));
     b->free_pending = true;
+    c->last_step_ev = b->ev_free;
   }
   return DFH_OK;
 }
@@ -399,7 +397,9 @@ int dispatch_L(int kp, F&& f) {
   return DFH_OK;
 }
 
-int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr) {
+constexpr KeyRange kAllKeys{0u, 0xFFFFFFFFu, 0u};
+
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr, const MixSrc* mix = nullptr) {
   BatchView bv = batch_view(b);
   bv.uw = uw;
   // one wave per example, all resident at once where possible: the kernel is
@@ -417,17 +417,23 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* 
     ea = TimeScope::get(c);
     eb = TimeScope::get(c);
   }
+  MixSrc mx{nullptr, 0};
+  if (mix) mx = *mix;
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
-#define DFH_FWD(D)                                                                                             \
-  if (ea && eb) hipExtLaunchKernelGGL((k_forward<L, D>), dim3(grid), dim3(256), 0, s, ea, eb, 0, bv, src, k, kp); \
-  else hipLaunchKernelGGL((k_forward<L, D>), dim3(grid), dim3(256), 0, s, bv, src, k, kp)
+#define DFH_FWD1(D, M)                                                                                                       \
+  if (ea && eb) hipExtLaunchKernelGGL((k_forward<L, D, M>), dim3(grid), dim3(256), 0, s, ea, eb, 0, bv, src, k, kp, mx); \
+  else hipLaunchKernelGGL((k_forward<L, D, M>), dim3(grid), dim3(256), 0, s, bv, src, k, kp, mx)
+#define DFH_FWD(D)                      \
+  if (mix) { DFH_FWD1(D, true); }       \
+  else { DFH_FWD1(D, false); }
     switch (fwd_depth) {
       case 4: DFH_FWD(4); break;
       case 10: DFH_FWD(10); break;
       case 8: DFH_FWD(8); break;
       default: DFH_FWD(5); break;
     }
+#undef DFH_FWD1
 #undef DFH_FWD
   });
   if (ea && eb) c->spans.push_back({DFH_K_FORWARD, ea, eb});
@@ -460,7 +466,7 @@ int launch_auc(dfh_batch* b) {
 
 template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
-                    uint32_t* need) {
+                    uint32_t* need, KeyRange rg = kAllKeys) {
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
@@ -492,10 +498,10 @@ int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float*
 #define DFH_BWD(LEAN, EXACT)                                                                                          \
   if (ea && eb)                                                                                                       \
     hipExtLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, ea, eb, 0, bv, src, tv, grads, \
-                          gstride, k, kp, need, nh, nm, nlist);                                                       \
+                          gstride, k, kp, need, nh, nm, nlist, rg);                                                   \
   else                                                                                                                \
     hipLaunchKernelGGL((k_backward_all<LL, FUSED, LEAN, EXACT>), grid, block, 0, s, bv, src, tv, grads, gstride, k, kp, \
-                       need, nh, nm, nlist)
+                       need, nh, nm, nlist, rg)
     if (lean && kp == 4 * LL) {
       DFH_BWD(FUSED, true);
     } else if (lean) {
@@ -625,6 +631,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "bwd_small_blocks") {
     DFH_ARG(value >= 1 && value <= 65536, "bwd_small_blocks must be in [1, 65536]");
     c->bwd_small_blocks = value;
+  } else if (n == "prep_gate") {
+    DFH_ARG(value == 0 || value == 1, "prep_gate must be 0 or 1");
+    c->prep_gate = value;
   } else if (n == "prep_priority") {
     DFH_ARG(value >= -1 && value <= 1, "prep_priority must be -1 (lowest), 0 (default) or 1 (highest)");
     DFH_ARG(c->preps.empty(), "prep_priority must be set before dfh_ctx_set_pipeline creates the streams");
@@ -1553,9 +1562,6 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_btotal, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_nheads, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_lh, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_loc_ctr, 64, uint32_t);
-  DFH_ALLOC(b->d_loc_flag, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_loc_word, LOC_MAX_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
   DFH_ALLOC(b->d_feacnt, N, float);
   DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
@@ -1587,10 +1593,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
-  DFH_HIP(hipMemsetAsync(b->d_loc_ctr, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_auc_acc, 0, 8 * sizeof(unsigned long long), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_loc_flag, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_loc_word, 0, LOC_MAX_BUCKETS * sizeof(uint64_t), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
   return DFH_OK;
@@ -1601,6 +1604,7 @@ int dfh_batch_destroy(dfh_batch* b) {
   hipSetDevice(b->ctx->device);
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
+  if (b->ev_free && b->ctx->last_step_ev == b->ev_free) b->ctx->last_step_ev = nullptr;
   if (b->ev_free) hipEventDestroy(b->ev_free);
   if (b->ev_staged) hipEventDestroy(b->ev_staged);
   if (b->h_stage) hipHostFree(b->h_stage);
@@ -1610,7 +1614,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
                   b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
                   b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw,
-                  b->d_loc_ctr, b->d_loc_flag, b->d_loc_word, b->d_auc_acc};
+                  b->d_auc_acc};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1785,46 +1789,20 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    // two launches when every tile can be resident at once (the partition kernel meets at a grid
-    // barrier; two blocks of 1024 threads fit a compute unit, and every preparation stream may be
-    // running one such kernel) and positions fit the hand-off words; else the four-launch form
-    const bool fused = b->loc_launches == 2 && (size_t)v.ntiles * std::max(1u, c->nprep) <= 2 * (size_t)c->num_cu && N < LOC_WORD_MASK;
+    hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+#ifdef DFH_LOC_USE_SCAN
+    hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
+#endif
+    hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
 #ifndef DFH_LOC_GRID_CAP
 #define DFH_LOC_GRID_CAP 1024
 #endif
     const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
-    if (fused) {
-      LocSync y;
-      y.bar = b->d_loc_ctr;
-      y.ticket = b->d_loc_ctr + 16;
-      y.err = b->d_loc_ctr + 32;
-      y.flag_a = b->d_loc_flag;
-      y.word = b->d_loc_word;
-      if (b->loc_seq >= LOC_SEQ_MAX) {  // the sequence tag wraps: forget every old tag first
-        DFH_HIP(hipMemsetAsync(b->d_loc_flag, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), s));
-        DFH_HIP(hipMemsetAsync(b->d_loc_word, 0, LOC_MAX_BUCKETS * sizeof(uint64_t), s));
-        b->loc_seq = 0;
-      }
-      y.seq = ++b->loc_seq;
-      b->loc_bar_total += (uint32_t)v.ntiles;
-      y.bar_target = b->loc_bar_total;
-      y.ticket_base = b->loc_ticket_total;
-      b->loc_ticket_total += (uint32_t)P + gsort;  // every block draws one ticket past the last bucket
-      hipLaunchKernelGGL(k_loc_partition, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos, y);
-      hipLaunchKernelGGL(k_loc_sort_emit, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v, y, b->d_pos,
-                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                         b->d_s_val, b->d_U, sl);
-    } else {
-      hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-#ifdef DFH_LOC_USE_SCAN
-      hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
-#endif
-      hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
-      hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
-      hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
-                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                         b->d_s_val, b->d_U, sl);
-    }
+    if (c->pipeline && c->prep_gate && c->last_step_ev && s != c->stream) DFH_HIP(hipStreamWaitEvent(s, c->last_step_ev, 0));
+    hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
+                       b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                       b->d_s_val, b->d_U, sl);
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
   } else {
@@ -1863,14 +1841,6 @@ int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
   }
   if (std::string(name) == "force_sort_fallback") {
     b->force_sort_fallback = value != 0;
-    return DFH_OK;
-  }
-  if (std::string(name) == "localizer_launches") {
-    if (value != 2 && value != 4) {
-      set_error("localizer_launches: 2 (fused kernels, the default) or 4");
-      return DFH_ERR_ARG;
-    }
-    b->loc_launches = value;
     return DFH_OK;
   }
   if (std::string(name) == "reset_splitters") {
@@ -1981,16 +1951,8 @@ int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
     uint32_t u = 0;
     int rc = sync_all(b->ctx);
     if (rc) return rc;
-    uint32_t loc_err = 0;
     DFH_HIP(hipMemcpyAsync(&u, b->d_U, 4, hipMemcpyDeviceToHost, b->ctx->stream));
-    DFH_HIP(hipMemcpyAsync(&loc_err, b->d_loc_ctr + 32, 4, hipMemcpyDeviceToHost, b->ctx->stream));
     DFH_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (loc_err) {
-      DFH_HIP(hipMemsetAsync(b->d_loc_ctr + 32, 0, 4, b->ctx->stream));
-      set_error("the Localizer gave up waiting for its own blocks (is the GPU shared with other processes running full-size "
-                "minibatches?  batch option localizer_launches = 4 needs no resident grid); this minibatch is invalid");
-      return DFH_ERR_STATE;
-    }
     *U = u;
   }
   return DFH_OK;
@@ -2134,7 +2096,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     }
   } else {
     BatchView bv = batch_view(b);
-    hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(Nb, c), PROG_SLOTS)), dim3(256), 0, s, bv, src, t->v, k, kp);
+    hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(Nb, c), PROG_SLOTS)), dim3(256), 0, s, bv, src, t->v, k, kp, kAllKeys);
     DFH_HIP(hipGetLastError());
   }
   return main_end(b);

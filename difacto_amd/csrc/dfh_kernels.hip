@@ -223,7 +223,10 @@ constexpr uint32_t BWD_SMALL = DFH_BWD_SMALL;
 constexpr uint32_t BWD_MID = DFH_BWD_MID;
 constexpr int BWD_DEPTH = DFH_BWD_DEPTH;
 constexpr int BWD_SMALL_DEPTH = DFH_BWD_SMALL_DEPTH;
-constexpr int BWD_THREADS = 512;    // threads per block of k_backward_all
+#ifndef DFH_BWD_THREADS
+#define DFH_BWD_THREADS 512
+#endif
+constexpr int BWD_THREADS = DFH_BWD_THREADS;    // threads per block of k_backward_all
 #ifdef DFH_BWD_TRACE
 __device__ unsigned long long g_bwd_trace[3 * 8192];
 #endif
@@ -266,6 +269,19 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
     // {row, w} per unique key, batch-local and L2-resident: the forward then touches nothing of a
     // row but its V lines (the weight is read here once per KEY instead of once per nonzero)
     if (uw) uw[u] = make_uint2(r, __float_as_uint(w));
+  }
+}
+
+constexpr uint32_t kRemoteRow = 0x80000000u;  // bit 31 of a uw[] row word: the row is in the pulled-rows buffer, not in the table
+
+// sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
+// the pulled-rows buffer belongs to key u; the slots of this rank's own keys [lo, hi) are unused)
+__global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,
+                            uint32_t hi, uint2* __restrict__ uw) {
+  const uint32_t U = *d_U;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
+    if (u - lo < hi - lo) continue;
+    uw[u] = make_uint2(u | kRemoteRow, __float_as_uint(rows[(size_t)u * stride]));
   }
 }
 
@@ -350,8 +366,16 @@ __global__ void k_refrand_advance(TableView t, const uint32_t* __restrict__ tota
 constexpr int PROG_SLOTS = 16384;
 constexpr int PROG_LOSS = 0, PROG_PENALTY = 1, PROG_AUC = 2;  // [PROG_AUC * PROG_SLOTS] is a single accumulator
 
-template <int L, int FWD_DEPTH>
-__global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, RowSrc src, int k, int kp) {
+// MIXED (sharded store): a key's V row lives either in this rank's table (the keys this rank owns) or in
+// the buffer of rows pulled from the other owners; bit 31 of the row word k_lookup / k_uw_remote leave
+// in uw[] says which, and the address is chosen per row.
+struct MixSrc {
+  const float* vbase2;   // V of the pulled rows (packed layout)
+  size_t vstride2;
+};
+
+template <int L, int FWD_DEPTH, bool MIXED>
+__global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, RowSrc src, int k, int kp, MixSrc mix) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
@@ -405,7 +429,14 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
             // the row load does not wait for has_V: a row without V holds zeros
             const bool ok = t < cnt && sub_ok;
             xs[q] = (ok && hh != 0) ? xx : 0.f;
-            v[q] = ok ? ld4(src.vbase + (size_t)rr * src.vstride + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MIXED) {
+              const bool rem = (rr & kRemoteRow) != 0u;
+              const float* vb = rem ? mix.vbase2 : src.vbase;
+              const size_t vs = rem ? mix.vstride2 : src.vstride;
+              v[q] = ok ? ld4(vb + (size_t)(rr & ~kRemoteRow) * vs + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+              v[q] = ok ? ld4(src.vbase + (size_t)rr * src.vstride + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
           }
 #pragma unroll
           for (int q = 0; q < FWD_DEPTH; ++q) {
@@ -473,6 +504,14 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
 // list) before consuming any; V rows are read speculatively (a row without V holds
 // zeros, in the table and in packed rows alike).
 // ---------------------------------------------------------------------------
+
+// a launch of k_backward_all / k_penalty may be restricted to the keys whose rank u lies inside
+// (inv = 0) or outside (inv = 1) [lo, hi): the sharded store runs the keys this rank owns through the
+// fused in-place update and the others through the gradient-row form.  Default: every key.
+struct KeyRange {
+  uint32_t lo, hi, inv;
+};
+__device__ __forceinline__ bool key_in(const KeyRange& kr, uint32_t u) { return ((u - kr.lo < kr.hi - kr.lo) ? 1u : 0u) != kr.inv; }
 
 struct KeySums {
   float gw;    // sum p x
@@ -655,7 +694,7 @@ __device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_
 template <int L, bool FUSED, int NW>
 __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                          size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
-                                         uint32_t nwaves, uint32_t nb, double& pen_acc) {
+                                         uint32_t nwaves, uint32_t nb, const KeyRange& rg, double& pen_acc) {
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
@@ -672,6 +711,7 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
     const uint32_t* __restrict__ ent = b.seg.mid_ent + co.y;
     for (uint32_t q = sub_w; q < nm; q += G) {
       const uint32_t u = ent[q];
+      if (!key_in(rg, u)) continue;  // uniform per wave
       const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
       const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
       KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
@@ -683,7 +723,7 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
 template <int L, bool FUSED, int NW>
 __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                          size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t blk,
-                                         uint32_t nblk, uint32_t nb, double& pen_acc) {
+                                         uint32_t nblk, uint32_t nb, const KeyRange& rg, double& pen_acc) {
   __shared__ float part[NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
   const int lane = lane_id();
   const int grp = lane / L;
@@ -703,6 +743,7 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
   const uint32_t* __restrict__ ent = b.seg.hot_ent + co.y;
   for (uint32_t q = sub_b; q < nh; q += G) {
     const uint32_t u = ent[q];
+    if (!key_in(rg, u)) continue;  // uniform per block
     const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
     const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
     KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
@@ -741,7 +782,7 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
 template <int L, bool FUSED>
 __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src, const TableView& t, float* __restrict__ grads,
                                            size_t gstride, int k, int kp, uint32_t* __restrict__ need_init, uint32_t wave,
-                                           uint32_t nwaves, double& pen_acc) {
+                                           uint32_t nwaves, const KeyRange& rg, double& pen_acc) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
@@ -755,7 +796,7 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
       const uint32_t u = min(u0 + grp, U - 1);
       const uint32_t beg = b.col_ptr[u], end_all = b.col_ptr[u + 1];
       const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-      const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL;
+      const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL && key_in(rg, u);
       const uint32_t end = mine ? end_all : beg;
       KeySums s;
       s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -818,7 +859,7 @@ struct SmallArgs {
 // rows), and with the register file capping the waves per SIMD, more independent chains per wave
 // are the only way to more requests in flight.
 template <int L, bool EXACT>
-__device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wave, uint32_t nwaves, double& pen_acc) {
+__device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wave, uint32_t nwaves, const KeyRange& rg, double& pen_acc) {
   constexpr int G = 64 / L;
   constexpr int KPG = DFH_BWD_SMALL_KEYS;
   const int lane = lane_id();
@@ -846,7 +887,7 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
     float xs[KPG][BWD_SMALL_DEPTH];
 #pragma unroll
     for (int h = 0; h < KPG; ++h) {  // round trip 2: the model row and the first occurrences, back to back
-      mine[h] = (u0 + h * G + grp) < U && end[h] - beg[h] <= BWD_SMALL;
+      mine[h] = (u0 + h * G + grp) < U && end[h] - beg[h] <= BWD_SMALL && key_in(rg, u[h]);
       if (!mine[h]) end[h] = beg[h];
       const RowHdr* hp = a.hdr + r[h];
       const float* va = a.va + (size_t)r[h] * (2 * kp);
@@ -970,7 +1011,7 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
 template <int L, bool FUSED, bool LEAN, bool EXACT>
 __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,
                                                                 size_t gstride, int k, int kp, uint32_t* __restrict__ need_init,
-                                                                uint32_t nb_hot, uint32_t nb_mid, uint32_t nlist) {
+                                                                uint32_t nb_hot, uint32_t nb_mid, uint32_t nlist, KeyRange rg) {
   constexpr int NW = BWD_THREADS / 64;
   double pen_acc = 0.0;
 #ifdef DFH_BWD_TRACE
@@ -990,10 +1031,10 @@ __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(Bat
     small_id = blockIdx.x - before;
   }
   if (is_big && big_id < nb_hot) {
-    hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, big_id, nb_hot, nlist, pen_acc);
+    hot_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, big_id, nb_hot, nlist, rg, pen_acc);
   } else if (is_big) {
     mid_role<L, FUSED, NW>(b, src, t, grads, gstride, k, kp, need_init, (big_id - nb_hot) * NW + (threadIdx.x >> 6),
-                           nb_mid * NW, nlist, pen_acc);
+                           nb_mid * NW, nlist, rg, pen_acc);
   } else {
     const uint32_t wave = small_id * NW + (threadIdx.x >> 6);
     const uint32_t nwaves = (gridDim.x - nb_big) * NW;
@@ -1002,9 +1043,9 @@ __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(Bat
       sa.d_U = b.d_U; sa.col_ptr = b.col_ptr; sa.urow = src.urow; sa.s_row = b.s_row; sa.s_val = b.s_val;
       sa.slope = b.slope; sa.xv = b.xv; sa.feaids = b.feaids; sa.hdr = t.hdr; sa.va = t.va; sa.need_init = need_init;
       sa.prog = b.prog; sa.k = k; sa.kp = kp; sa.p = t.p;
-      small_role_lean<L, EXACT>(sa, wave, nwaves, pen_acc);
+      small_role_lean<L, EXACT>(sa, wave, nwaves, rg, pen_acc);
     } else {
-      small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, pen_acc);
+      small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, rg, pen_acc);
     }
   }
   if (FUSED) flush_penalty(b, pen_acc);
@@ -1054,13 +1095,14 @@ __global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0) {
 
 // penalty only (validation batches: no backward pass)
 template <int L>
-__global__ void __launch_bounds__(256) k_penalty(BatchView b, RowSrc src, TableView t, int k, int kp) {
+__global__ void __launch_bounds__(256) k_penalty(BatchView b, RowSrc src, TableView t, int k, int kp, KeyRange rg) {
   const int lane = lane_id();
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t U = *b.d_U;
   double pen_acc = 0.0;
   for (uint32_t u = wave; u < U; u += nwaves) {
+    if (!key_in(rg, u)) continue;
     const uint32_t r = src.urow ? src.urow[u] : u;
     const float2 wf = *reinterpret_cast<const float2*>(src.wbase + (size_t)r * src.wstride);
     float pen = 0.f;

@@ -6,9 +6,7 @@
 // counts (:35-48) and maps every nnz to the rank of its key (:63-77).  A
 // minibatch is small for a GPU (N ~ 4e5 pairs of 12 B: the whole thing lives
 // in L2 / the memory-side cache), so the job is launch- and latency-bound; the
-// design minimises dependent passes.  Steady state = TWO launches (k_loc_partition, k_loc_sort_emit:
-// the four passes below fused pairwise, the hand-offs between blocks done inside the launch); the
-// four-launch form is kept for minibatches with more tiles than the chip has compute units:
+// design minimises dependent passes.  Steady state = FOUR launches:
 //
 //   k_loc_count    per tile of 2048 pairs: bucket of every pair (binary search over <= 1023
 //                  splitters in LDS) + LDS histogram, whose atomic's return value is the pair's
@@ -39,7 +37,12 @@
 // Splitting on the COMPOSITE (key, pos) makes every element distinct, so buckets stay balanced
 // however skewed the key distribution is (a feature present in every row just spreads over
 // several buckets); equal keys that straddle a bucket boundary are stitched in k_loc_emit.
-// Measured dead ends, kept out: a bitonic network (60+ barrier-separated stages at one or two
+// Measured dead ends, kept out: fusing the four passes pairwise (count + scatter around a grid-wide
+// barrier; sort + emit with ticketed buckets, the sorted pairs kept in LDS and two tagged hand-offs
+// between blocks) — bit-exact, but every hand-off between blocks inside a launch is a device-scope
+// round trip across the 8 XCDs and costs more than the launch boundary it replaces (21 + 51 us against
+// 19 + 34 us; 66 + 233 us with release / acquire fences, which write back and invalidate the L2);
+// a bitonic network (60+ barrier-separated stages at one or two
 // waves per SIMD: ~1 us of dependent issue latency each), full O(n^2) ranking of a bucket
 // (VALU-bound: 7+ us even when perfectly balanced), an 8-pass LSD radix sort (18 launches).
 // The result is the fully sorted pair list (ties by position), i.e. bit-identical to the
@@ -105,33 +108,6 @@ struct SegListsOut {
   uint2* hot;
   uint32_t* hot_ent;
 };
-
-// cross-block hand-offs of the fused kernels: per batch object, zero at creation.  Counters only ever
-// grow (the host passes the value that ends this call), flags carry the call's sequence number, so
-// nothing has to be reset between calls.
-struct LocSync {
-  uint32_t* bar;         // k_loc_partition: tiles that have reserved their runs
-  uint32_t* ticket;      // k_loc_sort_emit: buckets handed out
-  uint32_t* err;         // bit 0 / 1: a wait in k_loc_partition / k_loc_sort_emit gave up (see LOC_SPIN_TICKS)
-  uint32_t* flag_a;      // [P] == seq: last_key[b] of this call is published
-  uint64_t* word;        // [P] seq << 42 | (unique keys the bucket adds) << 21 | (last run head + 1, 0: none)
-  uint32_t bar_target;
-  uint32_t ticket_base;
-  uint32_t seq;          // 1 .. LOC_SEQ_MAX
-};
-constexpr uint32_t LOC_SEQ_MAX = (1u << 22) - 2;
-// Every wait between blocks is bounded: after 20 ms of the 100 MHz wall clock (the kernels take tens of
-// microseconds) the waiter records an error and goes on with whatever it has — the minibatch is then
-// reported as failed by the host (DFH_ERR_STATE) instead of the GPU hanging.  The only way there is a
-// grid that cannot become resident: several processes running full-size Localizers on one GPU (use
-// the batch option localizer_launches = 4 for that).
-constexpr uint64_t LOC_SPIN_TICKS = 2000000;
-__device__ __forceinline__ bool loc_wait_expired(uint64_t t0, uint32_t* err, uint32_t bit) {
-  if (wall_clock64() - t0 <= LOC_SPIN_TICKS) return false;
-  atomicOr(err, bit);
-  return true;
-}
-constexpr uint32_t LOC_WORD_MASK = (1u << 21) - 1;   // the fused path serves N < 2^21 - 1 pairs
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
 // default max_index = 2^64-1 (x % (2^64-1) is x, except the all-ones id which maps to 0)
@@ -409,110 +385,6 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
     if (i < v.n) {
       const uint32_t dst = off[pk[e] >> 16] + (pk[e] & 0xFFFFu);
       v.bkeys[dst] = make_key(raw[e], v.max_index);
-      v.bpos[dst] = i;
-    }
-  }
-}
-
-// ---- count + scatter in ONE launch: the tiles count, reserve their runs, meet at a grid-wide
-// barrier (every tile is resident: the host takes this kernel only when ntiles <= compute units),
-// derive the bucket starts from the totals and write their pairs — keys, buckets and ranks never
-// leave the registers, the raw ids are read once.  The totals are written by device-scope atomics
-// and read back, after the barrier, by device-scope atomic loads: nothing else crosses between blocks.
-__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_partition(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
-                                                                    uint32_t* __restrict__ rowid, LocSync y) {
-  __shared__ uint64_t sk[LOC_MAX_BUCKETS];
-  __shared__ uint32_t sp[LOC_MAX_BUCKETS];
-  __shared__ uint32_t hist[LOC_MAX_BUCKETS];  // pairs per bucket of this tile, then the tile's destination per bucket
-  __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
-  const int P = v.P;
-  for (int b = threadIdx.x; b < LOC_MAX_BUCKETS; b += blockDim.x) {
-    hist[b] = 0;
-    sk[b] = b < P - 1 ? v.spl_key[b] : ~0ULL;  // spl[P-1] = +inf
-    sp[b] = b < P - 1 ? v.spl_pos[b] : ~0u;
-  }
-  const uint32_t base = blockIdx.x * LOC_TILE;
-  uint64_t key[LOC_PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
-    key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
-  }
-  {  // side job (see k_loc_count): rowid[pos] = row of nnz position pos
-    const uint32_t rpb = (nrows + gridDim.x - 1) / gridDim.x;
-    const uint32_t r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-      const uint32_t e = offset[r + 1];
-      for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
-    }
-  }
-  __syncthreads();
-  int lo[LOC_PER_THREAD], hi[LOC_PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) { lo[e] = 0; hi[e] = P - 1; }
-  for (int step = P; step > 1; step = (step + 1) >> 1) {
-#pragma unroll
-    for (int e = 0; e < LOC_PER_THREAD; ++e) {
-      if (lo[e] < hi[e]) {
-        const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
-        const int mid = (lo[e] + hi[e]) >> 1;
-        if (comp_less(key[e], i, sk[mid], sp[mid])) hi[e] = mid; else lo[e] = mid + 1;
-      }
-    }
-  }
-  uint32_t rk[LOC_PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
-    rk[e] = i < v.n ? atomicAdd(&hist[lo[e]], 1u) : 0u;
-  }
-  __syncthreads();
-  // this thread's LOC_BPT consecutive buckets: reserve the tile's runs (see k_loc_count)
-  const int b0 = threadIdx.x * LOC_BPT;
-  uint32_t ro[LOC_BPT];
-#pragma unroll
-  for (int q = 0; q < LOC_BPT; ++q) {
-    const uint32_t h = b0 + q < P ? hist[b0 + q] : 0u;
-    ro[q] = h ? atomicAdd(&v.btotal[b0 + q], h) : 0u;
-  }
-  // grid barrier
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(y.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t t0 = wall_clock64();
-    while ((int32_t)(__hip_atomic_load(y.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - y.bar_target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (loc_wait_expired(t0, y.err, 1u)) break;
-    }
-  }
-  __syncthreads();
-  // bucket starts = exclusive scan of the totals; every tile derives them, tile 0 publishes them
-  uint32_t tt[LOC_BPT];
-  uint32_t sum = 0;
-#pragma unroll
-  for (int q = 0; q < LOC_BPT; ++q) {
-    tt[q] = b0 + q < P ? __hip_atomic_load(&v.btotal[b0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    sum += tt[q];
-  }
-  uint32_t total;
-  uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(sum, wsum, &total);
-#pragma unroll
-  for (int q = 0; q < LOC_BPT; ++q) {
-    if (b0 + q < P) {
-      hist[b0 + q] = ex + ro[q];  // each entry is read (above) and written by its owner thread only
-      if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
-    }
-    ex += tt[q];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
-    if (i < v.n) {
-      const uint32_t dst = hist[lo[e]] + rk[e];
-      v.bkeys[dst] = key[e];
       v.bpos[dst] = i;
     }
   }
@@ -846,98 +718,6 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     __syncthreads();
     loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr,
                         index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot);
-  }
-}
-
-// ---- sort + emit in ONE launch.  A block takes the next bucket from a ticket counter (so that every
-// bucket with a smaller number is running or done: whoever waits, waits for blocks that never wait for
-// it), sorts it in LDS, and stitches itself to its predecessors through two hand-offs in global memory
-// (device-scope atomic stores / loads, tagged with the call's sequence number):
-//   A  last_key[b]                       -> the next non-empty bucket learns whether its first key continues it
-//   B  word[b] = {unique keys the bucket adds, last run head + 1}   -> every later bucket sums / maxes them
-// then writes the Localizer's outputs straight from LDS: the sorted pairs never travel through memory.
-__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort_emit(LocView v, LocSync y, const uint32_t* __restrict__ rowid,
-                                                                     const float* __restrict__ value, uint64_t* __restrict__ feaids,
-                                                                     uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
-                                                                     uint32_t* __restrict__ s_row, float* __restrict__ s_val,
-                                                                     uint32_t* __restrict__ d_U, SegListsOut sl) {
-  constexpr int NW = LOC_SORT_THREADS / 64;
-  __shared__ uint64_t ak[LOC_LDS_CAP];
-  __shared__ uint32_t ap[LOC_LDS_CAP];
-  __shared__ uint64_t bk[LOC_LDS_CAP];
-  __shared__ uint32_t bp[LOC_LDS_CAP];
-  __shared__ uint32_t red[2][NW];
-  __shared__ uint32_t wsum[NW], wmax[NW];
-  __shared__ uint32_t sh_b, sh_cont, n_mid, n_hot;
-  const uint32_t P = (uint32_t)v.P;
-  const uint32_t seq = y.seq;
-  for (;;) {
-    __syncthreads();  // LDS and the shared words of the previous bucket are done with
-    if (threadIdx.x == 0) {
-      sh_b = atomicAdd(y.ticket, 1u) - y.ticket_base;
-      n_mid = 0;
-      n_hot = 0;
-    }
-    __syncthreads();
-    const uint32_t b = sh_b;
-    if (b >= P) break;
-    const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
-    const uint32_t n = end - beg;
-    if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_partition: ready for the next call
-    if (n == 0) {
-      if (threadIdx.x == 0) {
-        __hip_atomic_store(&y.flag_a[b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&y.word[b], (uint64_t)seq << 42, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        sl.mid[b] = make_uint2(0u, 0u);
-        sl.hot[b] = make_uint2(0u, 0u);
-      }
-      continue;
-    }
-    const uint64_t* sk;
-    const uint32_t* sp;
-    loc_sort_bucket(v, beg, n, ak, ap, bk, bp, &sk, &sp);
-    const BucketSummary sm = loc_bucket_summary(sk, n, red);
-    if (threadIdx.x == 0) {
-      // hand-off A, then: does my first key continue the previous non-empty bucket?
-      __hip_atomic_store(&v.last_key[b], sm.last_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&y.flag_a[b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      int p = (int)b - 1;
-      while (p >= 0 && v.bstart[p + 1] == v.bstart[p]) --p;
-      uint32_t c = 0;
-      if (p >= 0) {
-        const uint64_t t0 = wall_clock64();
-        while (__hip_atomic_load(&y.flag_a[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-          __builtin_amdgcn_s_sleep(1);
-          if (loc_wait_expired(t0, y.err, 2u)) break;
-        }
-        c = __hip_atomic_load(&v.last_key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sm.first_key ? 1u : 0u;
-      }
-      sh_cont = c;
-      // hand-off B
-      const uint32_t uniq = sm.nheads - c;
-      const uint32_t lhp = sm.lh > 0 ? sm.lh + 1 : (c ? 0u : 1u);
-      __hip_atomic_store(&y.word[b], (uint64_t)seq << 42 | (uint64_t)uniq << 21 | (uint64_t)lhp, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // every earlier bucket's word: unique keys before this bucket, position + 1 of the last run head before it
-    uint32_t part = 0, carry1 = 0;
-    for (uint32_t q = threadIdx.x; q < b; q += blockDim.x) {
-      uint64_t w;
-      const uint64_t t0 = wall_clock64();
-      while (((w = __hip_atomic_load(&y.word[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 42) != seq) {
-        __builtin_amdgcn_s_sleep(1);
-        if (loc_wait_expired(t0, y.err, 2u)) break;
-      }
-      part += (uint32_t)(w >> 21) & LOC_WORD_MASK;
-      const uint32_t lhp = (uint32_t)w & LOC_WORD_MASK;
-      if (lhp) carry1 = max(carry1, v.bstart[q] + lhp);
-    }
-    uint32_t ubase, carry_all;
-    block_exclusive_scan<NW>(part, wsum, &ubase);
-    block_exclusive_max<NW>(carry1, wmax, &carry_all);
-    __syncthreads();
-    loc_emit_bucket<NW>(v, b, beg, n, sk, sp, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr, index, s_row, s_val,
-                        d_U, sl, wsum, wmax, &n_mid, &n_hot);
   }
 }
 

@@ -9,12 +9,18 @@
 // One dfh_shard_step = the batch executor of SGDLearner::IterateData (sgd_learner.cc:131-178) with
 // the store calls turned into one exchange each way:
 //     counts   every rank learns how many keys each peer sends it (+ "I still have data")
-//     K        keys (+ epoch-0 counts) --alltoallv--> owners
+//     L        the keys THIS rank owns never leave it: k_lookup on its own table (row ids, Push(kFeaCount))
+//     K        the other keys (+ epoch-0 counts, same message group) --alltoallv--> owners
 //     R        owners: resolve keys -> rows once, Push(kFeaCount) per source, Pull (one gather)
 //     RW       rows --alltoallv--> workers          fixed stride dfh_row_stride(V_dim)
-//     F        FMLoss::Predict / Evaluate / CalcGrad on the pulled rows (k_forward, k_backward_all)
+//     F        FMLoss::Predict / Evaluate on a mixed source: own keys read the table in place, the others
+//              the pulled rows (k_forward<MIXED>); CalcGrad in two launches of k_backward_all: the others'
+//              keys into gradient rows, the own keys straight into the fused in-place update
 //     G        gradients --alltoallv--> owners
-//     P        owners: Push(kGradient), the sources applied in ascending rank order in ONE launch
+//     P        owners: Push(kGradient) of the other sources, applied in ascending rank order in ONE launch
+// A key's pushes are applied owner first, then the other sources in ascending rank order — one legal
+// execution of the reference's asynchronous Push protocol, the same on every run.  With one rank
+// nothing is exchanged and nothing waits for the host: the step is dfh_sgd_step.
 // Zero staleness: every minibatch reads the model all earlier ones have updated.  No all-reduce:
 // the traffic is key-routed rows, an all-to-all that uses every xGMI link of a GPU at once.
 //
@@ -128,46 +134,88 @@ struct dfh_shard {
 
 namespace {
 
-// alltoallv of device buffers; counts in bytes per peer, contiguous in peer order on both sides
-int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b) {
+// one part of an exchange: per peer p, send_b[p] bytes from d_send + send_off[p] and recv_b[p] bytes into
+// d_recv + recv_off[p] (offsets NULL: contiguous in peer order)
+struct XPart {
+  const void* d_send;
+  const size_t* send_b;
+  const size_t* send_off;
+  void* d_recv;
+  const size_t* recv_b;
+  const size_t* recv_off;
+};
+
+// alltoallv of device buffers, nparts parts in ONE message group (one RCCL launch)
+int comm_exchange(dfh_comm* c, const XPart* parts, int nparts) {
   hipStream_t s = c->ctx->stream;
+  const int W = c->world;
   if (c->rccl) {
     RcclApi* a = rccl_api();
+    bool any = false;
+    for (int i = 0; i < nparts && !any; ++i)
+      for (int p = 0; p < W; ++p) any = any || parts[i].send_b[p] || parts[i].recv_b[p];
+    if (!any) return DFH_OK;
     DFH_RCCL(a->GroupStart());
-    size_t so = 0, ro = 0;
-    for (int p = 0; p < c->world; ++p) {
-      if (send_b[p]) DFH_RCCL(a->Send(static_cast<const char*>(d_send) + so, send_b[p], 0 /* ncclChar */, p, c->rccl, s));
-      if (recv_b[p]) DFH_RCCL(a->Recv(static_cast<char*>(d_recv) + ro, recv_b[p], 0, p, c->rccl, s));
-      so += send_b[p];
-      ro += recv_b[p];
+    for (int i = 0; i < nparts; ++i) {
+      const XPart& x = parts[i];
+      size_t so = 0, ro = 0;
+      for (int p = 0; p < W; ++p) {
+        const size_t sp = x.send_off ? x.send_off[p] : so, rp = x.recv_off ? x.recv_off[p] : ro;
+        if (x.send_b[p]) DFH_RCCL(a->Send(static_cast<const char*>(x.d_send) + sp, x.send_b[p], 0 /* ncclChar */, p, c->rccl, s));
+        if (x.recv_b[p]) DFH_RCCL(a->Recv(static_cast<char*>(x.d_recv) + rp, x.recv_b[p], 0, p, c->rccl, s));
+        so += x.send_b[p];
+        ro += x.recv_b[p];
+      }
     }
     DFH_RCCL(a->GroupEnd());
     return DFH_OK;
   }
-  size_t st = 0, rt = 0;
-  for (int p = 0; p < c->world; ++p) {
-    st += send_b[p];
-    rt += recv_b[p];
+  // host callback: every part staged contiguously through pinned memory
+  for (int i = 0; i < nparts; ++i) {
+    const XPart& x = parts[i];
+    size_t st = 0, rt = 0;
+    for (int p = 0; p < W; ++p) {
+      st += x.send_b[p];
+      rt += x.recv_b[p];
+    }
+    const size_t need = std::max(st, rt);
+    if (need > c->h_cap) {
+      if (c->h_send) DFH_HIP(hipHostFree(c->h_send));
+      if (c->h_recv) DFH_HIP(hipHostFree(c->h_recv));
+      c->h_send = c->h_recv = nullptr;
+      c->h_cap = 0;
+      const size_t cap = std::max<size_t>(need * 2, 1 << 16);
+      DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_send), cap, hipHostMallocDefault));
+      DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_recv), cap, hipHostMallocDefault));
+      c->h_cap = cap;
+    }
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < W; ++p) {
+      const size_t sp = x.send_off ? x.send_off[p] : so;
+      if (x.send_b[p])
+        DFH_HIP(hipMemcpyAsync(c->h_send + so, static_cast<const char*>(x.d_send) + sp, x.send_b[p], hipMemcpyDeviceToHost, s));
+      so += x.send_b[p];
+    }
+    DFH_HIP(hipStreamSynchronize(s));
+    if (c->fn(c->user, c->h_send, x.send_b, c->h_recv, x.recv_b) != 0) {
+      set_error("dfh_comm: the host exchange callback failed");
+      return DFH_ERR_HIP;
+    }
+    for (int p = 0; p < W; ++p) {
+      const size_t rp = x.recv_off ? x.recv_off[p] : ro;
+      if (x.recv_b[p])
+        DFH_HIP(hipMemcpyAsync(static_cast<char*>(x.d_recv) + rp, c->h_recv + ro, x.recv_b[p], hipMemcpyHostToDevice, s));
+      ro += x.recv_b[p];
+    }
+    // h_recv is reused by the next part: its copies must have left it
+    if (i + 1 < nparts) DFH_HIP(hipStreamSynchronize(s));
   }
-  const size_t need = std::max(st, rt);
-  if (need > c->h_cap) {
-    if (c->h_send) DFH_HIP(hipHostFree(c->h_send));
-    if (c->h_recv) DFH_HIP(hipHostFree(c->h_recv));
-    c->h_send = c->h_recv = nullptr;
-    c->h_cap = 0;
-    const size_t cap = std::max<size_t>(need * 2, 1 << 16);
-    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_send), cap, hipHostMallocDefault));
-    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_recv), cap, hipHostMallocDefault));
-    c->h_cap = cap;
-  }
-  if (st) DFH_HIP(hipMemcpyAsync(c->h_send, d_send, st, hipMemcpyDeviceToHost, s));
-  DFH_HIP(hipStreamSynchronize(s));
-  if (c->fn(c->user, c->h_send, send_b, c->h_recv, recv_b) != 0) {
-    set_error("dfh_comm: the host exchange callback failed");
-    return DFH_ERR_HIP;
-  }
-  if (rt) DFH_HIP(hipMemcpyAsync(d_recv, c->h_recv, rt, hipMemcpyHostToDevice, s));
   return DFH_OK;
+}
+
+int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b) {
+  XPart x{d_send, send_b, nullptr, d_recv, recv_b, nullptr};
+  return comm_exchange(c, &x, 1);
 }
 
 template <typename T>
@@ -341,41 +389,54 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   }
   DFH_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const int W = c->world;
-  const int k = t->v.k;
+  const int W = c->world, me = c->rank;
+  const int k = t->v.k, kp = t->v.kp;
   const size_t stride = dfh_row_stride(k);
   int rc;
-  // ---- counts: {keys for every owner, "I have a minibatch"} -> every peer, then to the host (the step's one host wait)
   const bool have = b != nullptr && b->nnz > 0;
   if (b) {
     rc = main_begin(b);
     if (rc) return rc;
   }
-  if (have) {
-    const uint64_t span = W == 1 ? ~0ULL : (~0ULL / (uint64_t)W) + 1;
-    hipLaunchKernelGGL(k_key_ranges64, dim3((W + 256) / 256), dim3(256), 0, st, b->d_feaids, b->d_U, W, span, s->d_splits,
-                       s->d_bounds, 0u);
+  // ---- counts: {keys for every owner, "I have a minibatch"} -> every peer, then to the host (the step's one
+  // host wait).  One rank: every key is its own, nothing to count, nothing to wait for.
+  std::vector<size_t> send(W, 0), recv(W, 0), seg(W + 1, 0), off(W + 1, 0);
+  size_t nrecv = 0, active = b != nullptr ? 1 : 0;
+  uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu;  // ranks [own_lo, own_hi) of the minibatch's unique keys are this rank's
+  if (W > 1) {
+    if (have) {
+      const uint64_t span = (~0ULL / (uint64_t)W) + 1;
+      hipLaunchKernelGGL(k_key_ranges64, dim3((W + 256) / 256), dim3(256), 0, st, b->d_feaids, b->d_U, W, span, s->d_splits,
+                         s->d_bounds, 0u);
+    }
+    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, st, have ? s->d_bounds : (const int64_t*)nullptr, W,
+                       (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
+    DFH_HIP(hipGetLastError());
+    {
+      std::vector<size_t> cb(W, 2 * sizeof(int64_t));
+      rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data());
+      if (rc) return rc;
+    }
+    DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DFH_HIP(hipStreamSynchronize(st));
+    active = 0;
+    for (int p = 0; p < W; ++p) {
+      send[p] = (size_t)s->h_cnt[2 * p];
+      recv[p] = (size_t)s->h_cnt[2 * W + 2 * p];
+      active += s->h_cnt[2 * W + 2 * p + 1] != 0 ? 1 : 0;
+      off[p + 1] = off[p] + send[p];   // = bounds[p + 1]: owner p's keys are ranks [off[p], off[p+1]) of the minibatch
+    }
+    own_lo = (uint32_t)off[me];
+    own_hi = (uint32_t)off[me + 1];
+    send[me] = recv[me] = 0;           // the rank's own keys are not exchanged
+    for (int p = 0; p < W; ++p) {
+      nrecv += recv[p];
+      seg[p + 1] = seg[p] + recv[p];
+    }
   }
-  hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, st, have ? s->d_bounds : (const int64_t*)nullptr, W,
-                     (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
-  DFH_HIP(hipGetLastError());
-  {
-    std::vector<size_t> cb(W, 2 * sizeof(int64_t));
-    rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data());
-    if (rc) return rc;
-  }
-  DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  DFH_HIP(hipStreamSynchronize(st));
-  std::vector<size_t> send(W), recv(W), seg(W + 1, 0);
-  size_t U = 0, nrecv = 0, active = 0;
-  for (int p = 0; p < W; ++p) {
-    send[p] = (size_t)s->h_cnt[2 * p];
-    recv[p] = (size_t)s->h_cnt[2 * W + 2 * p];
-    active += s->h_cnt[2 * W + 2 * p + 1] != 0 ? 1 : 0;
-    U += send[p];
-    nrecv += recv[p];
-    seg[p + 1] = seg[p] + recv[p];
-  }
+  const size_t U = off[W];             // W > 1 only; with one rank the count stays on the device (d_U)
+  const bool any_own = W == 1 ? have : (have && own_hi > own_lo);
+  const bool any_remote = W > 1 && have && (own_lo > 0 || (size_t)own_hi < U);
   if (any_active) *any_active = active != 0 ? 1 : 0;
   ++s->steps;
   if (b) b->nrows_seen += (float)b->nrows;
@@ -388,30 +449,46 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       return rc;
     s->r_cap = cap;
   }
-  if (U > s->w_cap) {
+  if (any_remote && U > s->w_cap) {
     const size_t cap = U + U / 2 + 1024;
     if ((rc = grow(&s->w_rows, cap * stride, st)) || (rc = grow(&s->w_grads, cap * stride, st))) return rc;
     s->w_cap = cap;
   }
-  std::vector<size_t> sb(W), rb(W);
-  auto bytes = [&](size_t unit) {
+  std::vector<size_t> sb(W), rb(W), so(W), sb2(W), rb2(W), so2(W);
+  auto bytes = [&](size_t unit, std::vector<size_t>& sbv, std::vector<size_t>& rbv, std::vector<size_t>& sov) {
     for (int p = 0; p < W; ++p) {
-      sb[p] = send[p] * unit;
-      rb[p] = recv[p] * unit;
+      sbv[p] = send[p] * unit;
+      rbv[p] = recv[p] * unit;
+      sov[p] = off[p] * unit;          // worker-side buffers are indexed by the key's rank u: owner p's slice starts at off[p]
     }
   };
-  // ---- K: keys (+ counts in epoch 0) to their owners
-  bytes(sizeof(uint64_t));
-  rc = comm_alltoallv(c, have ? b->d_feaids : nullptr, sb.data(), s->r_keys, rb.data());
-  if (rc) return rc;
-  if (push_cnt) {
-    if (have && !b->has_cnt) {
-      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, ctx)), dim3(256), 0, st, b->d_col_ptr, b->d_U, b->d_feacnt);
-      DFH_HIP(hipGetLastError());
-      b->has_cnt = true;
+  const uint32_t n_own = own_hi - own_lo;  // meaningless for W == 1 (the kernels clamp to *d_U)
+  // ---- L: this rank's own keys: rows + Push(kFeaCount) on its own table, {row, w} per key for the forward
+  if (any_own) {
+    const bool counts = push_cnt != 0;
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
+                       W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
+                       (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo, counts ? 1 : 0,
+                       (uint32_t*)nullptr, 0, b->d_uw + own_lo);
+    DFH_HIP(hipGetLastError());
+  }
+  // ---- K: the other keys (+ counts in epoch 0) to their owners, one message group
+  if (W > 1) {
+    bytes(sizeof(uint64_t), sb, rb, so);
+    XPart parts[2];
+    parts[0] = XPart{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys, rb.data(), nullptr};
+    int nparts = 1;
+    if (push_cnt) {
+      if (have && !b->has_cnt) {
+        hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, ctx)), dim3(256), 0, st, b->d_col_ptr, b->d_U, b->d_feacnt);
+        DFH_HIP(hipGetLastError());
+        b->has_cnt = true;
+      }
+      bytes(sizeof(float), sb2, rb2, so2);
+      parts[1] = XPart{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt, rb2.data(), nullptr};
+      nparts = 2;
     }
-    bytes(sizeof(float));
-    rc = comm_alltoallv(c, have ? b->d_feacnt : nullptr, sb.data(), s->r_cnt, rb.data());
+    rc = comm_exchange(c, parts, nparts);
     if (rc) return rc;
   }
   // ---- R: owners resolve once, count-push, pull (every source reads the same model version)
@@ -425,36 +502,55 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     rc = dfh_shard_pull_resolved(t, s->r_rowid, nrecv, s->r_rows);
     if (rc) return rc;
   }
-  // ---- RW: rows back to the workers
-  bytes(stride * sizeof(float));
-  rc = comm_alltoallv(c, s->r_rows, rb.data(), s->w_rows, sb.data());
-  if (rc) return rc;
-  // ---- F: the worker's math on the pulled rows
+  // ---- RW: rows back to the workers, each owner's slice to its place among the minibatch's keys
+  if (W > 1) {
+    bytes(stride * sizeof(float), sb, rb, so);
+    XPart x{s->r_rows, rb.data(), nullptr, s->w_rows, sb.data(), so.data()};
+    rc = comm_exchange(c, &x, 1);
+    if (rc) return rc;
+  }
+  // ---- F: the worker's math: own keys on the table, the others on the pulled rows
+  const KeyRange own{own_lo, own_hi, 0u}, others{own_lo, own_hi, 1u};
   if (b) {
-    const int kp = (k + 3) / 4 * 4;
     rc = ensure_xv(b, kp);
     if (rc) return rc;
-    rc = launch_forward(b, packed_src(s->w_rows, k), k, kp);
+    const RowSrc tsrc = table_src(t, b->d_urow);
+    if (any_remote) {
+      hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(U, ctx)), dim3(256), 0, st, s->w_rows, stride, b->d_U, own_lo, own_hi,
+                         b->d_uw);
+      DFH_HIP(hipGetLastError());
+    }
+    MixSrc mix{any_remote ? s->w_rows + 4 : nullptr, stride};
+    rc = launch_forward(b, tsrc, k, kp, b->d_uw, W > 1 ? &mix : nullptr);
     if (rc) return rc;
     if (b->compute_auc) {
       rc = launch_auc(b);
       if (rc) return rc;
     }
-    if (have) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
-      BatchView bv = batch_view(b);
-      hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS)), dim3(256), 0, st, bv,
-                         packed_src(s->w_rows, k), t->v, k, kp);
+    BatchView bv = batch_view(b);
+    const int pgrid = have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
+    if (any_remote) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
+      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows, k), t->v, k, kp, others);
       DFH_HIP(hipGetLastError());
     }
-    if (is_train && have) {
+    if (is_train && any_remote) {
       TableView dummy{};
-      rc = launch_backward<false>(b, packed_src(s->w_rows, k), dummy, s->w_grads, stride, k, kp, nullptr);
+      rc = launch_backward<false>(b, packed_src(s->w_rows, k), dummy, s->w_grads, stride, k, kp, nullptr, others);
       if (rc) return rc;
+    }
+    if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own);
+      if (rc) return rc;
+    } else if (any_own) {
+      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
+      DFH_HIP(hipGetLastError());
     }
   }
   // ---- G + P: gradients to the owners, applied source rank after source rank
-  if (is_train) {
-    rc = comm_alltoallv(c, s->w_grads, sb.data(), s->r_rows, rb.data());
+  if (is_train && W > 1) {
+    bytes(stride * sizeof(float), sb, rb, so);
+    XPart x{s->w_grads, sb.data(), so.data(), s->r_rows, rb.data(), nullptr};
+    rc = comm_exchange(c, &x, 1);
     if (rc) return rc;
     if (nrecv) {
       rc = dfh_shard_push_grad_multi(t, s->r_rowid, s->r_keys, seg.data(), W, 0, s->r_rows);

@@ -110,9 +110,6 @@ class HipBackend:
             self.ctx.set_pipeline(True)
         self.table = capi.Table(self.ctx, capacity, V_dim=V_dim, init_mode=capi.INIT_HASH, **hyper)
         self.batches = [capi.Batch(self.ctx, max_rows, max_nnz) for _ in range(NSLOTS)]
-        if os.environ.get("DFH_BENCH_BACKEND", "nccl") == "gloo":
-            for b in self.batches:   # dry run, processes sharing a GPU: no kernel that needs its whole grid resident
-                b.set_option("localizer_launches", 4)
         self._keep = [None] * NSLOTS
         self.V_dim = V_dim
         self.stride = capi.row_stride(V_dim)
@@ -532,9 +529,6 @@ def bench_main_native(args, rank, world, local_rank, hyper):
         dev.append((capi.DeviceBuffer.from_numpy(ctx, hb["offset"].astype(np.uint32)), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
                     capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
     bts = [capi.Batch(ctx, B, B * S) for _ in range(3)]
-    if shared:
-        for b in bts:   # processes sharing a GPU: no kernel that needs its whole grid resident (dfh_localize.hip)
-            b.set_option("localizer_launches", 4)
 
     def prep(i):
         o, x, l = dev[i % nd]

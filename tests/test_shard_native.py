@@ -7,8 +7,9 @@ calls one entry point per minibatch.
     carries the bytes; RCCL cannot put two ranks on one device), with UNEVEN numbers of minibatches
     per rank (a rank whose data is exhausted keeps serving its shard), uniform and balanced key
     ranges: per-rank logits, loss, penalty and the union of the shards against ONE oracle store that
-    receives the same requests in the documented order (count pushes, pulls, then gradient pushes,
-    each in ascending source-rank order).
+    receives the same requests in the documented order (count pushes, pulls, then gradient pushes: a
+    key's owner first — its own keys never leave it and are updated in place by its backward pass —
+    then the other sources in ascending rank order).
 """
 import os
 import sys
@@ -37,9 +38,22 @@ def make_batches(rank):
     return [random_batch(rng, ROWS, 2 ** 64 - 1 if i % 2 else 3000, 30, binary=(i % 2 == 0)) for i in range(nsteps(rank))]
 
 
-def emulate(oracle, batches, V_dim, hyper):
-    """ONE store receiving the ranks' requests of every step in ascending rank order"""
+def subset_push(store, kind, keys, grads, lens, mask):
+    """push the entries of a ragged gradient vector selected by mask (one bool per key)"""
+    ends = np.cumsum(lens)
+    begs = ends - lens
+    sel = np.flatnonzero(mask)
+    if len(sel) == 0:
+        return
+    g = np.concatenate([grads[begs[j]:ends[j]] for j in sel])
+    store.push(keys[sel], kind, g, lens[sel])
+
+
+def emulate(oracle, batches, V_dim, hyper, splits):
+    """ONE store receiving the ranks' requests of every step: count pushes, pulls, then the gradient pushes —
+    per key the owner's own push first, then the other ranks' in ascending rank order"""
     from oracle import bindings as ob
+    from difacto_amd import sharded
     world = len(batches)
     steps = max(len(b) for b in batches)
     store = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=V_dim, **hyper)
@@ -61,8 +75,11 @@ def emulate(oracle, batches, V_dim, hyper):
             preds[r].append(p)
             loss[r] += oracle.loss_evaluate(b["label"], p)
             grads[r] = oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp)
-        for r in act:
-            store.push(locs[r]["feaids"], ob.GRADIENT, grads[r], pulled[r][1])
+        owner = {r: sharded.owner_of(locs[r]["feaids"], splits) for r in act}
+        for r in act:   # every owner's own keys first
+            subset_push(store, ob.GRADIENT, locs[r]["feaids"], grads[r], pulled[r][1], owner[r] == r)
+        for r in act:   # then the keys other ranks own, source rank after source rank
+            subset_push(store, ob.GRADIENT, locs[r]["feaids"], grads[r], pulled[r][1], owner[r] != r)
     return store, preds, loss
 
 
@@ -132,7 +149,14 @@ def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced):
     port = 29700 + (os.getpid() % 80) + WORLD
     mp.spawn(_worker, args=(WORLD, port, str(tmp_path), balanced), nprocs=WORLD, join=True)
     batches = [make_batches(r) for r in range(WORLD)]
-    store, preds, loss = emulate(oracle, batches, V_DIM, HYPER)
+    from difacto_amd import sharded
+    from difacto_amd.synth import reverse_bytes_np
+    if balanced:
+        ids = np.concatenate([b["index"] for r in range(WORLD) for b in batches[r]])
+        splits = sharded.balanced_splits(reverse_bytes_np(ids), WORLD)
+    else:
+        splits = sharded.uniform_splits(WORLD)
+    store, preds, loss = emulate(oracle, batches, V_DIM, HYPER, splits)
     total, total_loss = 0, 0.0
     for r in range(WORLD):
         got = np.load(os.path.join(tmp_path, "rank%d.npz" % r))
@@ -153,8 +177,9 @@ def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced):
 
 @pytest.mark.gpu
 def test_shard_step_world1_over_rccl_matches_fused():
-    """one rank over the real transport (RCCL loaded at run time, self send / recv): pull -> packed rows
-    -> k_forward / k_backward_all<.., false, ..> -> push must give what the fused step gives"""
+    """one rank over the real transport (RCCL loaded at run time): every key is the rank's own, so the step
+    is the fused step (k_lookup -> k_forward<MIXED> on the table -> k_backward_all with the in-place
+    update) and must give what dfh_sgd_step gives"""
     from conftest import random_batch
     from difacto_amd import capi
     ctx = capi.Context(0)
