@@ -65,8 +65,8 @@ def parse_args():
                          "keeps 2 in flight)")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
-    ap.add_argument("--prep-gate", action="store_true",
-                    help="A/B: the Localizer's sort / emit launches wait for the step queued last to end (ctx option prep_gate)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: validated launch tuning passed to dfh_ctx_set_option (fwd_depth, bwd_small_blocks, ...)")
     ap.add_argument("--no-relocalize", action="store_true",
                     help="diagnostic (NOT the metric): localize every batch object once and time lookup + forward + backward alone")
     ap.add_argument("--uniform-ranges", action="store_true",
@@ -288,8 +288,9 @@ def main():
     # depth+1 batch objects: batches t+1 .. t+depth are localized on the preparation streams while
     # batch t trains on the main stream (updates are still applied strictly in batch order)
     depth = 0 if args.no_pipeline else max(1, min(args.prep_streams, 4))
-    if args.prep_gate:
-        ctx.set_option("prep_gate", 1)
+    for kv in args.ctx_option:
+        name, val = kv.split("=", 1)
+        ctx.set_option(name, int(val))
     ctx.set_pipeline(depth)
     ahead = max(depth, 1)
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers

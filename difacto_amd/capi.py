@@ -28,7 +28,7 @@ SYMBOLS = [
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
-    "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step",
+    "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
 ]
 K_COUNT = 7
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
@@ -169,6 +169,7 @@ def lib():
     L.dfh_shard_destroy.argtypes = [vp]
     L.dfh_shard_owned_range.argtypes = [vp, vp, PP(u64), PP(u64)]
     L.dfh_shard_step.argtypes = [vp, vp, i32, i32, PP(i32)]
+    L.dfh_shard_prefetch_counts.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -632,6 +633,10 @@ class Shard:
         _ck(lib().dfh_shard_step(self.h, batch.h if batch is not None else None, 1 if is_train else 0, 1 if push_cnt else 0,
                                  C.byref(act)))
         return bool(act.value)
+
+    def prefetch_counts(self, next_batch):
+        """collective, right before step(): the minibatch of the FOLLOWING step (localize queued) or None"""
+        _ck(lib().dfh_shard_prefetch_counts(self.h, next_batch.h if next_batch is not None else None))
 
     def owned_range(self):
         lo, hi = C.c_uint64(0), C.c_uint64(0)

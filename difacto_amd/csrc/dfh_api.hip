@@ -38,9 +38,6 @@ struct dfh_ctx {
   int fwd_blocks = 0;          // cap on the forward grid (0: one wave per example)
   int bwd_small_blocks = 2048; // cap on the short-segment blocks of the backward/update launch
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
-  int prep_gate = 0;           // 1: a Localizer's sort / emit launches wait for the step queued last to end (they cost
-                               //    a concurrent backward/update launch more than their own time; count / scatter do not)
-  hipEvent_t last_step_ev = nullptr;  // ev_free of the step queued last on the main stream
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
   struct Span { int id; hipEvent_t a, b; };
@@ -204,7 +201,6 @@ int main_end(dfh_batch* b) {
   if (c->pipeline) {
     DFH_HIP(hipEventRecord(b->ev_free, c->stream));
     b->free_pending = true;
-    c->last_step_ev = b->ev_free;
   }
   return DFH_OK;
 }
@@ -631,9 +627,6 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "bwd_small_blocks") {
     DFH_ARG(value >= 1 && value <= 65536, "bwd_small_blocks must be in [1, 65536]");
     c->bwd_small_blocks = value;
-  } else if (n == "prep_gate") {
-    DFH_ARG(value == 0 || value == 1, "prep_gate must be 0 or 1");
-    c->prep_gate = value;
   } else if (n == "prep_priority") {
     DFH_ARG(value >= -1 && value <= 1, "prep_priority must be -1 (lowest), 0 (default) or 1 (highest)");
     DFH_ARG(c->preps.empty(), "prep_priority must be set before dfh_ctx_set_pipeline creates the streams");
@@ -1604,7 +1597,6 @@ int dfh_batch_destroy(dfh_batch* b) {
   hipSetDevice(b->ctx->device);
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
-  if (b->ev_free && b->ctx->last_step_ev == b->ev_free) b->ctx->last_step_ev = nullptr;
   if (b->ev_free) hipEventDestroy(b->ev_free);
   if (b->ev_staged) hipEventDestroy(b->ev_staged);
   if (b->h_stage) hipHostFree(b->h_stage);
@@ -1798,7 +1790,6 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
 #define DFH_LOC_GRID_CAP 1024
 #endif
     const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
-    if (c->pipeline && c->prep_gate && c->last_step_ev && s != c->stream) DFH_HIP(hipStreamWaitEvent(s, c->last_step_ev, 0));
     hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
     hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
                        b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,

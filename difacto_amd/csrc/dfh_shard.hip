@@ -130,6 +130,12 @@ struct dfh_shard {
   float* w_grads = nullptr;
   size_t w_cap = 0;
   uint64_t steps = 0;
+  // counts of the FOLLOWING step, exchanged inside the current one (dfh_shard_prefetch_counts)
+  dfh_batch* next_b = nullptr;
+  bool next_armed = false;            // the next dfh_shard_step issues the counts exchange of next_b
+  bool counts_ready = false;          // h_cnt holds the counts of counts_for; cnt_ev marks their arrival
+  dfh_batch* counts_for = nullptr;
+  hipEvent_t cnt_ev = nullptr;
 };
 
 namespace {
@@ -348,6 +354,7 @@ int dfh_shard_create(dfh_table* t, dfh_comm* c, const uint64_t* splits, dfh_shar
   DFH_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bounds), (W + 1) * sizeof(int64_t)));
   DFH_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_cnt), 4 * (size_t)W * sizeof(int64_t)));
   DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), 4 * (size_t)W * sizeof(int64_t), hipHostMallocDefault));
+  DFH_HIP(hipEventCreateWithFlags(&s->cnt_ev, hipEventDisableTiming));
   DFH_HIP(hipStreamSynchronize(st));
   *out = s;
   return DFH_OK;
@@ -361,6 +368,7 @@ int dfh_shard_destroy(dfh_shard* s) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (s->h_cnt) hipHostFree(s->h_cnt);
+  if (s->cnt_ev) hipEventDestroy(s->cnt_ev);
   delete s;
   return DFH_OK;
 }
@@ -371,6 +379,46 @@ int dfh_shard_owned_range(dfh_shard* s, const uint64_t* splits, uint64_t* key_lo
   const uint64_t span = W == 1 ? ~0ULL : (~0ULL / (uint64_t)W) + 1;
   *key_lo = r == 0 ? 0 : (splits ? splits[r - 1] : (uint64_t)r * span);
   *key_hi = r == W - 1 ? 0 : (splits ? splits[r] : (uint64_t)(r + 1) * span);  // 0: no upper bound
+  return DFH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// queue, on the main stream: owner ranges of b's keys -> {keys for every owner, "I have a minibatch"} ->
+// every peer -> pinned host memory
+int queue_counts(dfh_shard* s, dfh_batch* b) {
+  dfh_comm* c = s->c;
+  hipStream_t st = c->ctx->stream;
+  const int W = c->world;
+  const bool have = b != nullptr && b->nnz > 0;
+  if (have) {
+    const uint64_t span = (~0ULL / (uint64_t)W) + 1;
+    hipLaunchKernelGGL(k_key_ranges64, dim3((W + 256) / 256), dim3(256), 0, st, b->d_feaids, b->d_U, W, span, s->d_splits,
+                       s->d_bounds, 0u);
+  }
+  hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, st, have ? s->d_bounds : (const int64_t*)nullptr, W,
+                     (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
+  DFH_HIP(hipGetLastError());
+  std::vector<size_t> cb(W, 2 * sizeof(int64_t));
+  int rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data());
+  if (rc) return rc;
+  DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  return DFH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dfh_shard_prefetch_counts(dfh_shard* s, dfh_batch* b_next) {
+  DFH_ARG(s, "dfh_shard_prefetch_counts: NULL shard");
+  DFH_ARG(!b_next || b_next->ctx == s->t->ctx, "batch and shard must share a context");
+  if (b_next && !b_next->localized) {
+    set_error("dfh_shard_prefetch_counts: batch is not localized (call dfh_localize first)");
+    return DFH_ERR_STATE;
+  }
+  s->next_b = b_next;
+  s->next_armed = s->c->world > 1;  // one rank: there is nothing to count
   return DFH_OK;
 }
 
@@ -404,21 +452,16 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   size_t nrecv = 0, active = b != nullptr ? 1 : 0;
   uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu;  // ranks [own_lo, own_hi) of the minibatch's unique keys are this rank's
   if (W > 1) {
-    if (have) {
-      const uint64_t span = (~0ULL / (uint64_t)W) + 1;
-      hipLaunchKernelGGL(k_key_ranges64, dim3((W + 256) / 256), dim3(256), 0, st, b->d_feaids, b->d_U, W, span, s->d_splits,
-                         s->d_bounds, 0u);
-    }
-    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, st, have ? s->d_bounds : (const int64_t*)nullptr, W,
-                       (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
-    DFH_HIP(hipGetLastError());
-    {
-      std::vector<size_t> cb(W, 2 * sizeof(int64_t));
-      rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data());
+    if (s->counts_ready && s->counts_for == b) {
+      // exchanged inside the previous step: long arrived
+      DFH_HIP(hipEventSynchronize(s->cnt_ev));
+    } else {
+      DFH_ARG(!s->counts_ready, "dfh_shard_step: the batch differs from the one announced to dfh_shard_prefetch_counts");
+      rc = queue_counts(s, b);
       if (rc) return rc;
+      DFH_HIP(hipStreamSynchronize(st));
     }
-    DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    DFH_HIP(hipStreamSynchronize(st));
+    s->counts_ready = false;
     active = 0;
     for (int p = 0; p < W; ++p) {
       send[p] = (size_t)s->h_cnt[2 * p];
@@ -440,7 +483,10 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   if (any_active) *any_active = active != 0 ? 1 : 0;
   ++s->steps;
   if (b) b->nrows_seen += (float)b->nrows;
-  if (active == 0) return b ? main_end(b) : DFH_OK;
+  if (active == 0) {
+    s->next_armed = false;  // the epoch is over: nothing follows
+    return b ? main_end(b) : DFH_OK;
+  }
   // ---- buffers
   if (nrecv > s->r_cap) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
@@ -545,6 +591,21 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
       DFH_HIP(hipGetLastError());
     }
+  }
+  // ---- the counts of the FOLLOWING step (dfh_shard_prefetch_counts): on their way to the host while this
+  // step's gradients travel and are applied, so that the next call finds them there
+  if (s->next_armed) {
+    s->next_armed = false;
+    dfh_batch* nb = s->next_b;
+    if (nb) {
+      rc = main_begin(nb);  // its Localizer (preparation stream) has to be through
+      if (rc) return rc;
+    }
+    rc = queue_counts(s, nb);
+    if (rc) return rc;
+    DFH_HIP(hipEventRecord(s->cnt_ev, st));
+    s->counts_ready = true;
+    s->counts_for = nb;
   }
   // ---- G + P: gradients to the owners, applied source rank after source rank
   if (is_train && W > 1) {

@@ -148,7 +148,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   dfh_table* table = GetUpdater()->table();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
   auto ensure = [&](size_t rows, size_t nnz) {
-    if (batch_[0] && rows <= batch_rows_ && nnz <= batch_nnz_) return;
+    if (batch_[0] && batch_[1] && rows <= batch_rows_ && nnz <= batch_nnz_) return;
     for (auto& b : batch_) {
       if (b) {
         dfh_progress p;
@@ -169,7 +169,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     const auto& blk = reader.Value();
     // a growing batch needs new buffers while the other slot may be in flight: drain first (the
     // main loop has already trained the pending batch)
-    if (!batch_[0] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
+    if (!batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
       DFH_CALL(dfh_ctx_sync(ctx));
       sgd::Progress keep;
       for (auto& b : batch_) {
@@ -195,7 +195,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     DFH_CALL(dfh_batch_lookup(table, b));
   };
   auto needs_growth = [&](const dmlc::RowBlock<feaid_t>& blk) {
-    return !batch_[0] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
+    return !batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
   };
   bool have = reader.Next();
   int i = 0;
@@ -228,7 +228,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
 
 // ---- the sharded worker loop: sgd_learner.cc:129-227 with Store::Pull / Push turned into the exchange of
 // dfh_shard_step.  The ranks step together; a rank whose part of the data is exhausted keeps serving
-// its shard (b = NULL) until nobody has a minibatch left.
+// its shard (b = NULL) until nobody has a minibatch left.  Two batch objects: while one minibatch steps,
+// the next is copied in and localized on the preparation stream, and its per-owner key counts travel
+// inside the running step (dfh_shard_prefetch_counts) — the two minibatches the reference's batch
+// tracker keeps in flight (sgd_learner.cc:219-223), without its staleness.
 void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
@@ -236,7 +239,7 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
   BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
                      train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   dfh_ctx* ctx = DeviceContext::Get();
-  DFH_CALL(dfh_ctx_set_pipeline(ctx, 0));
+  DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
   auto drain = [&](dfh_batch* b) {
     dfh_progress p;
     DFH_CALL(dfh_batch_progress(b, &p, 1));
@@ -244,31 +247,56 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
     q.loss = p.loss; q.penalty = p.penalty; q.auc = p.auc; q.nrows = p.nrows;
     progress->Merge(q);
   };
-  int active = 1;
-  while (active) {
-    dfh_batch* b = nullptr;
-    if (reader.Next()) {
-      const auto& blk = reader.Value();
-      const size_t nnz = blk.offset[blk.size] - blk.offset[0];
-      if (!batch_[0] || blk.size > batch_rows_ || nnz > batch_nnz_) {
-        if (batch_[0]) {
-          drain(batch_[0]);
-          dfh_batch_destroy(batch_[0]);
-        }
-        batch_rows_ = std::max<size_t>(blk.size, batch_rows_);
-        batch_nnz_ = std::max(nnz * 2, batch_nnz_);
-        DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &batch_[0]));
-        DFH_CALL(dfh_batch_set_option(batch_[0], "compute_auc", 1));  // sgd_learner.cc:153-155
-      }
-      b = batch_[0];
-      DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
-      DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
+  size_t cap_rows[2] = {0, 0}, cap_nnz[2] = {0, 0};
+  for (int q = 0; q < 2; ++q) {  // objects left by an earlier job keep their size
+    if (batch_[q]) {
+      cap_rows[q] = batch_rows_;
+      cap_nnz[q] = batch_nnz_;
     }
-    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step: batch " << (b ? "yes" : "none");
-    DFH_CALL(dfh_shard_step(ss->shard(), b, train ? 1 : 0, push_cnt ? 1 : 0, &active));
-    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step done: active " << active;
   }
-  if (batch_[0]) drain(batch_[0]);
+  // the next minibatch of this rank into slot `q` (whose previous occupant has been stepped), or NULL
+  auto prepare = [&](int q) -> dfh_batch* {
+    if (!reader.Next()) return nullptr;
+    const auto& blk = reader.Value();
+    const size_t nnz = blk.offset[blk.size] - blk.offset[0];
+    if (!batch_[q] || blk.size > cap_rows[q] || nnz > cap_nnz[q]) {
+      // only this slot grows: the other one may hold a prepared minibatch that has not stepped yet
+      if (batch_[q]) {
+        drain(batch_[q]);              // synchronises: its last step is through
+        dfh_batch_destroy(batch_[q]);
+      }
+      cap_rows[q] = std::max<size_t>(blk.size, std::max(cap_rows[q], batch_rows_));
+      cap_nnz[q] = std::max(nnz * 2, std::max(cap_nnz[q], batch_nnz_));
+      DFH_CALL(dfh_batch_create(ctx, cap_rows[q], std::max<size_t>(cap_nnz[q], 1), &batch_[q]));
+      DFH_CALL(dfh_batch_set_option(batch_[q], "compute_auc", 1));  // sgd_learner.cc:153-155
+    }
+    dfh_batch* b = batch_[q];
+    DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
+    DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
+    return b;
+  };
+  dfh_batch* cur = prepare(0);
+  int active = 1;
+  for (int i = 0; active; ++i) {
+    dfh_batch* nxt = prepare((i + 1) & 1);
+    DFH_CALL(dfh_shard_prefetch_counts(ss->shard(), nxt));
+    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step: batch " << (cur ? "yes" : "none");
+    DFH_CALL(dfh_shard_step(ss->shard(), cur, train ? 1 : 0, push_cnt ? 1 : 0, &active));
+    if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step done: active " << active;
+    cur = nxt;
+  }
+  for (int q = 0; q < 2; ++q) {
+    if (!batch_[q]) continue;
+    drain(batch_[q]);
+    // the fused loop sizes both objects alike: keep that invariant for whichever job runs next
+    if (cap_rows[q] != std::max(cap_rows[0], cap_rows[1]) || cap_nnz[q] != std::max(cap_nnz[0], cap_nnz[1])) {
+      dfh_batch_destroy(batch_[q]);
+      batch_[q] = nullptr;
+    }
+  }
+  batch_rows_ = std::max(cap_rows[0], cap_rows[1]);
+  batch_nnz_ = std::max(cap_nnz[0], cap_nnz[1]);
+  if (!batch_[0] && batch_[1]) std::swap(batch_[0], batch_[1]);
   uint64_t nkeys;
   DFH_CALL(dfh_table_size(GetUpdater()->table(), &nkeys));  // surfaces a full shard as an error
 }

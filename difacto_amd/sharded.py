@@ -538,6 +538,7 @@ def bench_main_native(args, rank, world, local_rank, hyper):
 
     def step(i):
         prep(i + 1)
+        shard.prefetch_counts(bts[(i + 1) % len(bts)])   # the next step will not wait for its counts mid-way
         shard.step(bts[i % len(bts)], is_train=True, push_cnt=True)
 
     prep(0)

@@ -336,6 +336,14 @@ int dfh_shard_owned_range(dfh_shard* s, const uint64_t* splits, uint64_t* key_lo
  * no-op: the epoch is over).  Asynchronous apart from one small host wait; progress accumulates in
  * the batch as in dfh_sgd_step. */
 int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* any_active);
+/* Optional, COLLECTIVE like the step: called on every rank right before dfh_shard_step, it names the
+ * minibatch of the FOLLOWING step (its dfh_localize already queued; NULL if this rank has none left).
+ * The step then sends that minibatch's per-owner key counts on their way inside itself — behind its own
+ * backward pass, while its gradients travel — and the following dfh_shard_step (which must be given
+ * exactly that batch) starts with the counts already on the host instead of waiting for them mid-way:
+ * what the reference's batch tracker achieves by keeping two minibatches in flight
+ * (sgd_learner.cc:219-223), here without staleness.  No-op with one rank. */
+int dfh_shard_prefetch_counts(dfh_shard* s, dfh_batch* b_next);
 
 /* raw device memory for hosts without a HIP runtime of their own */
 int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);

@@ -83,7 +83,7 @@ def emulate(oracle, batches, V_dim, hyper, splits):
     return store, preds, loss
 
 
-def _worker(rank, world, port, out_dir, balanced):
+def _worker(rank, world, port, out_dir, balanced, prefetch):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -107,22 +107,39 @@ def _worker(rank, world, port, out_dir, balanced):
     sh = capi.Shard(tb, comm, splits)
     batches = make_batches(rank)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
-    bt = capi.Batch(ctx, ROWS, max_nnz)
+    bts = [capi.Batch(ctx, ROWS, max_nnz) for _ in range(2)]
+    bt = bts[0]
+    if prefetch:
+        ctx.set_pipeline(1)   # the next minibatch is localized on the preparation stream while this one steps
+
+    def prepare(j):
+        if j >= len(batches):
+            return None
+        b = batches[j]
+        bts[j % 2].load_host(b["offset"], b["index"], b["value"], b["label"])
+        bts[j % 2].localize()
+        return bts[j % 2]
+
     preds, i = [], 0
+    cur = prepare(0)
     while True:
-        b = batches[i] if i < len(batches) else None
-        if b is not None:
-            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
-            bt.localize()
-        active = sh.step(bt if b is not None else None, is_train=True, push_cnt=i < PUSH_CNT_STEPS)
+        if prefetch:
+            # the following step's per-owner counts travel inside this step (dfh_shard_prefetch_counts)
+            nxt = prepare(i + 1)
+            sh.prefetch_counts(nxt)
+        active = sh.step(cur, is_train=True, push_cnt=i < PUSH_CNT_STEPS)
         if not active:
             break
-        if b is not None:
-            preds.append(bt.pred().copy())
+        if cur is not None:
+            preds.append(cur.pred().copy())
         i += 1
+        cur = nxt if prefetch else prepare(i)
     assert i == max(nsteps(r) for r in range(world))
     tb.check()
-    prog = bt.progress()
+    progs = [x.progress() for x in bts]
+    import types
+    prog = types.SimpleNamespace(loss=sum(p.loss for p in progs), nrows=sum(p.nrows for p in progs),
+                                 penalty=sum(p.penalty for p in progs))
     tot = comm.allreduce_sum([prog.loss, prog.nrows, 1.0])
     assert tot[2] == world
     from oracle import bindings as ob
@@ -137,17 +154,17 @@ def _worker(rank, world, port, out_dir, balanced):
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), preds=np.concatenate(preds), loss=prog.loss, penalty=prog.penalty,
              nrows=prog.nrows, total_loss=tot[0], total_rows=tot[1], nkeys=tb.size(), keys=mine, vals=vals, lens=lens)
     dist.barrier()
-    for o_ in (sh, bt, tb, comm):
+    for o_ in [sh] + bts + [tb, comm]:
         o_.close()
     ctx.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("WORLD,balanced", [(2, False), (4, True)])
-def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced):
-    port = 29700 + (os.getpid() % 80) + WORLD
-    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), balanced), nprocs=WORLD, join=True)
+@pytest.mark.parametrize("WORLD,balanced,prefetch", [(2, False, False), (2, True, True), (4, True, False), (4, False, True)])
+def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced, prefetch):
+    port = 29700 + (os.getpid() % 80) + WORLD + (10 if prefetch else 0)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), balanced, prefetch), nprocs=WORLD, join=True)
     batches = [make_batches(r) for r in range(WORLD)]
     from difacto_amd import sharded
     from difacto_amd.synth import reverse_bytes_np
