@@ -1587,6 +1587,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
   DFH_HIP(hipMemsetAsync(b->d_auc_acc, 0, 8 * sizeof(unsigned long long), c->stream));
+  // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
+  // all-ones makes a stray use fault at once instead of reading some row
+  DFH_HIP(hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream));
+  DFH_HIP(hipMemsetAsync(b->d_uw, 0xFF, N * sizeof(uint2), c->stream));
   DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
   return DFH_OK;

@@ -529,9 +529,10 @@ struct KeyRow {   // what a role prefetches for one key
 
 template <bool FUSED>
 __device__ __forceinline__ KeyRow load_key_row(const RowSrc& src, const TableView& t, uint32_t u, int sub, bool sub_ok,
-                                               int k, int kp) {
+                                               int k, int kp, bool resolved = true) {
   KeyRow kr;
-  kr.r = src.urow ? src.urow[u] : u;
+  // resolved = false: the key is outside the launch's range and may have no row id (speculative load: row 0)
+  kr.r = src.urow ? (resolved ? src.urow[u] : 0u) : u;
   const float* wp = src.wbase + (size_t)kr.r * src.wstride;
   kr.v = make_float4(0.f, 0.f, 0.f, 0.f);
   kr.acc = kr.v;
@@ -795,8 +796,9 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
       // requested for every lane group (keys left to the mid / hot roles waste one speculative read)
       const uint32_t u = min(u0 + grp, U - 1);
       const uint32_t beg = b.col_ptr[u], end_all = b.col_ptr[u + 1];
-      const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-      const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL && key_in(rg, u);
+      const bool in_rg = key_in(rg, u);
+      const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp, in_rg);
+      const bool mine = (u0 + grp) < U && end_all - beg <= BWD_SMALL && in_rg;
       const uint32_t end = mine ? end_all : beg;
       KeySums s;
       s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -879,7 +881,9 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
       u[h] = min(uu, U - 1);
       beg[h] = a.col_ptr[u[h]];
       end[h] = a.col_ptr[u[h] + 1];
-      r[h] = a.urow[u[h]];
+      // keys outside the launch's range have no row id in urow (the sharded store resolves only the keys
+      // this rank owns): their speculative row loads below go to row 0
+      r[h] = key_in(rg, u[h]) ? a.urow[u[h]] : 0u;
     }
     float4 h0[KPG], v[KPG], acc[KPG], gv[KPG];
     float fea_cnt[KPG], gw[KPG], xxp[KPG];
@@ -1006,7 +1010,7 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
 // short-segment code (fused update on the resident table).
 // ---------------------------------------------------------------------------
 #ifndef DFH_BWD_WAVES
-#define DFH_BWD_WAVES 6
+#define DFH_BWD_WAVES 8
 #endif
 template <int L, bool FUSED, bool LEAN, bool EXACT>
 __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(BatchView b, RowSrc src, TableView t, float* __restrict__ grads,

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """End-to-end rate of build/difacto from files (PCIe and parsing included): Criteo-shaped rows written
 as criteo text, libsvm text and .rec (RecordIO of LZ4 compressed row blocks), one training epoch each
-with the C3 hyper-parameters.  usage: e2e_cli.py [rows] -> one JSON object per format on stdout"""
+with the C3 hyper-parameters.  Every format is run on the generated file (`rows` rows) and on that file
+repeated `rep` times; the difference of the two wall times over the difference of the row counts is the
+steady-state rate (process start, table allocation and the first-touch costs cancel).
+usage: e2e_cli.py [rows [rep]] -> one JSON object per format on stdout"""
 import json, os, subprocess, sys, tempfile, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +12,7 @@ sys.path.insert(0, R)
 from oracle import ingest as oi
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+rep = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rng = np.random.default_rng(1)
 d = tempfile.mkdtemp(prefix="e2e_")
 # tokens: 13 integer slots (10 000 values each), 26 categorical slots (8 hex chars, Zipf-ish)
@@ -31,12 +35,26 @@ open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
 sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
 common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
           "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
-for fmt in ("criteo", "libsvm", "rec"):
-    path = os.path.join(d, "train." + fmt)
+def run(path, fmt):
     t0 = time.time()
     r = subprocess.run([os.path.join(R, "build", "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=900)
     dt = time.time() - t0
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
-    print(json.dumps(dict(format=fmt, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt, rows_per_s=rows / dt, rc=r.returncode,
-                          line=loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])))
+    return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])
+
+
+for fmt in ("criteo", "libsvm", "rec"):
+    path = os.path.join(d, "train." + fmt)
+    big = os.path.join(d, "train_x%d.%s" % (rep, fmt))
+    with open(big, "wb") as out:   # text lines and RecordIO records both concatenate
+        blob = open(path, "rb").read()
+        for _ in range(rep):
+            out.write(blob)
+    dt1, rc1, line1 = run(path, fmt)
+    dt2, rc2, line2 = run(big, fmt)
+    steady = rows * (rep - 1) / max(dt2 - dt1, 1e-9)
+    print(json.dumps(dict(format=fmt, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt1, rows_per_s=rows / dt1, rc=rc1,
+                          line=line1, rows_big=rows * rep, wall_s_big=dt2, rows_per_s_big=rows * rep / dt2, rc_big=rc2,
+                          steady_rows_per_s=steady, steady_mb_per_s=steady * os.path.getsize(path) / rows / 1e6, line_big=line2)))
+    os.remove(big)

@@ -36,5 +36,5 @@ try:
   print('$f', round(d['value']/1e6,2), round(d['ms_per_step'],4), {k:round(x,4) for k,x in (d.get('kernel_ms_per_step') or {}).items()}, 'live fwd/bwd', (d.get('roofline') or {}).get('avg_launch_ms'), (d.get('roofline_backward') or {}).get('avg_launch_ms'))
 except Exception as e: print('$f ERR', e); print(open('$O/$f.err').read()[-800:])"
 done
-find $O -name "*.db" -size +18M -delete
+find $O -name "*.db" -delete; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/prof_c3 $O/prof_c3_np $O/prof_w1 $O/prof_c5
 du -sh $O
