@@ -13,8 +13,10 @@
  * A file is cut into num_parts byte ranges; text parts start at the first line start at or after
  * their first byte and end with the line crossing their last; RecordIO parts at record heads (the
  * magic word at a 4-byte-aligned position followed by a head or whole-record flag).  Rows come in
- * chunks (a chunk of text / one record), parsed by a background thread one chunk ahead of the
- * consumer — the overlap the reference gets from dmlc's ThreadedParser (reader.h:44).
+ * chunks (a chunk of text / one record).  A chunk is FETCHED from the file in order (cheap) and PARSED
+ * (tokenising, CityHash64, LZ4: all of the time) by a pool of background threads, several chunks in
+ * flight, delivered to the consumer in file order — dmlc's ThreadedParser (reader.h:44) overlaps one
+ * parser thread with the consumer; one thread feeds 0.7-2.8 M rows/s, the device takes 77 M.
  *
  * BatchReader::Next() fills minibatches of batch_size rows across chunk borders, with the optional
  * shuffle buffer (a nested reader of shuffle_buf_size rows whose order is permuted) and negative
@@ -41,12 +43,28 @@ namespace difacto {
 
 typedef dmlc::data::RowBlockContainer<feaid_t> RowChunk;
 
-/*! \brief a parser yields the rows of its part of the file chunk by chunk */
+/*! \brief a parser yields the rows of its part of the file chunk by chunk, in two stages so that the
+ * expensive one can run on several threads: Fetch (sequential, file order) and Parse (a pure function
+ * of the fetched bytes) */
 class ChunkParser {
  public:
   virtual ~ChunkParser() {}
-  /*! \brief fills *out (cleared first) with the next chunk of rows; false at the end of the part */
-  virtual bool ParseNext(RowChunk* out) = 0;
+  /*! \brief the raw bytes of the next chunk; false at the end of the part.  Called under the reader's lock. */
+  virtual bool Fetch(std::string* raw) = 0;
+  /*! \brief rows of a fetched chunk into *out (cleared first; may stay empty).  Thread-safe. */
+  virtual void Parse(std::string* raw, RowChunk* out) const = 0;
+  /*! \brief single-threaded convenience: the next non-empty chunk of rows */
+  bool ParseNext(RowChunk* out) {
+    out->Clear();
+    while (out->Size() == 0) {
+      if (!Fetch(&raw_)) return false;
+      Parse(&raw_, out);
+    }
+    return true;
+  }
+
+ private:
+  std::string raw_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -101,20 +119,17 @@ class LibsvmChunkParser : public ChunkParser {
  public:
   LibsvmChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes)
       : src_(uri, part, nparts, chunk_bytes) {}
-  bool ParseNext(RowChunk* out) override {
+  bool Fetch(std::string* raw) override { return src_.Next(raw); }
+  void Parse(std::string* raw, RowChunk* out) const override {
     out->Clear();
-    while (out->Size() == 0) {
-      if (!src_.Next(&buf_)) return false;
-      const char* p = buf_.c_str();
-      const char* const end = p + buf_.size();
-      while (p < end) {
-        const char* eol = static_cast<const char*>(memchr(p, '\n', end - p));
-        if (!eol) eol = end;
-        ParseLine(p, eol, out);
-        p = eol + 1;
-      }
+    const char* p = raw->c_str();
+    const char* const end = p + raw->size();
+    while (p < end) {
+      const char* eol = static_cast<const char*>(memchr(p, '\n', end - p));
+      if (!eol) eol = end;
+      ParseLine(p, eol, out);
+      p = eol + 1;
     }
-    return true;
   }
 
  private:
@@ -144,7 +159,6 @@ class LibsvmChunkParser : public ChunkParser {
     out->offset.push_back(out->index.size());
   }
   TextChunks src_;
-  std::string buf_;
 };
 
 /**
@@ -158,13 +172,10 @@ class CriteoChunkParser : public ChunkParser {
  public:
   CriteoChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes, bool is_train)
       : src_(uri, part, nparts, chunk_bytes), is_train_(is_train) {}
-  bool ParseNext(RowChunk* out) override {
+  bool Fetch(std::string* raw) override { return src_.Next(raw); }
+  void Parse(std::string* raw, RowChunk* out) const override {
     out->Clear();
-    while (out->Size() == 0) {
-      if (!src_.Next(&buf_)) return false;
-      Parse(&buf_[0], &buf_[0] + buf_.size(), is_train_, out);
-    }
-    return true;
+    Parse(raw->data(), raw->data() + raw->size(), is_train_, out);
   }
   /*! \brief the reference's parse loop over one chunk of text */
   static void Parse(const char* p, const char* end, bool is_train, RowChunk* blk) {
@@ -208,7 +219,6 @@ class CriteoChunkParser : public ChunkParser {
   }
   TextChunks src_;
   bool is_train_;
-  std::string buf_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -318,25 +328,23 @@ inline void DecompressRowBlock(const char* data, size_t size, RowChunk* blk) {
 class CrbRecordParser : public ChunkParser {
  public:
   CrbRecordParser(const std::string& uri, unsigned part, unsigned nparts) : src_(uri, part, nparts) {}
-  bool ParseNext(RowChunk* out) override {
-    out->Clear();
-    while (out->Size() == 0) {
-      if (!src_.NextRecord(&rec_)) return false;
-      CHECK_NE(rec_.size(), 0u);
-      DecompressRowBlock(rec_.data(), rec_.size(), out);
-    }
-    return true;
+  bool Fetch(std::string* raw) override { return src_.NextRecord(raw); }
+  void Parse(std::string* raw, RowChunk* out) const override {
+    CHECK_NE(raw->size(), 0u);
+    DecompressRowBlock(raw->data(), raw->size(), out);
   }
 
  private:
   RecordIOPart src_;
-  std::string rec_;
 };
 
-/*! \brief Reader (src/reader/reader.h:27-58): format -> parser, one chunk parsed ahead on a thread */
+/*! \brief Reader (src/reader/reader.h:27-58): format -> parser; chunks are parsed by a pool of threads,
+ * up to 2 x threads of them in flight, and handed to the consumer in file order */
 class Reader {
  public:
-  Reader(const std::string& uri, const std::string& format, unsigned part, unsigned nparts, size_t chunk_bytes = 1 << 24) {
+  Reader(const std::string& uri, const std::string& format, unsigned part, unsigned nparts, size_t chunk_bytes = 1 << 22,
+         int nthreads = 0) {
+    if (const char* e = getenv("DIFACTO_CHUNK_BYTES")) chunk_bytes = std::max<size_t>(64, strtoull(e, nullptr, 10));  // text formats
     if (format == "libsvm") {
       parser_.reset(new LibsvmChunkParser(uri, part, nparts, chunk_bytes));
     } else if (format == "criteo") {
@@ -348,7 +356,15 @@ class Reader {
     } else {
       LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test and rec)";
     }
-    worker_ = std::thread([this] { Produce(); });
+    if (nthreads <= 0) {
+      // DIFACTO_PARSER_THREADS, else a quarter of the hardware threads (several readers may be alive: one per
+      // rank of a node, a training and a validation reader), at least 1, at most 8
+      const char* e = getenv("DIFACTO_PARSER_THREADS");
+      nthreads = e ? atoi(e) : static_cast<int>(std::thread::hardware_concurrency() / 4);
+      nthreads = std::max(1, std::min(nthreads, 8));
+    }
+    slots_.resize(2 * static_cast<size_t>(nthreads));
+    for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { Work(); });
   }
   ~Reader() {
     {
@@ -356,48 +372,72 @@ class Reader {
       stop_ = true;
     }
     cv_.notify_all();
-    if (worker_.joinable()) worker_.join();
+    for (auto& w : workers_)
+      if (w.joinable()) w.join();
   }
+  /*! \brief the next non-empty chunk of rows in file order; false when the part is exhausted */
   bool Next() {
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [this] { return ready_ || done_; });
-    if (!ready_) return false;
-    std::swap(cur_, next_);
-    ready_ = false;
-    lk.unlock();
-    cv_.notify_all();
-    blk_ = cur_.GetBlock();
-    return true;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      Slot& s = slots_[take_ % slots_.size()];
+      // chunk number take_ is parsed, or no chunk will ever get that number
+      cv_.wait(lk, [&] { return (s.state == kParsed && s.seq == take_) || (fetch_done_ && take_ >= fetched_); });
+      if (!(s.state == kParsed && s.seq == take_)) return false;
+      std::swap(cur_, s.rows);
+      s.state = kFree;
+      ++take_;
+      lk.unlock();
+      cv_.notify_all();
+      if (cur_.Size() == 0) continue;  // a chunk of comment / empty lines
+      blk_ = cur_.GetBlock();
+      return true;
+    }
   }
   const dmlc::RowBlock<feaid_t>& Value() const { return blk_; }
 
  private:
-  void Produce() {
-    RowChunk tmp;
+  enum State { kFree, kBusy, kParsed };
+  struct Slot {
+    State state = kFree;
+    size_t seq = 0;
+    std::string raw;
+    RowChunk rows;
+  };
+  void Work() {
     for (;;) {
-      const bool ok = parser_->ParseNext(&tmp);
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [this] { return !ready_ || stop_; });
-      if (stop_) return;
-      if (!ok) {
-        done_ = true;
-        lk.unlock();
-        cv_.notify_all();
-        return;
+      Slot* s = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        // chunk number fetched_ goes into slot fetched_ % n: wait until the consumer has emptied it
+        cv_.wait(lk, [&] { return stop_ || fetch_done_ || slots_[fetched_ % slots_.size()].state == kFree; });
+        if (stop_ || fetch_done_) return;
+        s = &slots_[fetched_ % slots_.size()];
+        // the fetch itself stays under the lock: chunks leave the file in order
+        if (!parser_->Fetch(&s->raw)) {
+          fetch_done_ = true;
+          lk.unlock();
+          cv_.notify_all();
+          return;
+        }
+        s->state = kBusy;
+        s->seq = fetched_++;
       }
-      next_.Clear();
-      std::swap(next_, tmp);
-      ready_ = true;
-      lk.unlock();
+      parser_->Parse(&s->raw, &s->rows);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        s->state = kParsed;
+      }
       cv_.notify_all();
     }
   }
   std::unique_ptr<ChunkParser> parser_;
-  std::thread worker_;
+  std::vector<std::thread> workers_;
   std::mutex mu_;
   std::condition_variable cv_;
-  bool ready_ = false, done_ = false, stop_ = false;
-  RowChunk cur_, next_;
+  std::vector<Slot> slots_;
+  size_t fetched_ = 0, take_ = 0;   // chunks handed to workers / to the consumer
+  bool fetch_done_ = false, stop_ = false;
+  RowChunk cur_;
   dmlc::RowBlock<feaid_t> blk_;
 };
 
@@ -412,7 +452,7 @@ class BatchReader {
       CHECK_GE(shuf_buf_, batch_size_);
       buf_reader_.reset(new BatchReader(uri, format, part_index, num_parts, shuf_buf_));
     } else {
-      reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 24));
+      reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 22));
     }
   }
 

@@ -199,3 +199,54 @@ def test_libsvm_reader_parts_and_sampling(ing, tmp_path):
     sh = read_all(ing, path, "libsvm", batch=50, shuffle=200)
     assert len(sh["label"]) == 1000 and sorted(sh["index"].tolist()) == sorted(got["index"].tolist())
     assert not np.array_equal(sh["index"], got["index"])
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_parser_pool_keeps_file_order(ing, tmp_path, monkeypatch, threads):
+    """the chunks of a part are parsed by a pool of threads (batch_reader.h: Reader) and must reach the
+    consumer in file order whatever the number of threads and however small the chunks: libsvm and criteo
+    text cut into ~100 chunks (with comment-only and empty chunks in between), a .rec file of 40 records"""
+    from oracle import ingest as oi
+    rng = np.random.default_rng(threads)
+    monkeypatch.setenv("DIFACTO_PARSER_THREADS", str(threads))
+    monkeypatch.setenv("DIFACTO_CHUNK_BYTES", "2048")
+    lines, ids_all = [], []
+    for i in range(3000):
+        if i % 500 == 250:
+            lines.extend(["# " + "x" * 100] * 60)   # more than one chunk of comments: an empty chunk of rows
+        n = int(rng.integers(1, 12))
+        ids = rng.integers(1, 10 ** 12, size=n)
+        ids_all.append(ids)
+        lines.append(" ".join([str(i % 2)] + ["%d:%g" % (a, 0.5) for a in ids]))
+    path = tmp_path / "d.libsvm"
+    path.write_text("\n".join(lines) + "\n")
+    got = read_all(ing, path, "libsvm", batch=97)
+    assert len(got["label"]) == 3000
+    assert np.array_equal(got["index"], np.concatenate(ids_all).astype(np.uint64))
+    assert np.array_equal(got["label"], (np.arange(3000) % 2).astype(np.float32))
+    parts = [read_all(ing, path, "libsvm", part=p, nparts=3, batch=50) for p in range(3)]
+    assert np.array_equal(np.concatenate([p["index"] for p in parts]), got["index"])
+    # criteo text
+    rows = 1500
+    ints = rng.integers(0, 1000, size=(rows, 13))
+    cats = rng.integers(0, 2 ** 32, size=(rows, 26), dtype=np.uint64)
+    text = "".join("%d\t%s\t%s\n" % (i % 2, "\t".join(map(str, ints[i])), "\t".join("%08x" % c for c in cats[i]))
+                   for i in range(rows)).encode()
+    cpath = tmp_path / "d.criteo"
+    cpath.write_bytes(text)
+    off, lab, idx = oi.parse_criteo(text)
+    gc = read_all(ing, cpath, "criteo", batch=128)
+    assert np.array_equal(gc["index"], idx) and np.array_equal(gc["offset"], off) and np.array_equal(gc["label"], lab)
+    # .rec: 40 records of 50 rows
+    recs, want = [], []
+    for r in range(40):
+        n = 50
+        o = np.arange(n + 1, dtype=np.uint64) * 7
+        ix = rng.integers(1, 2 ** 60, size=n * 7, dtype=np.uint64)
+        recs.append(oi.write_crb_record(o, np.full(n, r, np.float32), ix))
+        want.append(ix)
+    rpath = tmp_path / "d.rec"
+    rpath.write_bytes(oi.write_recordio(recs))
+    gr = read_all(ing, rpath, "rec", batch=64)
+    assert np.array_equal(gr["index"], np.concatenate(want))
+    assert np.array_equal(gr["label"], np.repeat(np.arange(40), 50).astype(np.float32))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 2, GPU call Y: the round's profile set on the final tree
+# The round's profile set on the final tree: parity suite, smoke, host tests, bench presets, kernel stats (pipelined, serial, sharded, C5 slice), HBM traffic counters, end-to-end CLI rate.  Output: gpurun_out/r02e (summaries only)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-O=$R/gpurun_out/r02y; mkdir -p $O; cd $R
+O=$R/gpurun_out/r02e; mkdir -p $O; cd $R
 ( time timeout 600 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -4 $O/pytest_gpu.log | cut -c1-300; grep -E "^E |^FAILED" $O/pytest_gpu.log | head -30
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -27,7 +27,7 @@ python $R/tools/rocpd_stats.py $(ls $O/prof_w1/*.db $O/prof_w1/*/*.db 2>/dev/nul
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o kt -- python $R/bench.py --preset c5-slice --steps 100 --warmup 20 > $O/bench_c5_slice.json 2> $O/bench_c5_slice.err
 python $R/tools/rocpd_stats.py $(ls $O/prof_c5/*.db $O/prof_c5/*/*.db 2>/dev/null | head -1) $O/kernel_stats_c5_slice_pipelined.txt > /dev/null 2>&1
 cd $R
-timeout 600 python tools/e2e_cli.py 200000 > $O/e2e.jsonl 2> $O/e2e.err; cat $O/e2e.jsonl; tail -2 $O/e2e.err
+timeout 600 python tools/e2e_cli.py 200000 8 > $O/e2e.jsonl 2> $O/e2e.err; cat $O/e2e.jsonl; tail -2 $O/e2e.err
 for f in bench_c3 bench_c3_serial bench_c3_refdefaults bench_c2 bench_sharded_w1 bench_c5_slice; do
   python -c "
 import json

@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+cd $R
+bash tools/gpu_variants.sh r02af "--max-reps 60" base depth1 mid256 mid1024 small16 small4
