@@ -27,7 +27,7 @@ python $R/tools/rocpd_stats.py $(ls $O/prof_w1/*.db $O/prof_w1/*/*.db 2>/dev/nul
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o kt -- python $R/bench.py --preset c5-slice --steps 100 --warmup 20 > $O/bench_c5_slice.json 2> $O/bench_c5_slice.err
 python $R/tools/rocpd_stats.py $(ls $O/prof_c5/*.db $O/prof_c5/*/*.db 2>/dev/null | head -1) $O/kernel_stats_c5_slice_pipelined.txt > /dev/null 2>&1
 cd $R
-timeout 600 python tools/e2e_cli.py 200000 8 > $O/e2e.jsonl 2> $O/e2e.err; cat $O/e2e.jsonl; tail -2 $O/e2e.err
+timeout 600 python tools/e2e_cli.py 200000 16 > $O/e2e.jsonl 2> $O/e2e.err; cat $O/e2e.jsonl; tail -2 $O/e2e.err
 for f in bench_c3 bench_c3_serial bench_c3_refdefaults bench_c2 bench_sharded_w1 bench_c5_slice; do
   python -c "
 import json
