@@ -10,7 +10,7 @@
 // the store calls turned into one exchange each way:
 //     counts   every rank learns how many keys each peer sends it (+ "I still have data")
 //     L        the keys THIS rank owns never leave it: k_lookup on its own table (row ids, Push(kFeaCount))
-//     K        the other keys (+ epoch-0 counts, same message group) --alltoallv--> owners
+//     K        the other keys (+ epoch-0 counts) --alltoallv--> owners
 //     R        owners: resolve keys -> rows once, Push(kFeaCount) per source, Pull (one gather)
 //     RW       rows --alltoallv--> workers          fixed stride dfh_row_stride(V_dim)
 //     F        FMLoss::Predict / Evaluate on a mixed source: own keys read the table in place, the others
@@ -151,7 +151,8 @@ struct XPart {
   const size_t* recv_off;
 };
 
-// alltoallv of device buffers, nparts parts in ONE message group (one RCCL launch)
+// alltoallv of device buffers; nparts parts would share ONE message group (callers pass one part: one send and
+// one receive per peer and group)
 int comm_exchange(dfh_comm* c, const XPart* parts, int nparts) {
   hipStream_t s = c->ctx->stream;
   const int W = c->world;
@@ -518,12 +519,13 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
                        (uint32_t*)nullptr, 0, b->d_uw + own_lo);
     DFH_HIP(hipGetLastError());
   }
-  // ---- K: the other keys (+ counts in epoch 0) to their owners, one message group
+  // ---- K: the other keys (+ counts in epoch 0) to their owners.  Two message groups, one send and one receive
+  // per peer each — the pattern every RCCL release serves (several sends to one peer inside a group are not)
   if (W > 1) {
     bytes(sizeof(uint64_t), sb, rb, so);
-    XPart parts[2];
-    parts[0] = XPart{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys, rb.data(), nullptr};
-    int nparts = 1;
+    XPart xk{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys, rb.data(), nullptr};
+    rc = comm_exchange(c, &xk, 1);
+    if (rc) return rc;
     if (push_cnt) {
       if (have && !b->has_cnt) {
         hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, ctx)), dim3(256), 0, st, b->d_col_ptr, b->d_U, b->d_feacnt);
@@ -531,11 +533,10 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
         b->has_cnt = true;
       }
       bytes(sizeof(float), sb2, rb2, so2);
-      parts[1] = XPart{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt, rb2.data(), nullptr};
-      nparts = 2;
+      XPart xc{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt, rb2.data(), nullptr};
+      rc = comm_exchange(c, &xc, 1);
+      if (rc) return rc;
     }
-    rc = comm_exchange(c, parts, nparts);
-    if (rc) return rc;
   }
   // ---- R: owners resolve once, count-push, pull (every source reads the same model version)
   if (nrecv) {
