@@ -24,6 +24,10 @@
  */
 #ifndef DIFACTO_HOST_BATCH_READER_H_
 #define DIFACTO_HOST_BATCH_READER_H_
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
@@ -46,25 +50,34 @@ typedef dmlc::data::RowBlockContainer<feaid_t> RowChunk;
 /*! \brief a parser yields the rows of its part of the file chunk by chunk, in two stages so that the
  * expensive one can run on several threads: Fetch (sequential, file order) and Parse (a pure function
  * of the fetched bytes) */
+/*! \brief the bytes of one chunk: a view into the memory-mapped file (text), or owned (a RecordIO record
+ * put together from its parts; the last lines of a text file, copied so that they end with a NUL) */
+struct RawChunk {
+  const char* data = nullptr;
+  size_t size = 0;
+  std::string own;
+  void Own() { data = own.data(); size = own.size(); }
+};
+
 class ChunkParser {
  public:
   virtual ~ChunkParser() {}
   /*! \brief the raw bytes of the next chunk; false at the end of the part.  Called under the reader's lock. */
-  virtual bool Fetch(std::string* raw) = 0;
+  virtual bool Fetch(RawChunk* raw) = 0;
   /*! \brief rows of a fetched chunk into *out (cleared first; may stay empty).  Thread-safe. */
-  virtual void Parse(std::string* raw, RowChunk* out) const = 0;
+  virtual void Parse(const RawChunk& raw, RowChunk* out) const = 0;
   /*! \brief single-threaded convenience: the next non-empty chunk of rows */
   bool ParseNext(RowChunk* out) {
     out->Clear();
     while (out->Size() == 0) {
       if (!Fetch(&raw_)) return false;
-      Parse(&raw_, out);
+      Parse(raw_, out);
     }
     return true;
   }
 
  private:
-  std::string raw_;
+  RawChunk raw_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -73,44 +86,58 @@ class ChunkParser {
 class TextChunks {
  public:
   TextChunks(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes) : chunk_bytes_(chunk_bytes) {
-    fp_ = fopen(uri.c_str(), "rb");
-    CHECK(fp_ != nullptr) << "cannot open " << uri;
-    fseek(fp_, 0, SEEK_END);
-    const long size = ftell(fp_);
-    long beg = size / nparts * part;
-    end_ = (part + 1 == nparts) ? size : size / nparts * (part + 1);
+    fd_ = open(uri.c_str(), O_RDONLY);
+    CHECK(fd_ >= 0) << "cannot open " << uri;
+    struct stat st;
+    CHECK(fstat(fd_, &st) == 0) << "cannot stat " << uri;
+    size_ = static_cast<size_t>(st.st_size);
+    if (size_ == 0) return;
+    // the file is mapped, not read: fetching a chunk is finding its last line end, and the parser
+    // threads pull the bytes out of the page cache themselves
+    void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    CHECK(m != MAP_FAILED) << "cannot map " << uri;
+    base_ = static_cast<const char*>(m);
+    madvise(m, size_, MADV_SEQUENTIAL);
+    size_t beg = size_ / nparts * part;
+    end_ = (part + 1 == nparts) ? size_ : size_ / nparts * (part + 1);
     if (beg > 0) {  // the part starts at the first line start at or after beg
-      fseek(fp_, beg - 1, SEEK_SET);
-      int c;
-      while ((c = fgetc(fp_)) != EOF && c != '\n') {}
-    } else {
-      fseek(fp_, 0, SEEK_SET);
+      const char* nl = static_cast<const char*>(memchr(base_ + beg - 1, '\n', size_ - (beg - 1)));
+      beg = nl ? static_cast<size_t>(nl - base_) + 1 : size_;
     }
+    pos_ = beg;
   }
-  ~TextChunks() { if (fp_) fclose(fp_); }
+  ~TextChunks() {
+    if (base_) munmap(const_cast<char*>(base_), size_);
+    if (fd_ >= 0) close(fd_);
+  }
   /*! \brief next run of whole lines (no trailing partial line); false when the part is exhausted */
-  bool Next(std::string* buf) {
-    buf->clear();
-    long pos = ftell(fp_);
-    if (pos >= end_) return false;
-    const size_t want = std::min<size_t>(chunk_bytes_, static_cast<size_t>(end_ - pos));
-    buf->resize(want);
-    const size_t got = fread(&(*buf)[0], 1, want, fp_);
-    buf->resize(got);
-    if (got == 0) return false;
-    if (buf->back() != '\n') {  // finish the line that crosses the chunk (or the part) border
-      int c;
-      while ((c = fgetc(fp_)) != EOF) {
-        buf->push_back(static_cast<char>(c));
-        if (c == '\n') break;
-      }
+  bool Next(RawChunk* out) {
+    out->own.clear();
+    out->data = nullptr;
+    out->size = 0;
+    if (pos_ >= end_) return false;
+    size_t stop = std::min(pos_ + chunk_bytes_, end_);
+    if (base_[stop - 1] != '\n') {  // finish the line that crosses the chunk (or the part) border
+      const char* nl = static_cast<const char*>(memchr(base_ + stop, '\n', size_ - stop));
+      stop = nl ? static_cast<size_t>(nl - base_) + 1 : size_;
     }
+    if (stop == size_) {
+      // the last bytes of the file: copied, so that the number parsers find a NUL behind them even when
+      // the file does not end with a newline (or ends exactly at a page border)
+      out->own.assign(base_ + pos_, stop - pos_);
+      out->Own();
+    } else {
+      out->data = base_ + pos_;
+      out->size = stop - pos_;
+    }
+    pos_ = stop;
     return true;
   }
 
  private:
-  FILE* fp_ = nullptr;
-  long end_ = 0;
+  int fd_ = -1;
+  const char* base_ = nullptr;
+  size_t size_ = 0, pos_ = 0, end_ = 0;
   size_t chunk_bytes_;
 };
 
@@ -119,11 +146,11 @@ class LibsvmChunkParser : public ChunkParser {
  public:
   LibsvmChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes)
       : src_(uri, part, nparts, chunk_bytes) {}
-  bool Fetch(std::string* raw) override { return src_.Next(raw); }
-  void Parse(std::string* raw, RowChunk* out) const override {
+  bool Fetch(RawChunk* raw) override { return src_.Next(raw); }
+  void Parse(const RawChunk& raw, RowChunk* out) const override {
     out->Clear();
-    const char* p = raw->c_str();
-    const char* const end = p + raw->size();
+    const char* p = raw.data;
+    const char* const end = p + raw.size;
     while (p < end) {
       const char* eol = static_cast<const char*>(memchr(p, '\n', end - p));
       if (!eol) eol = end;
@@ -137,7 +164,7 @@ class LibsvmChunkParser : public ChunkParser {
     while (p < eol && (*p == ' ' || *p == '\t')) ++p;
     if (p >= eol || *p == '#' || *p == '\r') return;
     char* e;
-    const float label = strtof(p, &e);  // the buffer is NUL-terminated past eol; numbers never span lines
+    const float label = strtof(p, &e);  // numbers never span lines; the file's last lines are NUL-terminated (TextChunks)
     CHECK(e != p) << "bad libsvm line: " << std::string(p, eol - p);
     p = e;
     out->label.push_back(label);
@@ -172,10 +199,10 @@ class CriteoChunkParser : public ChunkParser {
  public:
   CriteoChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes, bool is_train)
       : src_(uri, part, nparts, chunk_bytes), is_train_(is_train) {}
-  bool Fetch(std::string* raw) override { return src_.Next(raw); }
-  void Parse(std::string* raw, RowChunk* out) const override {
+  bool Fetch(RawChunk* raw) override { return src_.Next(raw); }
+  void Parse(const RawChunk& raw, RowChunk* out) const override {
     out->Clear();
-    Parse(raw->data(), raw->data() + raw->size(), is_train_, out);
+    Parse(raw.data, raw.data + raw.size, is_train_, out);
   }
   /*! \brief the reference's parse loop over one chunk of text */
   static void Parse(const char* p, const char* end, bool is_train, RowChunk* blk) {
@@ -328,10 +355,14 @@ inline void DecompressRowBlock(const char* data, size_t size, RowChunk* blk) {
 class CrbRecordParser : public ChunkParser {
  public:
   CrbRecordParser(const std::string& uri, unsigned part, unsigned nparts) : src_(uri, part, nparts) {}
-  bool Fetch(std::string* raw) override { return src_.NextRecord(raw); }
-  void Parse(std::string* raw, RowChunk* out) const override {
-    CHECK_NE(raw->size(), 0u);
-    DecompressRowBlock(raw->data(), raw->size(), out);
+  bool Fetch(RawChunk* raw) override {
+    if (!src_.NextRecord(&raw->own)) return false;
+    raw->Own();
+    return true;
+  }
+  void Parse(const RawChunk& raw, RowChunk* out) const override {
+    CHECK_NE(raw.size, 0u);
+    DecompressRowBlock(raw.data, raw.size, out);
   }
 
  private:
@@ -400,7 +431,7 @@ class Reader {
   struct Slot {
     State state = kFree;
     size_t seq = 0;
-    std::string raw;
+    RawChunk raw;
     RowChunk rows;
   };
   void Work() {
@@ -422,7 +453,7 @@ class Reader {
         s->state = kBusy;
         s->seq = fetched_++;
       }
-      parser_->Parse(&s->raw, &s->rows);
+      parser_->Parse(s->raw, &s->rows);
       {
         std::lock_guard<std::mutex> lk(mu_);
         s->state = kParsed;
