@@ -29,6 +29,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -373,7 +374,7 @@ class CrbRecordParser : public ChunkParser {
  * up to 2 x threads of them in flight, and handed to the consumer in file order */
 class Reader {
  public:
-  Reader(const std::string& uri, const std::string& format, unsigned part, unsigned nparts, size_t chunk_bytes = 1 << 22,
+  Reader(const std::string& uri, const std::string& format, unsigned part, unsigned nparts, size_t chunk_bytes = 1 << 24,
          int nthreads = 0) {
     if (const char* e = getenv("DIFACTO_CHUNK_BYTES")) chunk_bytes = std::max<size_t>(64, strtoull(e, nullptr, 10));  // text formats
     if (format == "libsvm") {
@@ -388,11 +389,11 @@ class Reader {
       LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test and rec)";
     }
     if (nthreads <= 0) {
-      // DIFACTO_PARSER_THREADS, else a quarter of the hardware threads (several readers may be alive: one per
-      // rank of a node, a training and a validation reader), at least 1, at most 8
+      // DIFACTO_PARSER_THREADS, else an eighth of the hardware threads (several readers may be alive: one per
+      // rank of a node, a training and a validation reader), at least 1, at most 16
       const char* e = getenv("DIFACTO_PARSER_THREADS");
-      nthreads = e ? atoi(e) : static_cast<int>(std::thread::hardware_concurrency() / 4);
-      nthreads = std::max(1, std::min(nthreads, 8));
+      nthreads = e ? atoi(e) : static_cast<int>(std::thread::hardware_concurrency() / 8);
+      nthreads = std::max(1, std::min(nthreads, 16));
     }
     slots_.resize(2 * static_cast<size_t>(nthreads));
     for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { Work(); });
@@ -405,6 +406,9 @@ class Reader {
     cv_.notify_all();
     for (auto& w : workers_)
       if (w.joinable()) w.join();
+    if (getenv("DIFACTO_PROFILE"))
+      LOG(INFO) << "reader: " << take_ << " chunks, " << workers_.size() << " parser threads: parsing " << t_parse_
+                << " s (sum over threads), consumer waited " << t_wait_ << " s";
   }
   /*! \brief the next non-empty chunk of rows in file order; false when the part is exhausted */
   bool Next() {
@@ -412,7 +416,9 @@ class Reader {
       std::unique_lock<std::mutex> lk(mu_);
       Slot& s = slots_[take_ % slots_.size()];
       // chunk number take_ is parsed, or no chunk will ever get that number
+      const auto w0 = std::chrono::steady_clock::now();
       cv_.wait(lk, [&] { return (s.state == kParsed && s.seq == take_) || (fetch_done_ && take_ >= fetched_); });
+      t_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       if (!(s.state == kParsed && s.seq == take_)) return false;
       std::swap(cur_, s.rows);
       s.state = kFree;
@@ -453,10 +459,13 @@ class Reader {
         s->state = kBusy;
         s->seq = fetched_++;
       }
+      const auto p0 = std::chrono::steady_clock::now();
       parser_->Parse(s->raw, &s->rows);
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count();
       {
         std::lock_guard<std::mutex> lk(mu_);
         s->state = kParsed;
+        t_parse_ += dt;
       }
       cv_.notify_all();
     }
@@ -468,6 +477,7 @@ class Reader {
   std::vector<Slot> slots_;
   size_t fetched_ = 0, take_ = 0;   // chunks handed to workers / to the consumer
   bool fetch_done_ = false, stop_ = false;
+  double t_parse_ = 0, t_wait_ = 0;   // DIFACTO_PROFILE
   RowChunk cur_;
   dmlc::RowBlock<feaid_t> blk_;
 };
@@ -483,13 +493,32 @@ class BatchReader {
       CHECK_GE(shuf_buf_, batch_size_);
       buf_reader_.reset(new BatchReader(uri, format, part_index, num_parts, shuf_buf_));
     } else {
-      reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 22));
+      reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 24));
     }
   }
 
   /*! \brief next minibatch; false when the part is exhausted (batch_reader.cc:32-77) */
   bool Next() {
     batch_.Clear();
+    // a whole minibatch inside the current chunk, rows taken as they come: hand out a view of the chunk's
+    // arrays instead of copying 39 ids per row (dmlc's RowBlock convention: offset holds absolute positions
+    // into index / value).  Valid until the next call, like the copy.
+    if (shuf_buf_ == 0 && neg_sampling_ == 1.0f && end_ - start_ >= batch_size_) {
+      out_blk_.size = batch_size_;
+      out_blk_.offset = in_blk_.offset + start_;
+      out_blk_.label = in_blk_.label + start_;
+      out_blk_.weight = nullptr;
+      out_blk_.index = in_blk_.index;
+      out_blk_.value = in_blk_.value;
+      if (out_blk_.value) {  // an all-ones value array is dropped (batch_reader.cc:71-73)
+        bool binary = true;
+        for (size_t j = out_blk_.offset[0]; j < out_blk_.offset[batch_size_]; ++j)
+          if (out_blk_.value[j] != 1) { binary = false; break; }
+        if (binary) out_blk_.value = nullptr;
+      }
+      start_ += batch_size_;
+      return true;
+    }
     while (batch_.offset.size() < batch_size_ + 1) {
       if (start_ == end_) {
         if (shuf_buf_ == 0) {
@@ -511,12 +540,16 @@ class BatchReader {
       if (shuf_buf_ == 0 && neg_sampling_ == 1.0f) {
         Push(start_, len);
       } else {
+        // the rows picked by the permutation / the sampling first (same draws, same order as the
+        // reference's row-by-row loop, batch_reader.cc:55-63), then ONE append of all of them
+        sel_.clear();
         for (size_t i = start_; i < start_ + len; ++i) {
           const size_t j = shuf_buf_ ? rdp_[i] : i;  // (the reference reads an unset rdp_ here when only sampling)
           const float p = static_cast<float>(rand_r(&seed_)) / static_cast<float>(RAND_MAX);
           if (neg_sampling_ < 1.0f && in_blk_.label[j] <= 0 && p > 1 - neg_sampling_) continue;
-          Push(j, 1);
+          sel_.push_back(j);
         }
+        AppendRows();
       }
       start_ += len;
     }
@@ -542,6 +575,43 @@ class BatchReader {
     slice.value = in_blk_.value ? in_blk_.value + in_blk_.offset[pos] : nullptr;
     PushSlice(slice);
   }
+  // rows sel_[] of in_blk_, in that order, onto batch_: what Push(j, 1) per row gives, without the per-row
+  // bookkeeping (10 000 single-row slices per minibatch were the slowest thing on the host)
+  void AppendRows() {
+    if (sel_.empty()) return;
+    size_t add = 0;
+    for (size_t j : sel_) add += in_blk_.offset[j + 1] - in_blk_.offset[j];
+    const size_t nnz_before = batch_.index.size();
+    if (in_blk_.value && batch_.value.size() < nnz_before) batch_.value.resize(nnz_before, 1.0f);
+    batch_.index.resize(nnz_before + add);
+    if (in_blk_.value) batch_.value.resize(nnz_before + add);
+    else if (!batch_.value.empty()) batch_.value.resize(nnz_before + add, 1.0f);
+    const size_t r0 = batch_.label.size(), nsel = sel_.size();
+    batch_.label.resize(r0 + nsel);
+    batch_.offset.resize(batch_.offset.size() + nsel);
+    size_t at = nnz_before;
+    for (size_t q = 0; q < nsel; ++q) {  // where every row goes
+      at += in_blk_.offset[sel_[q] + 1] - in_blk_.offset[sel_[q]];
+      batch_.offset[r0 + 1 + q] = at;
+      batch_.label[r0 + q] = in_blk_.label[sel_[q]];
+    }
+    // the copy itself is a gather of ~300 B rows from a buffer far larger than the caches: a few threads
+    // hide the misses (the result does not depend on their number)
+    feaid_t mx = batch_.max_index;
+    const int nt = nsel >= 2048 ? 4 : 1;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(max : mx)
+    for (size_t q = 0; q < nsel; ++q) {
+      const size_t b = in_blk_.offset[sel_[q]], n = in_blk_.offset[sel_[q] + 1] - b;
+      const size_t dst = batch_.offset[r0 + q];
+      const feaid_t* src = in_blk_.index + b;   // offsets are absolute positions into index / value
+      for (size_t x = 0; x < n; ++x) {
+        batch_.index[dst + x] = src[x];
+        mx = std::max(mx, src[x]);
+      }
+      if (in_blk_.value) memcpy(&batch_.value[dst], in_blk_.value + b, n * sizeof(real_t));
+    }
+    batch_.max_index = mx;
+  }
   // a file may mix blocks with and without a value array (binary blocks drop it,
   // compressed_row_block.h:36-44): inside one minibatch a missing array means ones
   void PushSlice(const dmlc::RowBlock<feaid_t>& slice) {
@@ -559,6 +629,7 @@ class BatchReader {
   dmlc::RowBlock<feaid_t> in_blk_, out_blk_;
   RowChunk batch_;
   std::vector<unsigned> rdp_;
+  std::vector<size_t> sel_;
   unsigned int seed_ = 0;
 };
 

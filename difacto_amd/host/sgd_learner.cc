@@ -197,23 +197,38 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   auto needs_growth = [&](const dmlc::RowBlock<feaid_t>& blk) {
     return !batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
   };
+  // DIFACTO_PROFILE=1: where the host thread of this loop spends its time (reader wait + batch assembly,
+  // staging + Localizer / lookup queueing, step queueing), printed at the end of the job
+  const bool prof = getenv("DIFACTO_PROFILE") != nullptr;
+  double t_read = 0, t_prep = 0, t_step = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = prof ? now() : 0;
   bool have = reader.Next();
+  if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
   int i = 0;
   if (have) prepare(0);
+  if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
   while (have) {
     const int cur = i & 1;
     const bool have_next = reader.Next();
+    if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
     bool stepped = false;
     if (have_next && needs_growth(reader.Value())) {
       // growing re-creates BOTH batch objects: the prepared, not yet trained batch goes first
       DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
       stepped = true;
     }
+    if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
     if (have_next) prepare(cur ^ 1);
+    if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
     if (!stepped) DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+    if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
     have = have_next;
     ++i;
   }
+  if (prof)
+    LOG(INFO) << "host loop over " << i << " minibatches: reader " << t_read << " s, stage + localize + lookup " << t_prep
+              << " s, step " << t_step << " s";
   for (auto& b : batch_) {
     if (!b) continue;
     dfh_progress p;
