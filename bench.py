@@ -65,6 +65,9 @@ def parse_args():
                          "keeps 2 in flight)")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
+    ap.add_argument("--later-epoch", action="store_true",
+                    help="time the step of epochs after the first (no feature-count push, sgd_learner.cc:214-217) instead of "
+                         "the default epoch-0 step, which pushes counts every minibatch (the worst case)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: validated launch tuning passed to dfh_ctx_set_option (fwd_depth, bwd_small_blocks, ...)")
     ap.add_argument("--no-relocalize", action="store_true",
@@ -308,7 +311,7 @@ def main():
     def step(i):
         if not args.no_relocalize or i + ahead < len(bts):
             prep(i + ahead)
-        bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=True)
+        bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=not args.later_epoch)
 
     for i in range(ahead):
         prep(i)
@@ -425,7 +428,8 @@ def main():
                    "rows_per_step": B, "nnz_per_row": s_mean, "unique_keys_per_batch": U_mean,
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
                    "model_keys": int(nkeys), "table_bytes": table.bytes(), "prefilled": not args.no_prefill, "hyper": hyper,
-                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth},
+                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
+                   "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,
         "value_note": "median of `repetitions` timed regions of `steps` steps each"
