@@ -498,6 +498,11 @@ class BatchReader {
   }
 
   /*! \brief next minibatch; false when the part is exhausted (batch_reader.cc:32-77) */
+  ~BatchReader() {
+    if (getenv("DIFACTO_PROFILE") && (t_fill_ + t_shuf_ + t_sel_ + t_app_) > 0)
+      LOG(INFO) << "batch reader (" << batch_size_ << " rows, shuffle buffer " << shuf_buf_ << "): next chunk / buffer " << t_fill_
+                << " s, permutation " << t_shuf_ << " s, row selection " << t_sel_ << " s, row gather " << t_app_ << " s";
+  }
   bool Next() {
     batch_.Clear();
     // a whole minibatch inside the current chunk, rows taken as they come: hand out a view of the chunk's
@@ -521,17 +526,22 @@ class BatchReader {
     }
     while (batch_.offset.size() < batch_size_ + 1) {
       if (start_ == end_) {
+        const double f0 = Now();
         if (shuf_buf_ == 0) {
           if (!reader_->Next()) break;
           in_blk_ = reader_->Value();
+          t_fill_ += Now() - f0;
         } else {
           if (!buf_reader_->Next()) break;
           in_blk_ = buf_reader_->Value();
+          const double f1 = Now();
+          t_fill_ += f1 - f0;
           if (rdp_.size() != in_blk_.size) {
             rdp_.resize(in_blk_.size);
             for (size_t i = 0; i < in_blk_.size; ++i) rdp_[i] = static_cast<unsigned>(i);
           }
           std::random_shuffle(rdp_.begin(), rdp_.end());  // as the reference: libstdc++'s rand()-driven shuffle
+          t_shuf_ += Now() - f1;
         }
         start_ = 0;
         end_ = in_blk_.size;
@@ -542,6 +552,7 @@ class BatchReader {
       } else {
         // the rows picked by the permutation / the sampling first (same draws, same order as the
         // reference's row-by-row loop, batch_reader.cc:55-63), then ONE append of all of them
+        const double s0 = Now();
         sel_.clear();
         for (size_t i = start_; i < start_ + len; ++i) {
           const size_t j = shuf_buf_ ? rdp_[i] : i;  // (the reference reads an unset rdp_ here when only sampling)
@@ -549,7 +560,10 @@ class BatchReader {
           if (neg_sampling_ < 1.0f && in_blk_.label[j] <= 0 && p > 1 - neg_sampling_) continue;
           sel_.push_back(j);
         }
+        const double s1 = Now();
         AppendRows();
+        t_sel_ += s1 - s0;
+        t_app_ += Now() - s1;
       }
       start_ += len;
     }
@@ -595,12 +609,17 @@ class BatchReader {
       batch_.offset[r0 + 1 + q] = at;
       batch_.label[r0 + q] = in_blk_.label[sel_[q]];
     }
-    // the copy itself is a gather of ~300 B rows from a buffer far larger than the caches: a few threads
-    // hide the misses (the result does not depend on their number)
+    // the copy itself is a gather of ~300 B rows from a buffer far larger than the caches: the rows a few
+    // steps ahead are prefetched, so that their misses overlap instead of following one another
     feaid_t mx = batch_.max_index;
-    const int nt = nsel >= 2048 ? 4 : 1;
-#pragma omp parallel for num_threads(nt) schedule(static) reduction(max : mx)
+    constexpr size_t kAhead = 12;
     for (size_t q = 0; q < nsel; ++q) {
+      if (q + kAhead < nsel) {
+        const size_t pb = in_blk_.offset[sel_[q + kAhead]], pn = in_blk_.offset[sel_[q + kAhead] + 1] - pb;
+        const char* pp = reinterpret_cast<const char*>(in_blk_.index + pb);
+        for (size_t x = 0; x < pn * sizeof(feaid_t); x += 64) __builtin_prefetch(pp + x, 0, 0);
+        if (in_blk_.value) __builtin_prefetch(in_blk_.value + pb, 0, 0);
+      }
       const size_t b = in_blk_.offset[sel_[q]], n = in_blk_.offset[sel_[q] + 1] - b;
       const size_t dst = batch_.offset[r0 + q];
       const feaid_t* src = in_blk_.index + b;   // offsets are absolute positions into index / value
@@ -630,6 +649,8 @@ class BatchReader {
   RowChunk batch_;
   std::vector<unsigned> rdp_;
   std::vector<size_t> sel_;
+  static double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  double t_fill_ = 0, t_shuf_ = 0, t_sel_ = 0, t_app_ = 0;   // DIFACTO_PROFILE
   unsigned int seed_ = 0;
 };
 

@@ -65,12 +65,10 @@ struct RowBlockContainer {
     if (blk.label != nullptr) label.insert(label.end(), blk.label, blk.label + blk.size);
     if (blk.weight != nullptr) weight.insert(weight.end(), blk.weight, blk.weight + blk.size);
     size_t base = index.size();
-    index.resize(base + nnz);
-    for (size_t i = 0; i < nnz; ++i) {
-      IndexType id = static_cast<IndexType>(blk.index[i]);
-      index[base + i] = id;
-      max_index = std::max(max_index, id);
-    }
+    index.insert(index.end(), blk.index, blk.index + nnz);  // one pass (converts when I != IndexType), no zero fill
+    IndexType mx = max_index;
+    for (size_t i = 0; i < nnz; ++i) mx = std::max(mx, index[base + i]);
+    max_index = mx;
     if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
     size_t shift = offset.back();
     for (size_t i = 0; i < blk.size; ++i) {

@@ -42,7 +42,7 @@ def run(path, fmt):
     dt = time.time() - t0
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
     for l in r.stderr.splitlines():
-        if "host loop over" in l or "reader: " in l:   # DIFACTO_PROFILE=1
+        if "host loop over" in l or "reader: " in l or "batch reader" in l:   # DIFACTO_PROFILE=1
             sys.stderr.write(fmt + ": " + l.split("INFO")[-1].strip() + "\n")
     return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])
 
