@@ -553,21 +553,36 @@ def bench_main_native(args, rank, world, local_rank, hyper):
         b.progress(reset=True)
     mask = 0 if (args.no_timing or rank != 0) else (1 << capi.K_FORWARD)
     ctx.get_timing(reset=True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if mask and i % 4 == 0:
-            ctx.set_timing_mask(mask)
-            step(done)
-            ctx.set_timing_mask(0)
-        else:
-            step(done)
-        done += 1
-    ctx.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
+
+    def region():
+        """K steps between two barriers; the time is the maximum over the ranks (the same number on every rank)"""
+        nonlocal done
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if mask and i % 4 == 0:
+                ctx.set_timing_mask(mask)
+                step(done)
+                ctx.set_timing_mask(0)
+            else:
+                step(done)
+            done += 1
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        return float(dt_t.item())
+
+    # the K-step region is repeated until min_time seconds are timed (every rank derives the same count from the
+    # all-reduced time of the first region); the reported time is the median region
+    reps = [region()]
+    more = int(min(max(np.ceil(args.min_time / max(reps[0], 1e-9)) - 1, 0), args.max_reps - 1))
+    for _ in range(more):
+        reps.append(region())
+    dt = float(sorted(reps)[len(reps) // 2])
     fwd_t = ctx.get_timing(reset=True).get("forward", (0.0, 0)) if mask else (0.0, 0)
     table.check()
     progs = [b.progress(reset=True) for b in bts]
@@ -587,7 +602,9 @@ def bench_main_native(args, rank, world, local_rank, hyper):
             "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
             "value": ex_per_s, "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "repetitions": len(reps),
+            "ms_per_step_min": min(reps) / args.steps * 1e3, "ms_per_step_max": max(reps) / args.steps * 1e3,
+            "value_note": "median of `repetitions` timed regions of `steps` steps each, every region's time = max over ranks",
             "config": {"workload": "C4: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, model row-sharded by key "
                                    "range over %d MI355X, RCCL ncclSend/ncclRecv all-to-all-v inside libdifacto_hip.so"
                                    % (args.ids, k, world),
