@@ -1699,7 +1699,7 @@ __global__ void k_loc_counts(const uint32_t* __restrict__ col_ptr, const uint32_
 __global__ void k_auc_keys(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
                            uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t b = __float_as_uint(pred[i]);
+    const uint32_t b = __float_as_uint(pred[i] + 0.0f);  // -0 and +0 compare equal in the reference: one image
     keys[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     pos[i] = label[i] > 0 ? 1u : 0u;
   }
@@ -1766,14 +1766,14 @@ __global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pre
   const uint32_t j0 = blockIdx.y * AUC_TILE;
   const uint32_t lim = min((uint32_t)AUC_TILE, n - j0);
   for (uint32_t t = threadIdx.x; t < lim; t += blockDim.x) {
-    const uint32_t bits = __float_as_uint(pred[j0 + t]);
+    const uint32_t bits = __float_as_uint(pred[j0 + t] + 0.0f);  // -0 and +0 compare equal in the reference: one image
     col[t] = make_uint2((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u), label[j0 + t] > 0 ? 1u : 0u);
   }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ki = 0;
   bool neg = false, pos = false;
   if (i < n) {
-    const uint32_t bits = __float_as_uint(pred[i]);
+    const uint32_t bits = __float_as_uint(pred[i] + 0.0f);
     ki = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
     pos = label[i] > 0;
     neg = !pos;

@@ -912,6 +912,23 @@ def test_auc_vs_oracle(capi, ctx, oracle, n):
     assert ctx.auc_times_n(ones, pred) == 1.0 and ctx.auc_times_n(0 * ones, pred) == 1.0  # bin_class_metric.h:51
 
 
+@pytest.mark.parametrize("n", [100, 5000, 40000])
+def test_auc_with_tied_predictions(capi, ctx, n):
+    """equal predictions (the clamp at +-20 makes them common) are ranked by example index — the order a stable
+    sort by prediction gives; the reference's std::sort leaves it unspecified (bin_class_metric.h:43).  Both
+    device forms (pair counting, radix sort) must give exactly that."""
+    rng = np.random.default_rng(n)
+    pred = np.clip(np.round(rng.normal(size=n) * 15), -20, 20).astype(np.float32)   # ~40 distinct values
+    lab = np.where(rng.random(n) < 0.4, 1.0, -1.0).astype(np.float32)
+    order = np.argsort(pred, kind="stable")
+    sl = lab[order] > 0
+    area = int(np.cumsum(sl)[~sl].sum())
+    tp = int(sl.sum())
+    a = area / (tp * (n - tp))
+    exact = (1 - a if a < 0.5 else a) * n
+    assert ctx.auc_times_n(lab, pred) == pytest.approx(exact, rel=1e-6)
+
+
 def test_fused_step_auc(capi, ctx, oracle):
     rng = np.random.default_rng(4)
     b = random_batch(rng, 300, 2000, 20, empty_rows=False)
