@@ -75,11 +75,12 @@ int dfh_ctx_sync(dfh_ctx* ctx);
 void* dfh_ctx_stream(dfh_ctx* ctx);
 int dfh_ctx_device(dfh_ctx* ctx);
 
-/* Pipelining: with enable != 0 batch preparation (dfh_batch_load_*, dfh_localize,
- * dfh_batch_lookup) runs on a second HIP stream, so batch t+1 is prepared while
- * batch t trains — the overlap the reference gets from its reader thread
- * (src/sgd/sgd_learner.cc:196-224).  Ordering per batch object is kept with
- * events inside the library; use two dfh_batch objects alternately. */
+/* Pipelining: with enable = n in 1..4 batch preparation (dfh_batch_load_*, dfh_localize,
+ * dfh_batch_lookup) runs on n preparation streams of the lowest priority, taken round-robin, so
+ * batches t+1 .. t+n are prepared while batch t trains — the overlap the reference gets from its
+ * reader thread (src/sgd/sgd_learner.cc:196-224); steps are still applied strictly in batch order.
+ * Ordering per batch object is kept with events inside the library; use n + 1 (better n + 2)
+ * dfh_batch objects in rotation.  0 = everything on the context's stream. */
 int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
 /* launch tuning, validated (unknown names / out-of-range values: DFH_ERR_ARG):
  *   "fwd_depth"         4 | 5 | 8 | 10  independent V-row loads per forward lane (default 5)
