@@ -10,6 +10,7 @@
 
 #include "dfh_kernels.hip"
 #include "dfh_localize.hip"
+#include "dfh_update.hip"
 
 using namespace dfh;
 
@@ -37,6 +38,13 @@ struct dfh_ctx {
   int fwd_depth = 5;           // independent V-row loads a forward lane issues before consuming any
   int fwd_blocks = 0;          // cap on the forward grid (0: one wave per example)
   int bwd_small_blocks = 2048; // cap on the short-segment blocks of the backward/update launch
+  // k_update_fused (fused update on the resident table): 1 = on (default), 0 = k_backward_all's fused form;
+  // caps on the blocks of its four roles
+  int upd_kernel = 1;
+  int upd_hot_blocks = 256, upd_mid_blocks = 512, upd_few_blocks = 512, upd_single_blocks = 2048;
+  // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
+  // consumer of these events is a stream of this device
+  int event_flags = 1;
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
@@ -133,8 +141,8 @@ struct dfh_batch {
   uint32_t* d_U = nullptr;
   // step workspace
   // long-segment key lists for the backward pass (SegLists): list buckets = sort buckets
-  uint2 *d_mid = nullptr, *d_hot = nullptr;         // [list buckets] {cnt, off}
-  uint32_t *d_mid_ent = nullptr, *d_hot_ent = nullptr;
+  uint2 *d_mid = nullptr, *d_hot = nullptr, *d_few = nullptr;  // [list buckets] {cnt, off}
+  uint32_t *d_mid_ent = nullptr, *d_hot_ent = nullptr, *d_few_ent = nullptr;
   uint32_t seg_nb = 0;                              // list buckets of the current localized view
   uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
@@ -360,6 +368,8 @@ BatchView batch_view(const dfh_batch* b) {
   v.seg.mid_ent = b->d_mid_ent;
   v.seg.hot = b->d_hot;
   v.seg.hot_ent = b->d_hot_ent;
+  v.seg.few = b->d_few;
+  v.seg.few_ent = b->d_few_ent;
   return v;
 }
 
@@ -460,9 +470,74 @@ int launch_auc(dfh_batch* b) {
   return DFH_OK;
 }
 
+// the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
+// step's k_lookup left per unique key
+int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg) {
+  dfh_ctx* c = b->ctx;
+  hipStream_t s = c->stream;
+  const int L = lanes_for(kp);
+  UpdArgs a;
+  a.offset = b->d_offset;
+  a.index = b->d_index;
+  a.value = b->has_value ? b->d_value : nullptr;
+  a.uw = uw;
+  a.col_ptr = b->d_col_ptr;
+  a.feaids = b->d_feaids;
+  a.s_row = b->d_s_row;
+  a.s_val = b->has_value ? b->d_s_val : nullptr;
+  a.slope = b->d_slope;
+  a.xv = b->d_xv;
+  a.hdr = tv.hdr;
+  a.va = tv.va;
+  a.need_init = need;
+  a.prog = b->d_prog;
+  a.seg.mid = b->d_mid;
+  a.seg.mid_ent = b->d_mid_ent;
+  a.seg.hot = b->d_hot;
+  a.seg.hot_ent = b->d_hot_ent;
+  a.seg.few = b->d_few;
+  a.seg.few_ent = b->d_few_ent;
+  a.nrows = (uint32_t)b->nrows;
+  a.nlist = b->seg_nb;
+  a.k = k;
+  a.kp = kp;
+  a.rg = rg;
+  a.p = tv.p;
+  // blocks per role (U and the list sizes live on the device; nnz bounds them): surplus blocks find their
+  // list exhausted and leave at once
+  const size_t nnz = b->nnz, G = 64 / (size_t)L;
+  a.nb_hot = (uint32_t)std::max<size_t>(1, std::min<size_t>(nnz / (BWD_MID + 1) + 1, (size_t)c->upd_hot_blocks));
+  a.nb_mid = (uint32_t)std::max<size_t>(1, std::min<size_t>((nnz / (BWD_SMALL + 1)) / UPD_NW + 1, (size_t)c->upd_mid_blocks));
+  a.nb_few = (uint32_t)std::max<size_t>(1, std::min<size_t>((nnz / 2) / (UPD_NW * G) + 1, (size_t)c->upd_few_blocks));
+  const size_t nb_single = std::max<size_t>(1, std::min<size_t>((b->nrows + UPD_NW - 1) / UPD_NW, (size_t)c->upd_single_blocks));
+  hipEvent_t ea = nullptr, eb = nullptr;  // timing rides on the dispatch, like the forward's
+  if ((c->timing >> DFH_K_BACKWARD) & 1u) {
+    ea = TimeScope::get(c);
+    eb = TimeScope::get(c);
+  }
+  const dim3 grid((unsigned)(a.nb_hot + a.nb_mid + a.nb_few + nb_single)), block(UPD_THREADS);
+  int rc = dispatch_L(kp, [&](auto Lc) {
+    constexpr int LL = decltype(Lc)::value;
+#define DFH_UPD(EXACT, HV)                                                                              \
+  if (ea && eb) hipExtLaunchKernelGGL((k_update_fused<LL, EXACT, HV>), grid, block, 0, s, ea, eb, 0, a); \
+  else hipLaunchKernelGGL((k_update_fused<LL, EXACT, HV>), grid, block, 0, s, a)
+    if (kp == 4 * LL) {
+      if (b->has_value) { DFH_UPD(true, true); } else { DFH_UPD(true, false); }
+    } else {
+      if (b->has_value) { DFH_UPD(false, true); } else { DFH_UPD(false, false); }
+    }
+#undef DFH_UPD
+  });
+  if (ea && eb) c->spans.push_back({DFH_K_BACKWARD, ea, eb});
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
 template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
-                    uint32_t* need, KeyRange rg = kAllKeys) {
+                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr) {
+  if (FUSED && src.urow && uw && b->ctx->upd_kernel) return launch_update_fused(b, tv, k, kp, need, uw, rg);
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
@@ -627,6 +702,16 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "bwd_small_blocks") {
     DFH_ARG(value >= 1 && value <= 65536, "bwd_small_blocks must be in [1, 65536]");
     c->bwd_small_blocks = value;
+  } else if (n == "upd_kernel") {
+    DFH_ARG(value == 0 || value == 1, "upd_kernel must be 0 (k_backward_all) or 1 (k_update_fused)");
+    c->upd_kernel = value;
+  } else if (n == "upd_hot_blocks" || n == "upd_mid_blocks" || n == "upd_few_blocks" || n == "upd_single_blocks") {
+    DFH_ARG(value >= 1 && value <= 65536, "upd_*_blocks must be in [1, 65536]");
+    (n == "upd_hot_blocks" ? c->upd_hot_blocks : n == "upd_mid_blocks" ? c->upd_mid_blocks : n == "upd_few_blocks" ? c->upd_few_blocks
+                                                                                                        : c->upd_single_blocks) = value;
+  } else if (n == "event_flags") {
+    DFH_ARG(value == 0 || value == 1, "event_flags must be 0 (default events) or 1 (no system-scope fence); set before batches are created");
+    c->event_flags = value;
   } else if (n == "prep_priority") {
     DFH_ARG(value >= -1 && value <= 1, "prep_priority must be -1 (lowest), 0 (default) or 1 (highest)");
     DFH_ARG(c->preps.empty(), "prep_priority must be set before dfh_ctx_set_pipeline creates the streams");
@@ -712,7 +797,8 @@ int dfh_memcpy_d2h(dfh_ctx* c, void* dst, const void* src, size_t bytes) {
 int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out) {
   DFH_ARG(c && p && out, "dfh_table_create: NULL argument");
   DFH_ARG(p->V_dim >= 0 && p->V_dim <= 10000, "V_dim out of range [0, 10000] (FMLossParam, fm_loss.h:25)");
-  DFH_ARG(capacity_rows >= 1 && capacity_rows < 0xFFFFFFF0ULL, "capacity_rows must be in [1, 2^32-16)");
+  // the two top bits of a row word carry flags (kRemoteRow, kSingleRow); 2^30 rows of V_dim 64 would be 560 GB
+  DFH_ARG(capacity_rows >= 1 && capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^30)");
   DFH_ARG(p->lr > 0, "lr must be > 0");
   DFH_ARG(p->init_mode == DFH_INIT_HASH || p->init_mode == DFH_INIT_REFRAND, "bad init_mode");
   DFH_HIP(hipSetDevice(c->device));
@@ -1567,8 +1653,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   // bucket q of the sample sort may list n_q / 9 + 2 mid and n_q / 257 + 2 hot keys (k_loc_emit)
   DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
   DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
+  DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
   DFH_ALLOC(b->d_mid, LOC_MAX_BUCKETS, uint2);
   DFH_ALLOC(b->d_hot, LOC_MAX_BUCKETS, uint2);
+  DFH_ALLOC(b->d_few, LOC_MAX_BUCKETS, uint2);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1581,8 +1669,10 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_acc, 8, unsigned long long);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
-  DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
-  DFH_HIP(hipEventCreateWithFlags(&b->ev_free, hipEventDisableTiming));
+  // ev_ready / ev_free order streams of ONE device: no system-scope fence (cache write-back + invalidate) at the record
+  const unsigned evf = hipEventDisableTiming | (c->event_flags ? hipEventDisableSystemFence : 0u);
+  DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, evf));
+  DFH_HIP(hipEventCreateWithFlags(&b->ev_free, evf));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
@@ -1610,7 +1700,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
                   b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
                   b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw,
-                  b->d_auc_acc};
+                  b->d_auc_acc, b->d_few, b->d_few_ent};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -1778,6 +1868,8 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     sl.mid_ent = b->d_mid_ent;
     sl.hot = b->d_hot;
     sl.hot_ent = b->d_hot_ent;
+    sl.few = b->d_few;
+    sl.few_ent = b->d_few_ent;
     if (cold && P > 1) {
       const uint32_t S = (uint32_t)P * LOC_OVERSAMPLE;
       const uint32_t nt = (S + 255) / 256;
@@ -1812,9 +1904,9 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
                        b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                        b->d_s_row, b->d_s_val, b->d_U);
     // keys with long segments, for the backward pass: one list bucket
-    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot);
+    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few);
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
-                       b->d_col_ptr, b->d_U, b->d_mid, b->d_hot, b->d_mid_ent, b->d_hot_ent);
+                       b->d_col_ptr, b->d_U, b->d_mid, b->d_hot, b->d_few, b->d_mid_ent, b->d_hot_ent, b->d_few_ent);
     b->seg_nb = 1;
   }
   delete tsp;
@@ -1921,10 +2013,10 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot);
+  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few);
   if (U) {
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::min<size_t>((U + 1023) / 1024, 256)), dim3(1024), 0, s, b->d_col_ptr,
-                       b->d_U, b->d_mid, b->d_hot, b->d_mid_ent, b->d_hot_ent);
+                       b->d_U, b->d_mid, b->d_hot, b->d_few, b->d_mid_ent, b->d_hot_ent, b->d_few_ent);
   }
   b->seg_nb = 1;
   DFH_HIP(hipGetLastError());
@@ -2083,7 +2175,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   }
   if (is_train) {
     if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
-    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need);
+    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw);
     if (rc) return rc;
     if (refrand) {
       rc = refrand_flush(t, b->d_feaids, b->d_U, Nb, b->d_urow, b->d_need, b->d_rank, b->d_total);

@@ -69,7 +69,15 @@ struct SegLists {
   const uint32_t* mid_ent;
   const uint2* hot;         // [nb] {cnt, off}
   const uint32_t* hot_ent;
+  const uint2* few;         // [nb] {cnt, off}: keys with 2 .. BWD_SMALL occurrences (k_update_fused only)
+  const uint32_t* few_ent;
 };
+
+// flag bits of the row word k_lookup / k_uw_remote leave per unique key in uw[]: a table holds fewer
+// than 2^30 rows (dfh_table_create), so the two top bits are free
+constexpr uint32_t kRemoteRow = 0x80000000u;  // the row is in the pulled-rows buffer, not in the table (sharded store)
+constexpr uint32_t kSingleRow = 0x40000000u;  // the key occurs exactly once in this minibatch
+constexpr uint32_t kRowMask = 0x3FFFFFFFu;
 
 // "row source" seen by the forward / backward kernels: either the table
 // itself (rows addressed through urow[u]) or a packed [U x stride] buffer of

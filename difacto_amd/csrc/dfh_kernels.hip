@@ -205,7 +205,7 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
 #define DFH_BWD_SMALL 8
 #endif
 #ifndef DFH_BWD_MID
-#define DFH_BWD_MID 256
+#define DFH_BWD_MID 64
 #endif
 #ifndef DFH_BWD_DEPTH
 #define DFH_BWD_DEPTH 2
@@ -268,11 +268,14 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
     }
     // {row, w} per unique key, batch-local and L2-resident: the forward then touches nothing of a
     // row but its V lines (the weight is read here once per KEY instead of once per nonzero)
-    if (uw) uw[u] = make_uint2(r, __float_as_uint(w));
+    // bit 30 of the row word: the key occurs once in this minibatch (k_update_fused updates such keys example by
+    // example, without the key-ordered view)
+    if (uw) {
+      const bool single = col_ptr != nullptr && col_ptr[u + 1] - col_ptr[u] == 1u;
+      uw[u] = make_uint2(r | (single ? kSingleRow : 0u), __float_as_uint(w));
+    }
   }
 }
-
-constexpr uint32_t kRemoteRow = 0x80000000u;  // bit 31 of a uw[] row word: the row is in the pulled-rows buffer, not in the table
 
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
 // the pulled-rows buffer belongs to key u; the slots of this rank's own keys [lo, hi) are unused)
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
           // {row, w} of the key from the batch-local table k_lookup left in L2: no header access;
           // a row without V holds zeros, so its flag is not needed either
           const uint2 e = b.uw[b.index[j]];
-          r = e.x;
+          r = e.x & ~kSingleRow;
           hv = 1u;
           wsum += __uint_as_float(e.y) * x;
         } else {
@@ -1067,37 +1070,41 @@ __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(Bat
 }
 
 // k_seg_lists: one pass over the unique keys of a localized minibatch, compacting the keys with
-// long segments into ONE list bucket (one atomic per block and list; the two counters zeroed
-// before).  Used where the minibatch did not come out of k_rdx_emit (library-sort Localizer for
+// 2 .. BWD_SMALL ("few"), BWD_SMALL+1 .. BWD_MID ("mid") and more ("hot") occurrences into ONE list
+// bucket each (one atomic per block and list; the three counters zeroed before).  Used where the minibatch did not come out of k_rdx_emit (library-sort Localizer for
 // very large batches, batches localized on the host).
 __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U,
-                                                    uint2* __restrict__ mid0, uint2* __restrict__ hot0,
-                                                    uint32_t* __restrict__ mid_ent, uint32_t* __restrict__ hot_ent) {
-  __shared__ uint32_t cnt[2], base[2];
+                                                    uint2* __restrict__ mid0, uint2* __restrict__ hot0, uint2* __restrict__ few0,
+                                                    uint32_t* __restrict__ mid_ent, uint32_t* __restrict__ hot_ent,
+                                                    uint32_t* __restrict__ few_ent) {
+  __shared__ uint32_t cnt[3], base[3];
   const uint32_t U = *d_U;
   for (uint32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += gridDim.x * blockDim.x) {
-    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t u = u0 + threadIdx.x;
     uint32_t len = 0, slot = 0;
     if (u < U) len = col_ptr[u + 1] - col_ptr[u];
-    const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : -1);
+    const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : (len > 1 ? 2 : -1));
     if (which >= 0) slot = atomicAdd(&cnt[which], 1u);
     __syncthreads();
     if (threadIdx.x == 0 && cnt[0]) base[0] = atomicAdd(&mid0->x, cnt[0]);
     if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(&hot0->x, cnt[1]);
+    if (threadIdx.x == 2 && cnt[2]) base[2] = atomicAdd(&few0->x, cnt[2]);
     __syncthreads();
     if (which == 0) mid_ent[base[0] + slot] = u;
     if (which == 1) hot_ent[base[1] + slot] = u;
+    if (which == 2) few_ent[base[2] + slot] = u;
     __syncthreads();
   }
 }
 
 // one list bucket at offset 0, empty: what k_seg_lists adds to
-__global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0) {
+__global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0, uint2* few0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     *mid0 = make_uint2(0u, 0u);
     *hot0 = make_uint2(0u, 0u);
+    *few0 = make_uint2(0u, 0u);
   }
 }
 

@@ -107,6 +107,8 @@ struct SegListsOut {
   uint32_t* mid_ent;
   uint2* hot;
   uint32_t* hot_ent;
+  uint2* few;   // keys with 2 .. BWD_SMALL occurrences (k_update_fused)
+  uint32_t* few_ent;
 };
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
@@ -595,11 +597,12 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
 // bucket; does its first key continue the previous bucket's last key; where did the run that is
 // open at the bucket's start begin) and writes the Localizer's outputs.
 //
-// Segment lengths — needed to sort the keys into the short / mid / hot roles of
-// k_backward_all — are known where a segment ENDS: the head of the next run (or the end of the
+// Segment lengths — needed to sort the keys into the roles of k_backward_all / k_update_fused
+// (one occurrence: no list; 2 .. BWD_SMALL: "few"; .. BWD_MID: "mid"; more: "hot") — are known where a segment ENDS: the head of the next run (or the end of the
 // minibatch) closes it, and the closing thread knows the start from the running maximum of head
 // positions.  Every bucket lists the long segments it closes in its own slot range (at most
-// n_b / 9 + 2 mid and n_b / 257 + 2 hot ones: no atomics between blocks, no compaction pass).
+// n_b / 2 + 2 few, n_b / (BWD_SMALL + 1) + 2 mid and n_b / (BWD_MID + 1) + 2 hot ones: no atomics between
+// blocks, no compaction pass).
 // the writing half of emit for one bucket whose sorted pairs are sk / sp [0, n) (LDS or global):
 // `cont`: the bucket's first key continues the previous non-empty bucket's last key; `ubase`: unique
 // keys before the bucket; `carry1`: position + 1 of the last run head before the bucket (0: none).
@@ -611,9 +614,10 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
                                                 uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr,
                                                 uint32_t* __restrict__ index, uint32_t* __restrict__ s_row,
                                                 float* __restrict__ s_val, uint32_t* __restrict__ d_U, const SegListsOut& sl,
-                                                uint32_t* wsum, uint32_t* wmax, uint32_t* n_mid, uint32_t* n_hot) {
+                                                uint32_t* wsum, uint32_t* wmax, uint32_t* n_mid, uint32_t* n_hot,
+                                                uint32_t* n_few) {
   const uint32_t P = (uint32_t)v.P;
-  const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b;
+  const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b, foff = beg / 2 + 2 * b;
   uint32_t run_heads = 0, run_max1 = carry1;
   for (uint32_t base = 0; base < n; base += blockDim.x) {
     const uint32_t t = base + threadIdx.x;
@@ -641,6 +645,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
           const uint32_t len = i - (prev1 - 1);
           if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid - 1;
           else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid - 1;
+          else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = uid - 1;
         }
       }
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
@@ -652,6 +657,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
         const uint32_t len = v.n - (head ? i : prev1 - 1);
         if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid;
         else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid;
+        else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = uid;
       }
       // the splitters of the next call: the exact P-quantiles of this sorted order
       if (P > 1) {
@@ -669,6 +675,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
   if (threadIdx.x == 0) {
     sl.mid[b] = make_uint2(*n_mid, moff);
     sl.hot[b] = make_uint2(*n_hot, hoff);
+    sl.few[b] = make_uint2(*n_few, foff);
   }
 }
 
@@ -679,7 +686,7 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
                                                                 uint32_t* __restrict__ d_U, SegListsOut sl) {
   constexpr int NW = LOC_EMIT_THREADS / 64;
   __shared__ uint32_t wsum[NW], wmax[NW];
-  __shared__ uint32_t sh_cont, n_mid, n_hot;
+  __shared__ uint32_t sh_cont, n_mid, n_hot, n_few;
   const uint32_t P = (uint32_t)v.P;
   for (uint32_t b = blockIdx.x; b < P; b += gridDim.x) {
     __syncthreads();  // the shared counters of the previous bucket have been published
@@ -688,9 +695,11 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     if (threadIdx.x == 0) {
       n_mid = 0;
       n_hot = 0;
+      n_few = 0;
       if (n == 0) {
         sl.mid[b] = make_uint2(0u, 0u);
         sl.hot[b] = make_uint2(0u, 0u);
+        sl.few[b] = make_uint2(0u, 0u);
       }
     }
     if (n == 0) continue;
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     block_exclusive_max<NW>(carry1, wmax, &carry_all);
     __syncthreads();
     loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr,
-                        index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot);
+                        index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few);
   }
 }
 

@@ -586,7 +586,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       if (rc) return rc;
     }
     if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own);
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw);
       if (rc) return rc;
     } else if (any_own) {
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);

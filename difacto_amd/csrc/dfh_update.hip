@@ -1,0 +1,458 @@
+// k_update_fused: FMLoss::CalcGrad (src/loss/fm_loss.h:148-199) + Store::Push(kGradient) ->
+// SGDUpdater::Update (src/sgd/sgd_updater.cc:74-138) on the resident table, ONE launch, for gfx950.
+//
+// The segment lengths of a minibatch's keys are Zipf-distributed: at C3 size 80 % of the unique keys
+// occur exactly once, 17 % two to eight times, and the 4 000 keys beyond hold half of all occurrences
+// (up to ~1 300 each).  Four roles, chosen by block range, longest dependent chains first:
+//
+//   hot      > BWD_MID occurrences      one key per block: its waves split the segment in tiles of 64
+//                                       occurrences, partial sums meet in LDS in wave order
+//   mid      BWD_SMALL+1 .. BWD_MID     one key per wave, one tile
+//   few      2 .. BWD_SMALL             one L-lane group per key, occurrences summed serially in row
+//                                       order (the reference's own order, spmm.h:137-156)
+//   singles  1                          EXAMPLE by example, no key-ordered view at all: the wave that
+//                                       owns example i holds p_i and XV_i once (one coalesced 4*kp B
+//                                       read instead of a random one per key), picks the example's
+//                                       single-occurrence keys out of {row, flags} words k_lookup left
+//                                       in uw[] and updates up to DFH_UPD_ROUNDS * (64/L) rows per
+//                                       round trip.  gw = p x, gV = (XV p) x - V x^2 p: one term, no sum.
+//
+// hot / mid / few walk per-bucket key lists the Localizer's emit pass writes (k_loc_emit; k_seg_lists
+// for the other Localizer paths).  A tile keeps DFH_UPD_DEPTH XV-row loads per lane in flight (the
+// long-segment roles are chains of L2 round trips: depth, not occupancy, shortens them).  Every key is
+// updated by exactly one role, by one lane group: deterministic, no float atomics, nothing is
+// communicated between blocks.  V rows are read speculatively (a row without V holds zeros).
+// The update arithmetic is ftrl_update_w / adagrad_update_v of dfh_kernels.hip (operation for
+// operation the reference's); the kernel is pinned to 8 waves per SIMD (64 registers) like
+// k_backward_all, for the same reason (co-residency with the preparation stream).
+#ifndef DFH_UPDATE_HIP_
+#define DFH_UPDATE_HIP_
+#include "dfh_internal.h"
+
+namespace dfh {
+
+#ifndef DFH_UPD_DEPTH
+#define DFH_UPD_DEPTH 8
+#endif
+#ifndef DFH_UPD_ROUNDS
+#define DFH_UPD_ROUNDS 2
+#endif
+#ifndef DFH_UPD_FEW_DEPTH
+#define DFH_UPD_FEW_DEPTH 4
+#endif
+#ifndef DFH_UPD_ROLES
+#define DFH_UPD_ROLES 15  // measurement builds only: bit mask of the roles compiled in (hot, mid, few, singles)
+#endif
+#ifndef DFH_UPD_WAVES
+#define DFH_UPD_WAVES 5
+#endif
+#ifndef DFH_UPD_THREADS
+#define DFH_UPD_THREADS 256
+#endif
+constexpr int UPD_THREADS = DFH_UPD_THREADS;
+constexpr int UPD_NW = UPD_THREADS / 64;
+
+// one compact argument block (the roles use disjoint parts of it)
+struct UpdArgs {
+  // the minibatch, row order
+  const uint32_t* offset;   // [nrows + 1]
+  const uint32_t* index;    // [nnz] rank of the key of every nonzero
+  const float* value;       // [nnz] or NULL (binary features)
+  // per unique key
+  const uint2* uw;          // [U] {table row | kSingleRow, w} as of this step's k_lookup
+  const uint32_t* col_ptr;  // [U + 1] segment starts in the key-ordered view
+  const uint64_t* feaids;   // [U]
+  // key-ordered view
+  const uint32_t* s_row;    // [nnz]
+  const float* s_val;       // [nnz] or NULL
+  // per example, left by k_forward
+  const float* slope;       // [nrows] p_i
+  const float* xv;          // [nrows x kp]
+  // the model
+  RowHdr* hdr;
+  float* va;
+  uint32_t* need_init;      // REFRAND: keys whose V is to be initialised after the launch
+  double* prog;
+  SegLists seg;
+  uint32_t nrows;
+  uint32_t nlist;           // list buckets
+  uint32_t nb_hot, nb_mid, nb_few;  // blocks per role; the remaining blocks of the grid take the singles
+  int k, kp;
+  KeyRange rg;              // sharded store: only the keys this rank owns
+  dfh_updater_param p;
+};
+
+// SGDUpdater::Update(kGradient) for one key whose sums are complete: executed by the L lanes of ONE
+// group (the caller masks the others).  h0 = {w, has_V, sqrt_g, z}; vv / ac: this lane's V and
+// accumulator slices; g4: sum of (XV p) x over the occurrences.
+template <bool EXACT>
+__device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t u, const float4 h0, const float4 vv, const float4 ac,
+                                          float gw, float xxp, float4 g4, int sub, bool sub_ok, int k, int kp, float& pen) {
+  const float w_old = h0.x;
+  const bool has_v = k > 0 && __float_as_uint(h0.y) != 0u;
+  RowHdr* hp = a.hdr + r;
+  float* va = a.va + (size_t)r * (size_t)(2 * kp);
+  if (has_v) {
+    // grad_V = X'(diag(p) XV) - diag(XXp) V   (fm_loss.h:181-198)
+    g4.x -= vv.x * xxp; g4.y -= vv.y * xxp; g4.z -= vv.z * xxp; g4.w -= vv.w * xxp;
+    // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
+    if (sub_ok) pen += 0.5f * a.p.V_l2 * (vv.x * vv.x + vv.y * vv.y + vv.z * vv.z + vv.w * vv.w);
+  }
+  if (sub == 0) {
+    pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
+    float sqrt_g = h0.z, z = h0.w;
+    const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, a.p);
+    uint32_t hv = has_v ? 1u : 0u;
+    // lazy InitV when w leaves zero (sgd_updater.cc:122-126); fea_cnt is read only here
+    if (w_old == 0 && w_new != 0 && k > 0 && !has_v && hp->fea_cnt > (float)a.p.V_threshold) {
+      if (a.p.init_mode == DFH_INIT_HASH) {
+        const uint64_t key = a.feaids[u];
+        for (int j = 0; j < kp; ++j) {
+          va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
+          va[kp + j] = 0.0f;
+        }
+        hv = 1u;
+      } else {
+        a.need_init[u] = 1;
+      }
+    }
+    st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));  // one 16 B store
+  }
+  if (has_v && sub_ok) {
+    float4 nv = vv, na = ac;
+    adagrad_update_v(g4.x, nv.x, na.x, a.p);
+    adagrad_update_v(g4.y, nv.y, na.y, a.p);
+    adagrad_update_v(g4.z, nv.z, na.z, a.p);
+    adagrad_update_v(g4.w, nv.w, na.w, a.p);
+    if (!EXACT || k != kp) {  // padded coordinates (>= k) stay exactly zero
+      const int d0 = sub * 4;
+      if (d0 + 0 >= k) { nv.x = 0.f; na.x = 0.f; }
+      if (d0 + 1 >= k) { nv.y = 0.f; na.y = 0.f; }
+      if (d0 + 2 >= k) { nv.z = 0.f; na.z = 0.f; }
+      if (d0 + 3 >= k) { nv.w = 0.f; na.w = 0.f; }
+    }
+    st4_nt(va + sub * 4, nv);
+    st4_nt(va + kp + sub * 4, na);
+  }
+}
+
+// the model row of a key, for the group that will apply its update: {w, has_V, sqrt_g, z}, V and
+// accumulator slices, three independent loads.  NO load of this file sits behind a per-lane condition:
+// a conditional load compiles to a branch with the wait for its result inside, one load in flight at a
+// time.  Lanes with nothing to fetch read a valid address instead (row 0, their group's last row, the
+// row's first slice) and never use what arrives.
+__device__ __forceinline__ void upd_load_row(const UpdArgs& a, uint32_t r, int sub, bool sub_ok, int kp, float4& h0, float4& vv,
+                                             float4& ac) {
+  const float* va = a.va + (size_t)r * (size_t)(2 * kp) + (sub_ok ? sub * 4 : 0);
+  h0 = ld4(reinterpret_cast<const float*>(a.hdr + r));
+  vv = ld4_nt(va);
+  ac = ld4_nt(va + kp);
+}
+
+// 16 B from a batch-sized array: uniform base + 32-bit byte offset (one address register per load in flight)
+__device__ __forceinline__ float4 ld4_off(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// 0/1 factors instead of selects on loaded values: a select whose operand is a load is turned back into a
+// branch around that load by the code generator
+__device__ __forceinline__ float upd_mask(bool c) { return c ? 1.0f : 0.0f; }
+
+// sums over the occurrences [beg, end) this wave takes: tiles of 64 starting at tile w0, stride wstep
+// tiles.  Per tile: one coalesced read of the occurrence list, one gather of the slopes, then the XV
+// rows, DB loads per lane in flight (64/L rows per load instruction).  Result: gw / xxp wave-reduced,
+// gv reduced across the groups (every group holds the sums of its lane slice).
+template <int L, int DB, bool HAS_VAL>
+__device__ __forceinline__ KeySums upd_tile_sums(const UpdArgs& a, uint32_t beg, uint32_t end, uint32_t w0, uint32_t wstep, int grp,
+                                                 int sub, bool sub_ok, int k, int kp) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const uint32_t lane_off = (sub_ok ? sub * 16 : 0), row_bytes = (uint32_t)kp * 4u;
+  KeySums s;
+  s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint32_t base = beg + w0 * 64u; base < end; base += wstep * 64u) {
+    const uint32_t j = min(base + lane, end - 1);  // lanes past the end re-read the last occurrence; their x is 0
+    const uint32_t row = a.s_row[j];
+    const float x = (HAS_VAL ? a.s_val[j] : 1.0f) * upd_mask(base + lane < end);
+    const float p = a.slope[row];
+    s.gw += p * x;          // spmv.h:160-163
+    s.xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
+    const int cnt = (int)min(64u, end - base);
+    for (int t0 = 0; t0 < cnt; t0 += DB * G) {
+      float4 av[DB];
+#pragma unroll
+      for (int q = 0; q < DB; ++q) {  // DB row loads in flight per lane; occurrences past cnt: some valid row, factor 0
+        const int tt = t0 + q * G + grp;
+        const uint32_t rowi = __shfl(row, tt & 63, 64);
+        av[q] = ld4_off(a.xv, rowi * row_bytes + lane_off);
+      }
+#pragma unroll
+      for (int q = 0; q < DB; ++q) {
+        // the factors are fetched when the row has arrived: registers hold rows, not broadcasts
+        const int tt = t0 + q * G + grp;
+        const float pp = __shfl(p, tt & 63, 64);
+        const float xl = __shfl(x, tt & 63, 64);
+        const float xx = tt < cnt ? xl : 0.f;
+        s.gv.x += (av[q].x * pp) * xx; s.gv.y += (av[q].y * pp) * xx;
+        s.gv.z += (av[q].z * pp) * xx; s.gv.w += (av[q].w * pp) * xx;
+      }
+    }
+  }
+  s.gw = wave_sum(s.gw);
+  s.xxp = wave_sum(s.xxp);
+  s.gv.x = cross_group_sum<L>(s.gv.x); s.gv.y = cross_group_sum<L>(s.gv.y);
+  s.gv.z = cross_group_sum<L>(s.gv.z); s.gv.w = cross_group_sum<L>(s.gv.w);
+  return s;
+}
+
+// list buckets are dealt to teams of `units` (waves or blocks): T units per bucket when there are more
+// units than buckets.  -> false: this unit has no team
+struct UpdTeam {
+  uint32_t first, stride;  // buckets first, first + stride, ...
+  uint32_t sub, size;      // this unit's place in its team, units per team
+};
+__device__ __forceinline__ bool upd_team(uint32_t unit, uint32_t units, uint32_t nb, UpdTeam& t) {
+  if (nb == 0 || units == 0) return false;
+  t.size = max(1u, units / nb);
+  t.stride = units / t.size;
+  t.first = unit / t.size;
+  t.sub = unit % t.size;
+  return t.first < t.stride;
+}
+
+// ---- hot: one key per block and iteration
+template <int L, bool EXACT, int DB, bool HAS_VAL>
+__device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uint32_t nblk, float& pen) {
+  __shared__ float part[UPD_NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
+  const int lane = lane_id();
+  const int grp = lane / L, sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp, k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  const int w = threadIdx.x >> 6;
+  UpdTeam tm;
+  if (!upd_team(blk, nblk, a.nlist, tm)) return;  // uniform per block: the barriers below are reached by all of its threads
+  for (uint32_t lb = tm.first; lb < a.nlist; lb += tm.stride) {
+    const uint2 co = a.seg.hot[lb];
+    if (co.x == 0) continue;
+    const uint32_t* __restrict__ ent = a.seg.hot_ent + co.y;
+    for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
+      const uint32_t u = ent[q];
+      if (!key_in(a.rg, u)) continue;  // uniform per block
+      const uint32_t beg = a.col_ptr[u], end = a.col_ptr[u + 1];
+      const uint32_t r = a.uw[u].x & kRowMask;
+      const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
+      __syncthreads();  // the previous key's partials have been consumed
+      if (grp == 0) {
+        if (sub == 0) { part[w][0] = s.gw; part[w][1] = s.xxp; }
+        if (sub_ok) {
+          part[w][2 + sub * 4 + 0] = s.gv.x; part[w][2 + sub * 4 + 1] = s.gv.y;
+          part[w][2 + sub * 4 + 2] = s.gv.z; part[w][2 + sub * 4 + 3] = s.gv.w;
+        }
+      }
+      __syncthreads();
+      if (w == 0 && grp == 0) {
+        float4 h0, vv, ac;
+        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
+        float gw = 0.f, xxp = 0.f;
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < UPD_NW; ++i) {  // wave order: deterministic
+          gw += part[i][0];
+          xxp += part[i][1];
+          if (sub_ok) {
+            g4.x += part[i][2 + sub * 4 + 0]; g4.y += part[i][2 + sub * 4 + 1];
+            g4.z += part[i][2 + sub * 4 + 2]; g4.w += part[i][2 + sub * 4 + 3];
+          }
+        }
+        upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen);
+      }
+    }
+  }
+}
+
+// ---- mid: one key per wave and iteration
+template <int L, bool EXACT, int DB, bool HAS_VAL>
+__device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
+  const int lane = lane_id();
+  const int grp = lane / L, sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp, k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  UpdTeam tm;
+  if (!upd_team(wave, nwaves, a.nlist, tm)) return;
+  for (uint32_t lb = tm.first; lb < a.nlist; lb += tm.stride) {
+    const uint2 co = a.seg.mid[lb];
+    if (co.x == 0) continue;
+    const uint32_t* __restrict__ ent = a.seg.mid_ent + co.y;
+    for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
+      const uint32_t u = ent[q];
+      if (!key_in(a.rg, u)) continue;  // uniform per wave
+      const uint32_t beg = a.col_ptr[u], end = a.col_ptr[u + 1];
+      const uint32_t r = a.uw[u].x & kRowMask;
+      const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, 0u, 1u, grp, sub, sub_ok, k, kp);
+      // the key's row is fetched after the sums: one more round trip for a segment of 9+ occurrences,
+      // 12 registers fewer alive through the tile
+      if (grp == 0) {
+        float4 h0, vv, ac;
+        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
+        upd_apply<EXACT>(a, r, u, h0, vv, ac, s.gw, s.xxp, s.gv, sub, sub_ok, k, kp, pen);
+      }
+    }
+  }
+}
+
+// ---- few: one L-lane group per key, occurrences in row order
+template <int L, bool EXACT, bool HAS_VAL>
+__device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
+  constexpr int G = 64 / L;
+  constexpr int FD = DFH_UPD_FEW_DEPTH;
+  const int lane = lane_id();
+  const int grp = lane / L, sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp, k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  const uint32_t lane_off = (sub_ok ? sub * 16 : 0), row_bytes = (uint32_t)kp * 4u;
+  UpdTeam tm;
+  if (!upd_team(wave, nwaves, a.nlist, tm)) return;
+  for (uint32_t lb = tm.first; lb < a.nlist; lb += tm.stride) {
+    const uint2 co = a.seg.few[lb];
+    const uint32_t n = co.x;
+    if (n == 0) continue;
+    const uint32_t* __restrict__ ent = a.seg.few_ent + co.y;
+    for (uint32_t q0 = tm.sub * G; q0 < n; q0 += tm.size * G) {
+      // round trip 1: the key, its row word, its segment
+      const uint32_t q = q0 + grp;
+      const uint32_t u = ent[min(q, n - 1)];
+      const bool act = q < n && key_in(a.rg, u);
+      const uint32_t rw = a.uw[u].x;
+      const uint32_t beg = a.col_ptr[u];
+      const uint32_t len_all = a.col_ptr[u + 1] - beg;
+      const uint32_t len = act ? len_all : 0u;
+      const uint32_t last = beg + max(len_all, 1u) - 1u;
+      // a group without a key of its own (list exhausted, key of another rank) reads row 0 and drops it
+      const uint32_t r = (act && (rw & kRemoteRow) == 0u) ? (rw & kRowMask) : 0u;
+      // round trip 2: the model row and the first occurrences, back to back
+      float4 h0, vv, ac;
+      upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
+      float gw = 0.f, xxp = 0.f;
+      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t j0 = 0; __ballot(j0 < len) != 0ull; j0 += FD) {
+        uint32_t rows[FD];
+        float xs[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {  // occurrences past the segment: its last one again, factor 0
+          const uint32_t jj = min(beg + j0 + d, last);
+          rows[d] = a.s_row[jj];
+          xs[d] = (HAS_VAL ? a.s_val[jj] : 1.0f) * upd_mask(j0 + d < len);
+        }
+        float ps[FD];
+        float4 av[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {  // round trip 3 (+): slopes and XV rows of these occurrences
+          ps[d] = a.slope[rows[d]];
+          av[d] = ld4_off(a.xv, rows[d] * row_bytes + lane_off);
+        }
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {  // ascending rows: the reference's order (spmm.h:137-156)
+          const float pp = ps[d], xx = xs[d];
+          gw += pp * xx;
+          xxp += pp * (xx * xx);
+          g4.x += (av[d].x * pp) * xx; g4.y += (av[d].y * pp) * xx;
+          g4.z += (av[d].z * pp) * xx; g4.w += (av[d].w * pp) * xx;
+        }
+      }
+      if (act) upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen);
+    }
+  }
+}
+
+// ---- singles: example by example
+template <int L, bool EXACT, int RB, bool HAS_VAL>
+__device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const int grp = lane / L, sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp, k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  for (uint32_t i = wave; i < a.nrows; i += nwaves) {
+    const uint32_t beg = a.offset[i], end = a.offset[i + 1];
+    if (beg == end) continue;
+    // the example's slope and its XV slice: once per example, coalesced
+    const float p = a.slope[i];
+    const float4 xvi = ld4_off(a.xv, i * ((uint32_t)kp * 4u) + (sub_ok ? sub * 16 : 0));
+    for (uint32_t base = beg; base < end; base += 64u) {
+      const bool valid = base + lane < end;
+      const uint32_t j = min(base + lane, end - 1);
+      const uint32_t u = a.index[j];
+      const float x = HAS_VAL ? a.value[j] : 1.0f;
+      const uint32_t rw = a.uw[u].x;
+      const bool single = valid && (rw & (kSingleRow | kRemoteRow)) == kSingleRow && key_in(a.rg, u);
+      const unsigned long long mask = __ballot(single);
+      const int n1 = __popcll(mask);
+      if (n1 == 0) continue;
+      // compact the single-occurrence nonzeros to the low lanes (a permutation of the wave: the
+      // others are packed behind them)
+      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      const int dest = (single ? rank : n1 + (lane - rank)) * 4;
+      const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & kRowMask));
+      const uint32_t c_u = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)u);
+      const float c_x = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(x)));
+      for (int t0 = 0; t0 < n1; t0 += RB * G) {
+        float4 h0[RB], vv[RB], ac[RB];
+        uint32_t rr[RB], uu[RB];
+        float xs[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {  // RB * G model rows per round trip; groups past the last key fetch it again
+          const int t = min(t0 + q * G + grp, n1 - 1);
+          rr[q] = __shfl(c_r, t, 64);
+          uu[q] = __shfl(c_u, t, 64);
+          xs[q] = __shfl(c_x, t, 64);
+          upd_load_row(a, rr[q], sub, sub_ok, kp, h0[q], vv[q], ac[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          if (t0 + q * G + grp < n1) {
+            const float xx = xs[q];
+            // one occurrence: the segmented sums of the other roles with a single term (0 + term)
+            const float gw = p * xx, xxp = p * (xx * xx);
+            const float4 g4 = make_float4((xvi.x * p) * xx, (xvi.y * p) * xx, (xvi.z * p) * xx, (xvi.w * p) * xx);
+            upd_apply<EXACT>(a, rr[q], uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int L, bool EXACT, bool HAS_VAL>
+__global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
+  float pen = 0.f;
+  const uint32_t w = threadIdx.x >> 6;
+  uint32_t bid = blockIdx.x;
+  if (bid < a.nb_hot) {
+    if (DFH_UPD_ROLES & 1)
+    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid, a.nb_hot, pen);
+  } else if ((bid -= a.nb_hot) < a.nb_mid) {
+    if (DFH_UPD_ROLES & 2)
+    upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);
+  } else if ((bid -= a.nb_mid) < a.nb_few) {
+    if (DFH_UPD_ROLES & 4)
+    upd_few_role<L, EXACT, HAS_VAL>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
+  } else {
+    bid -= a.nb_few;
+    if (DFH_UPD_ROLES & 8)
+    upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL>(a, bid * UPD_NW + w, (gridDim.x - a.nb_hot - a.nb_mid - a.nb_few) * UPD_NW, pen);
+  }
+  // penalty of the pulled weights (sgd_learner.cc:249-273): per-lane fp32 partials (a handful of terms each),
+  // widened here; one private slot per block (same-address atomics serialise)
+  __shared__ double pen_blk[UPD_NW];
+  const double pw = wave_sum_d((double)pen);
+  if (lane_id() == 0) pen_blk[w] = pw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < UPD_NW; ++i) t += pen_blk[i];
+    if (t != 0.0) atomicAdd(&a.prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
+  }
+}
+
+}  // namespace dfh
+#endif  // DFH_UPDATE_HIP_
