@@ -292,7 +292,65 @@ class Ref:
         L.ref_auc.argtypes = [vp, vp, sz]
         L.ref_logit_objv.restype = f32
         L.ref_logit_objv.argtypes = [vp, vp, sz]
+        # data-format half (present when the build found an lz4.h: oracle/Makefile)
+        self.has_ingest = hasattr(L, "ref_crb_compress")
+        if self.has_ingest:
+            L.ref_crb_compress.restype = C.c_long
+            L.ref_crb_compress.argtypes = [sz, vp, vp, vp, vp, vp, vp, sz]
+            L.ref_crb_decompress.restype = C.c_long
+            L.ref_crb_decompress.argtypes = [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp]
+            L.ref_criteo_parse.restype = C.c_long
+            L.ref_criteo_parse.argtypes = [C.c_char_p, sz, i32, sz, sz, vp, vp, vp, vp]
+            L.ref_city_checker_hash64.restype = u64
+            L.ref_city_checker_hash64.argtypes = [C.c_char_p, sz]
         self._loss = {}
+
+    # ---- the reference's on-disk formats (src/data/compressed_row_block.h, src/reader/criteo_parser.h)
+    def crb_compress(self, offset, label, index, value=None, weight=None):
+        """CompressedRowBlock::Compress<feaid_t> -> the record's bytes"""
+        offset = _sz(offset)
+        label = _f32(label)
+        index = np.ascontiguousarray(index, np.uint64)
+        value, weight = _f32(value), _f32(weight)
+        n = len(offset) - 1
+        nnz = int(offset[-1] - offset[0])
+        cap = 64 + 2 * (8 * (n + 1) + 12 * max(nnz, 1) + 8 * max(n, 1)) + 4096
+        out = np.zeros(cap, np.uint8)
+        got = self.L.ref_crb_compress(n, _p(offset), _p(label), _p(index), _p(value), _p(weight), _p(out), cap)
+        assert got >= 0
+        return out[:got].tobytes()
+
+    def crb_decompress(self, rec, row_cap=1 << 16, nnz_cap=1 << 22):
+        """CompressedRowBlock::Decompress<feaid_t> -> dict(offset, label, index, value | None, weight | None)"""
+        rec = bytes(rec)
+        buf = np.frombuffer(rec, np.uint8)
+        off = np.zeros(row_cap + 1, np.uint64)
+        lab = np.zeros(row_cap, np.float32)
+        idx = np.zeros(nnz_cap, np.uint64)
+        val = np.zeros(nnz_cap, np.float32)
+        wgt = np.zeros(row_cap, np.float32)
+        cnt = np.zeros(4, np.int64)
+        n = self.L.ref_crb_decompress(_p(buf), len(rec), row_cap, nnz_cap, _p(off), _p(lab), _p(idx), _p(val), _p(wgt), _p(cnt))
+        assert n >= 0
+        nnz, nval, nw, nl = (int(c) for c in cnt)
+        return dict(offset=off[:n + 1].copy(), label=lab[:nl].copy(), index=idx[:nnz].copy(),
+                    value=val[:nval].copy() if nval else None, weight=wgt[:nw].copy() if nw else None)
+
+    def criteo_parse(self, text, is_train=True, row_cap=1 << 16, nnz_cap=1 << 22):
+        """CriteoParser::ParseNext over one chunk -> (offset, label, index)"""
+        text = bytes(text)
+        off = np.zeros(row_cap + 1, np.uint64)
+        lab = np.zeros(row_cap, np.float32)
+        idx = np.zeros(nnz_cap, np.uint64)
+        nnz = C.c_long(0)
+        n = self.L.ref_criteo_parse(text, len(text), 1 if is_train else 0, row_cap, nnz_cap, _p(off), _p(lab), _p(idx),
+                                    C.byref(nnz))
+        assert n >= 0
+        return off[:n + 1].copy(), lab[:n].copy(), idx[:nnz.value].copy()
+
+    def city_checker_hash64(self, s):
+        s = bytes(s)
+        return int(self.L.ref_city_checker_hash64(s, len(s)))
 
     def reverse_bytes(self, x):
         if np.isscalar(x) or isinstance(x, int):

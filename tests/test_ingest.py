@@ -250,3 +250,111 @@ def test_parser_pool_keeps_file_order(ing, tmp_path, monkeypatch, threads):
     gr = read_all(ing, rpath, "rec", batch=64)
     assert np.array_equal(gr["index"], np.concatenate(want))
     assert np.array_equal(gr["label"], np.repeat(np.arange(40), 50).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pinned to the REFERENCE'S OWN format code: tests/golden/ref_ingest.npz was written by
+# tools/make_golden_ingest.py through oracle/_ref = the reference's CompressedRowBlock::Compress
+# (src/data/compressed_row_block.h:23-50) and CriteoParser::ParseNext (src/reader/criteo_parser.h:40-94).
+# RecordIO framing (dmlc-core, absent) stays checked against oracle/ingest.py only; CityHash64 is unpinned
+# beyond k2 (three independent transcriptions agree: host/cityhash.h, oracle/ingest.py, oracle/city_checker.cc).
+# ---------------------------------------------------------------------------------------------------------
+GOLDEN_INGEST = os.path.join(ROOT, "tests", "golden", "ref_ingest.npz")
+
+
+def _golden_blocks(g):
+    i = 0
+    while "crb_rec_%d" % i in g:
+        blk = {k: (g["crb_%d_%s" % (i, k)] if "crb_%d_%s" % (i, k) in g else None) for k in ("offset", "label", "index", "value", "weight")}
+        yield g["crb_rec_%d" % i].tobytes(), blk
+        i += 1
+
+
+def test_rec_reader_on_blocks_compressed_by_the_reference(ing, tmp_path):
+    """the product's .rec reader (RecordIO + from-scratch LZ4 + CompressedRowBlock layout) decodes records the
+    REFERENCE's CompressedRowBlock::Compress wrote (golden fixture), incl. dropped all-ones values, weights,
+    and a block without nonzeros"""
+    from oracle import ingest as oi
+    g = np.load(GOLDEN_INGEST)
+    recs, blocks = zip(*_golden_blocks(g))
+    assert len(recs) >= 8
+    path = tmp_path / "ref.rec"
+    path.write_bytes(oi.write_recordio(recs))
+    got = read_all(ing, path, "rec", batch=37)
+    want_lab = np.concatenate([b["label"] for b in blocks])
+    want_idx = np.concatenate([b["index"] for b in blocks])
+    lens = np.concatenate([np.diff(b["offset"].astype(np.int64)) for b in blocks])
+    assert np.array_equal(got["label"], want_lab)
+    assert np.array_equal(np.diff(got["offset"].astype(np.int64)), lens)
+    assert np.array_equal(got["index"], want_idx)
+    want_val = np.concatenate([np.ones(len(b["index"]), np.float32) if (b["value"] is None or np.all(b["value"] == 1)) else b["value"]
+                               for b in blocks])
+    assert got["has_value"] and np.array_equal(got["value"], want_val)
+    # the Python writer the other .rec tests use produces the reference's bytes
+    for rec, b in zip(recs, blocks):
+        assert oi.write_crb_record(b["offset"], b["label"], b["index"], b["value"], b["weight"]) == rec
+
+
+def test_criteo_parser_on_the_reference_parsers_output(ing, tmp_path):
+    """CriteoChunkParser against what the reference's CriteoParser::ParseNext made of the same text (golden fixture):
+    missing fields, rows short of categorical features, CRLF, blank lines, a chunk ending without a newline, odd
+    labels and integer tokens, the criteo_test format.  (CityHash64: unpinned beyond k2 — the ids pin the slot tag,
+    the field splitting and the row cutting.)"""
+    g = np.load(GOLDEN_INGEST)
+    i = 0
+    while "criteo_text_%d" % i in g:
+        text = g["criteo_text_%d" % i].tobytes()
+        train = bool(g["criteo_%d_train" % i])
+        path = tmp_path / ("c%d.txt" % i)
+        path.write_bytes(text)
+        got = read_all(ing, path, "criteo" if train else "criteo_test", batch=50)
+        assert np.array_equal(got["offset"], g["criteo_%d_offset" % i]), i
+        assert np.array_equal(got["label"], g["criteo_%d_label" % i]), i
+        assert np.array_equal(got["index"], g["criteo_%d_index" % i]), i
+        i += 1
+    assert i >= 9
+
+
+def test_reference_format_code_live_when_built(ing, tmp_path):
+    """in the build container (oracle/_ref with the data-format half): random row blocks through the reference's
+    Compress -> product reader, oracle/ingest.py's writer -> the reference's Decompress, random criteo text through
+    both parsers, and the checker-side CityHash64 against the product's"""
+    from oracle import bindings as ob, ingest as oi
+    if not ob.have_ref():
+        pytest.skip("oracle/_ref not built here")
+    R = ob.Ref()
+    if not R.has_ingest:
+        pytest.skip("oracle/_ref built without the data-format half (no lz4.h)")
+    rng = np.random.default_rng(11)
+    recs, blocks = [], []
+    for b in range(6):
+        nrows = int(rng.integers(1, 200))
+        off = np.zeros(nrows + 1, np.uint64)
+        off[1:] = np.cumsum(rng.integers(0, 30, size=nrows))
+        nnz = int(off[-1])
+        idx = rng.integers(0, 2 ** 64 - 1, size=nnz, dtype=np.uint64)
+        val = None if b % 2 else rng.normal(size=nnz).astype(np.float32)
+        lab = rng.integers(0, 2, size=nrows).astype(np.float32)
+        rec = R.crb_compress(off, lab, idx, val)
+        assert rec == oi.write_crb_record(off, lab, idx, val)
+        d = R.crb_decompress(oi.write_crb_record(off, lab, idx, val))
+        assert np.array_equal(d["offset"], off) and np.array_equal(d["label"], lab) and np.array_equal(d["index"], idx)
+        assert (d["value"] is None) == (val is None) and (val is None or np.array_equal(d["value"], val))
+        recs.append(rec)
+        blocks.append((off, lab, idx, val))
+    path = tmp_path / "live.rec"
+    path.write_bytes(oi.write_recordio(recs))
+    got = read_all(ing, path, "rec", batch=64)
+    assert np.array_equal(got["index"], np.concatenate([b[2] for b in blocks]))
+    assert np.array_equal(got["label"], np.concatenate([b[1] for b in blocks]))
+    text = _criteo_text(rng, 300)
+    p2 = tmp_path / "live.txt"
+    p2.write_bytes(text)
+    off, lab, idx = R.criteo_parse(text)
+    got = read_all(ing, p2, "criteo", batch=128)
+    assert np.array_equal(got["offset"], off) and np.array_equal(got["label"], lab) and np.array_equal(got["index"], idx)
+    o2, l2, i2 = oi.parse_criteo(text)
+    assert np.array_equal(o2, off) and np.array_equal(i2, idx)
+    for n in list(range(0, 80)) + [127, 128, 129, 255, 256, 1000]:
+        s = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert R.city_checker_hash64(s) == ing.ingest_cityhash64(s, n) == oi.cityhash64(s), n
