@@ -41,7 +41,8 @@ struct dfh_ctx {
   // k_update_fused (fused update on the resident table): 1 = on (default), 0 = k_backward_all's fused form;
   // caps on the blocks of its four roles
   int upd_kernel = 1;
-  int upd_hot_blocks = 256, upd_mid_blocks = 512, upd_few_blocks = 512, upd_single_blocks = 2048;
+  int upd_hot_blocks = 256, upd_mid_blocks = 512, upd_few_blocks = 512, upd_single_blocks = 4096;
+  int upd_interleave = 2;      // every n-th block of the launch is a list-role block (0 / 1: list roles first)
   // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
   // consumer of these events is a stream of this device
   int event_flags = 1;
@@ -503,6 +504,7 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   a.kp = kp;
   a.rg = rg;
   a.p = tv.p;
+  a.ileave = (uint32_t)c->upd_interleave;
   // blocks per role (U and the list sizes live on the device; nnz bounds them): surplus blocks find their
   // list exhausted and leave at once
   const size_t nnz = b->nnz, G = 64 / (size_t)L;
@@ -709,6 +711,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
     DFH_ARG(value >= 1 && value <= 65536, "upd_*_blocks must be in [1, 65536]");
     (n == "upd_hot_blocks" ? c->upd_hot_blocks : n == "upd_mid_blocks" ? c->upd_mid_blocks : n == "upd_few_blocks" ? c->upd_few_blocks
                                                                                                         : c->upd_single_blocks) = value;
+  } else if (n == "upd_interleave") {
+    DFH_ARG(value >= 0 && value <= 64, "upd_interleave must be in [0, 64]");
+    c->upd_interleave = value;
   } else if (n == "event_flags") {
     DFH_ARG(value == 0 || value == 1, "event_flags must be 0 (default events) or 1 (no system-scope fence); set before batches are created");
     c->event_flags = value;

@@ -77,6 +77,8 @@ struct UpdArgs {
   uint32_t nrows;
   uint32_t nlist;           // list buckets
   uint32_t nb_hot, nb_mid, nb_few;  // blocks per role; the remaining blocks of the grid take the singles
+  uint32_t ileave;          // R > 1: every R-th block (in dispatch order) is a list-role block until those run out;
+                            // 0 / 1: all list-role blocks first
   int k, kp;
   KeyRange rg;              // sharded store: only the keys this rank owns
   dfh_updater_param p;
@@ -425,20 +427,40 @@ template <int L, bool EXACT, bool HAS_VAL>
 __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
   float pen = 0.f;
   const uint32_t w = threadIdx.x >> 6;
+  // block -> role.  The list roles (hot, mid, few) are chains of dependent round trips on few bytes, the singles
+  // stream most of the launch's HBM traffic: dispatched in that order the former would hold every block slot of
+  // the chip for the length of their chains before the first model row moves.  Interleaved 1 : (R - 1) both kinds
+  // are resident from the start.
+  const uint32_t nb_list = a.nb_hot + a.nb_mid + a.nb_few, nb_single = gridDim.x - nb_list;
   uint32_t bid = blockIdx.x;
-  if (bid < a.nb_hot) {
+  bool list_role = bid < nb_list;
+  if (a.ileave > 1u) {
+    // groups of [one list block, R - 1 singles blocks] while both kinds last, then the rest: list blocks, singles blocks
+    const uint32_t R = a.ileave, P = min(nb_list, nb_single / (R - 1u));
+    if (bid < P * R) {
+      list_role = bid % R == 0u;
+      bid = list_role ? bid / R : bid - (bid / R + 1u);
+    } else {
+      const uint32_t rem = bid - P * R;
+      list_role = rem < nb_list - P;
+      bid = list_role ? P + rem : P * (R - 1u) + (rem - (nb_list - P));
+    }
+  } else if (!list_role) {
+    bid -= nb_list;
+  }
+  if (!list_role) {
+    if (DFH_UPD_ROLES & 8)
+    upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL>(a, bid * UPD_NW + w, nb_single * UPD_NW, pen);
+  } else if (bid < a.nb_hot) {
     if (DFH_UPD_ROLES & 1)
     upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid, a.nb_hot, pen);
   } else if ((bid -= a.nb_hot) < a.nb_mid) {
     if (DFH_UPD_ROLES & 2)
     upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);
-  } else if ((bid -= a.nb_mid) < a.nb_few) {
+  } else {
+    bid -= a.nb_mid;
     if (DFH_UPD_ROLES & 4)
     upd_few_role<L, EXACT, HAS_VAL>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
-  } else {
-    bid -= a.nb_few;
-    if (DFH_UPD_ROLES & 8)
-    upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL>(a, bid * UPD_NW + w, (gridDim.x - a.nb_hot - a.nb_mid - a.nb_few) * UPD_NW, pen);
   }
   // penalty of the pulled weights (sgd_learner.cc:249-273): per-lane fp32 partials (a handful of terms each),
   // widened here; one private slot per block (same-address atomics serialise)

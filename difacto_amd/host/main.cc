@@ -13,7 +13,7 @@
 namespace difacto {
 
 struct DifactoParam : public dmlc::Parameter<DifactoParam> {
-  std::string task;     // train (default) | predict | convert
+  std::string task;     // train (default) | predict
   std::string learner;  // sgd
   DMLC_DECLARE_PARAMETER(DifactoParam) {
     DMLC_DECLARE_FIELD(learner).set_default("sgd");
@@ -81,9 +81,15 @@ int main(int argc, char* argv[]) {
     learner->Run();
     delete learner;
   } else if (param.task == "predict") {
-    LOG(FATAL) << "TODO";  // as the reference (main.cc:61-62)
+    // the reference stops at a TODO here (main.cc:61-62); its SGDLearnerParam already names model_in as the model of
+    // "a prediction task" (sgd_param.h:24-28).  The learner runs one forward pass over the data and writes pred_out.
+    Learner* learner = Learner::Create(param.learner);
+    kwargs_remain.push_back(std::make_pair("task", "predict"));
+    WarnUnknownKWArgs(param, learner->Init(kwargs_remain));
+    learner->Run();
+    delete learner;
   } else {
-    LOG(FATAL) << "unknown task: " << param.task << " (this build provides train)";
+    LOG(FATAL) << "unknown task: " << param.task << " (this build provides train and predict)";
   }
   return 0;
 }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <memory>
 #include <thread>
+#include <unistd.h>
 #include "./hip_fm_loss.h"
 #include "./host_localizer.h"
 #include "./libsvm_reader.h"
@@ -49,6 +50,11 @@ KWArgs SGDLearner::Init(const KWArgs& kwargs) {
 
 // reference: SGDLearner::RunScheduler, sgd_learner.cc:31-68
 void SGDLearner::RunScheduler() {
+  if (param_.task == "predict") {
+    RunPrediction();
+    return;
+  }
+  CHECK(param_.task == "train") << "unknown task " << param_.task;
   real_t pre_loss = 0, pre_val_auc = 0;
   for (int k = 0; k < param_.max_num_epochs; ++k) {
     sgd::Progress train_prog;
@@ -106,6 +112,39 @@ void SGDLearner::RunEpoch(int epoch, int job_type, sgd::Progress* prog) {
   if (sharded) MergeAcrossRanks(prog);
 }
 
+// task = predict (src/main.cc:61-62 is a TODO in the reference; sgd_param.h:24-28: "model_in ... should be specified if it
+// is a prediction task").  One pass, no shuffling, no sampling, nothing pushed: every data part is a job of kind
+// kPrediction whose worker loop is the validation loop (Localizer -> Pull -> FMLoss::Predict) plus the logits going to
+// a file.  One process: the parts run in order and append to <pred_out>.  Sharded: rank r takes the parts i = r (mod
+// ranks) and writes <pred_out>.part-<i>; the parts are consecutive byte ranges of the data, so concatenating the files
+// in part order gives the predictions in file order.
+void SGDLearner::RunPrediction() {
+  CHECK(param_.model_in.size()) << "task=predict needs model_in (sgd_param.h:24-28)";
+  CHECK(param_.pred_out.size()) << "task=predict needs pred_out=<file>";
+  sgd::Progress prog;
+  RunEpoch(0, sgd::Job::kPrediction, &prog);
+  LOG(INFO) << "predicted " << prog.nrows << " examples of " << (param_.data_val.size() ? param_.data_val : param_.data_in)
+            << " -> " << param_.pred_out << " (against their labels: " << prog.TextString() << ")";
+}
+
+const std::string& SGDLearner::JobData(const sgd::Job& job) const {
+  if (job.type == sgd::Job::kTraining) return param_.data_in;
+  if (job.type == sgd::Job::kPrediction) return param_.data_val.size() ? param_.data_val : param_.data_in;
+  return param_.data_val;
+}
+
+void SGDLearner::WritePredictions(dfh_batch* b) {
+  size_t nrows = 0;
+  DFH_CALL(dfh_batch_shape(b, &nrows, nullptr, nullptr));
+  pred_buf_.resize(nrows);
+  if (nrows == 0) return;
+  DFH_CALL(dfh_batch_get_pred(b, pred_buf_.data()));  // waits for the step
+  for (size_t i = 0; i < nrows; ++i) {
+    const float v = param_.pred_prob ? 1.0f / (1.0f + std::exp(-pred_buf_[i])) : pred_buf_[i];
+    CHECK_GT(fprintf(CHECK_NOTNULL(pred_file_), "%.9g\n", v), 0) << "cannot write " << param_.pred_out;
+  }
+}
+
 void SGDLearner::MergeAcrossRanks(sgd::Progress* prog) {
   auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
   if (!ss) return;
@@ -123,7 +162,17 @@ void SGDLearner::Process(const std::string& args, std::string* rets) {
   sgd::Progress prog;
   sgd::Job job;
   job.ParseFromString(args);
-  if (job.type == sgd::Job::kTraining || job.type == sgd::Job::kValidation) IterateData(job, &prog);
+  if (job.type == sgd::Job::kTraining || job.type == sgd::Job::kValidation) {
+    IterateData(job, &prog);
+  } else if (job.type == sgd::Job::kPrediction) {
+    const bool sharded = dynamic_cast<ShardedDeviceStore*>(store_) != nullptr;
+    const std::string path = sharded ? param_.pred_out + ".part-" + std::to_string(job.part_idx) : param_.pred_out;
+    pred_file_ = fopen(path.c_str(), (sharded || job.part_idx == 0) ? "w" : "a");
+    CHECK(pred_file_) << "cannot open " << path;
+    IterateData(job, &prog);
+    CHECK_EQ(fclose(pred_file_), 0) << "cannot write " << path;
+    pred_file_ = nullptr;
+  }
   prog.SerializeToString(rets);
 }
 
@@ -131,7 +180,7 @@ void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
   if (dynamic_cast<ShardedDeviceStore*>(store_)) {
     CHECK(GetUpdater()->device_param().device_path != "literal") << "the sharded store has no one-sided Push / Pull";
     IterateDataSharded(job, prog);
-  } else if (GetUpdater()->device_param().device_path == "literal") {
+  } else if (GetUpdater()->device_param().device_path == "literal" && job.type != sgd::Job::kPrediction) {
     IterateDataLiteral(job, prog);
   } else {
     IterateDataFused(job, prog);
@@ -141,8 +190,9 @@ void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
 // ---- the fused worker loop: sgd_learner.cc:129-227 on the device
 void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
+  const bool predict = job.type == sgd::Job::kPrediction;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
-  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+  BatchReader reader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
                      train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   dfh_ctx* ctx = DeviceContext::Get();
   dfh_table* table = GetUpdater()->table();
@@ -216,12 +266,16 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     if (have_next && needs_growth(reader.Value())) {
       // growing re-creates BOTH batch objects: the prepared, not yet trained batch goes first
       DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+      if (predict) WritePredictions(batch_[cur]);
       stepped = true;
     }
     if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
     if (have_next) prepare(cur ^ 1);
     if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
-    if (!stepped) DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+    if (!stepped) {
+      DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+      if (predict) WritePredictions(batch_[cur]);
+    }
     if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
     have = have_next;
     ++i;
@@ -249,9 +303,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
 // tracker keeps in flight (sgd_learner.cc:219-223), without its staleness.
 void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
+  const bool predict = job.type == sgd::Job::kPrediction;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
   auto* ss = CHECK_NOTNULL(dynamic_cast<ShardedDeviceStore*>(store_));
-  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+  BatchReader reader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
                      train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
   dfh_ctx* ctx = DeviceContext::Get();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
@@ -297,6 +352,7 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
     DFH_CALL(dfh_shard_prefetch_counts(ss->shard(), nxt));
     if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step: batch " << (cur ? "yes" : "none");
     DFH_CALL(dfh_shard_step(ss->shard(), cur, train ? 1 : 0, push_cnt ? 1 : 0, &active));
+    if (predict && cur) WritePredictions(cur);
     if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step done: active " << active;
     cur = nxt;
   }
@@ -394,15 +450,33 @@ void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress
   }
 }
 
-// Updater::Save / Load.  A sharded run writes one part per rank (<model_out>.part-<rank>) and reads
-// every part it finds, keeping the keys of its own range: a model can be re-loaded under any number
-// of ranks.
+// Updater::Save / Load.  A sharded run writes one part per rank (<model_out>.part-<rank>) plus a manifest
+// (<model_out>.parts: the number of parts, written by rank 0, which also removes the parts a run with more ranks left
+// behind under the same name) and reads exactly the parts the manifest names, keeping the keys of its own range: a
+// model can be re-loaded under any number of ranks, and stale parts of an earlier save are never imported.
 void SGDLearner::SaveModel() {
   auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
   const std::string path = ss ? param_.model_out + ".part-" + std::to_string(store_->Rank()) : param_.model_out;
-  std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(path.c_str(), "w"));
-  GetUpdater()->Save(true, fo.get());
+  {
+    std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(path.c_str(), "w"));
+    GetUpdater()->Save(true, fo.get());
+  }
   LOG(INFO) << "model saved to " << path;
+  if (ss && store_->Rank() == 0) {
+    const int world = store_->NumWorkers();
+    for (int n = world;; ++n) {  // parts of an earlier save with more ranks
+      const std::string stale = param_.model_out + ".part-" + std::to_string(n);
+      if (access(stale.c_str(), F_OK) != 0) break;
+      CHECK_EQ(unlink(stale.c_str()), 0) << "cannot remove the stale model part " << stale;
+      LOG(INFO) << "removed the stale model part " << stale;
+    }
+    const std::string mf = param_.model_out + ".parts";
+    FILE* f = fopen((mf + ".tmp").c_str(), "w");
+    CHECK(f) << "cannot write " << mf;
+    fprintf(f, "%d\n", world);
+    CHECK_EQ(fclose(f), 0);
+    CHECK_EQ(rename((mf + ".tmp").c_str(), mf.c_str()), 0);
+  }
 }
 
 void SGDLearner::LoadModel() {
@@ -416,10 +490,23 @@ void SGDLearner::LoadModel() {
   }
   uint64_t lo = 0, hi = 0, total = 0;
   DFH_CALL(dfh_shard_owned_range(ss->shard(), nullptr, &lo, &hi));
+  // how many parts: the manifest of the save; a model saved before manifests existed: every part up to the first gap
+  int want = -1;
+  const std::string mf = param_.model_in + ".parts";
+  if (FILE* f = fopen(mf.c_str(), "r")) {
+    CHECK(fscanf(f, "%d", &want) == 1 && want >= 1 && want <= 4096) << "bad model manifest " << mf;
+    fclose(f);
+  } else {
+    LOG(WARNING) << "no manifest " << mf << ": reading " << param_.model_in << ".part-<n> up to the first gap";
+  }
   int parts = 0;
   for (;; ++parts) {
+    if (want >= 0 && parts == want) break;
     const std::string path = param_.model_in + ".part-" + std::to_string(parts);
-    if (access(path.c_str(), R_OK) != 0) break;
+    if (access(path.c_str(), R_OK) != 0) {
+      CHECK(want < 0) << "model part " << path << " is missing (the manifest names " << want << " parts)";
+      break;
+    }
     uint64_t n = 0;
     int aux = 0;
     DFH_CALL(dfh_table_load(GetUpdater()->table(), path.c_str(), lo, hi, &aux, &n));

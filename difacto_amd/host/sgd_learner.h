@@ -18,6 +18,7 @@
  */
 #ifndef DIFACTO_HOST_SGD_LEARNER_H_
 #define DIFACTO_HOST_SGD_LEARNER_H_
+#include <cstdio>
 #include <functional>
 #include <string>
 #include <vector>
@@ -51,6 +52,12 @@ class SGDLearner : public Learner {
 
  private:
   void RunEpoch(int epoch, int job_type, sgd::Progress* prog);
+  /*! \brief task = predict: one forward pass of the loaded model over the data, predictions to pred_out */
+  void RunPrediction();
+  /*! \brief prediction jobs: the step's logits, one line per example, appended to the job's output file */
+  void WritePredictions(dfh_batch* b);
+  /*! \brief the data a job reads: data_in for training, data_val for validation, either for prediction */
+  const std::string& JobData(const sgd::Job& job) const;
   void IterateData(const sgd::Job& job, sgd::Progress* prog);
   void IterateDataFused(const sgd::Job& job, sgd::Progress* prog);
   void IterateDataLiteral(const sgd::Job& job, sgd::Progress* prog);
@@ -70,6 +77,8 @@ class SGDLearner : public Learner {
   // device batches of the fused path (double-buffered)
   dfh_batch* batch_[2] = {nullptr, nullptr};
   size_t batch_rows_ = 0, batch_nnz_ = 0;
+  FILE* pred_file_ = nullptr;       // open while a prediction job runs
+  std::vector<float> pred_buf_;
 };
 
 }  // namespace difacto

@@ -26,7 +26,15 @@ struct SGDLearnerParam : public dmlc::Parameter<SGDLearnerParam> {
   int num_jobs_per_epoch;    // file parts per worker and epoch
   real_t stop_rel_objv;      // stop if |objv - prev| / prev < this
   real_t stop_val_auc;       // stop if validation AUC gain < this
+  // task = predict (the reference leaves it a TODO, src/main.cc:61-62; its sgd_param.h:24-28 names model_in as
+  // the model of "a prediction task"): keys of this build, defaults leave training untouched
+  std::string task;          // "train" (default) | "predict": forward pass of model_in over data_val (else data_in)
+  std::string pred_out;      // predict: one line per example, in file order (<pred_out>.part-<i> per data part of a sharded run)
+  int pred_prob;             // predict: 0 writes the logit FMLoss::Predict returns (default), 1 writes 1 / (1 + exp(-logit))
   DMLC_DECLARE_PARAMETER(SGDLearnerParam) {
+    DMLC_DECLARE_FIELD(task).set_default("train");
+    DMLC_DECLARE_FIELD(pred_out).set_default("");
+    DMLC_DECLARE_FIELD(pred_prob).set_default(0);
     DMLC_DECLARE_FIELD(data_format).set_default("libsvm");
     DMLC_DECLARE_FIELD(data_in);
     DMLC_DECLARE_FIELD(data_val).set_default("");

@@ -34,7 +34,7 @@ struct PodRecord {
 
 /*! \brief what a worker is asked to do with which slice of the data */
 struct Job : public PodRecord<Job> {
-  enum Kind : int { kLoadModel = 1, kSaveModel = 2, kTraining = 3, kValidation = 4, kEvaluation = 5 };
+  enum Kind : int { kLoadModel = 1, kSaveModel = 2, kTraining = 3, kValidation = 4, kEvaluation = 5, kPrediction = 6 };
   int type = 0;
   int num_parts = 1;  // the data file is cut into this many byte ranges ...
   int part_idx = 0;   // ... and the job reads this one

@@ -80,7 +80,16 @@ class ShardedDeviceStore : public Store {
   ShardedDeviceStore() {
     const char* w = getenv("DMLC_NUM_WORKER");
     const char* r = getenv("DIFACTO_RANK");
+    // In the reference's launch a scheduler and servers run beside the workers and park in tracker_->Wait().  Here
+    // the workers own the model shards and schedule themselves: any other role joining would race the workers for
+    // rank 0.  It is refused, not parked: a launcher that starts one is misconfigured for this build.
+    const char* role = getenv("DMLC_ROLE");
+    CHECK(!role || std::string(role) == "worker")
+        << "DMLC_ROLE=" << role << ": this build runs workers only (each worker owns a key range of the model on its GPU and "
+        << "runs the scheduler loop itself); start DMLC_NUM_WORKER worker processes, no scheduler, no servers";
     world_ = w ? atoi(w) : 1;
+    CHECK(r || world_ <= 1) << "DMLC_NUM_WORKER=" << world_ << " needs DIFACTO_RANK (0.." << world_ - 1
+                            << ") in every worker's environment: without it every process would come up as rank 0";
     rank_ = r ? atoi(r) : 0;
     CHECK(world_ >= 1 && world_ <= 32 && rank_ >= 0 && rank_ < world_)
         << "DMLC_NUM_WORKER (1..32) / DIFACTO_RANK (0..DMLC_NUM_WORKER-1) are not consistent";

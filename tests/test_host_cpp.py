@@ -119,6 +119,7 @@ def test_cli_two_ranks_share_the_gpu_over_files(built, tmp_path):
     os.makedirs(rv)
     model = os.path.join(tmp_path, "model")
     args = [os.path.join(built, "difacto"), "argfile=" + _hash_conf(tmp_path, 5, 25), "model_out=" + model]
+    open(model + ".part-2", "wb").write(b"stale part of an earlier save with three ranks")   # must not survive
     procs = []
     for r in range(2):
         env = dict(os.environ, DMLC_ROLE="worker", DMLC_NUM_WORKER="2", DIFACTO_RANK=str(r), DIFACTO_DEVICE="0",
@@ -131,6 +132,7 @@ def test_cli_two_ranks_share_the_gpu_over_files(built, tmp_path):
     l0, l1 = _losses(outs[0][1]), _losses(outs[1][1])
     assert len(l0) >= 2 and l0 == l1, (l0, l1)          # the merged record is identical on both ranks
     assert l0[-1] < l0[0]
+    assert not os.path.exists(model + ".part-2") and open(model + ".parts").read().split() == ["2"]
     from difacto_amd import capi
     ctx = capi.Context(0)
     tb = capi.Table(ctx, 1 << 17, V_dim=8, init_mode=capi.INIT_HASH)
@@ -172,3 +174,69 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
         runs.append(_losses(r.stderr))
     assert len(runs[0]) == 3 and runs[0] == runs[1], runs
     assert runs[0][-1] < runs[0][0]
+
+
+@pytest.mark.gpu
+def test_cli_task_predict_matches_the_oracle(built, tmp_path):
+    """task=predict (a TODO in the reference's src/main.cc:61-62; sgd_param.h:24-28 names model_in for it): train with
+    model_out, then a second process loads model_in and writes one logit per example to pred_out — several data parts
+    and several minibatches per part, in file order.  Checked against FMLoss::Predict of the oracle on the weights of
+    the saved model (rtol 1e-5 + the summation floor of oracle/tolerance.py); pred_prob=1 gives the sigmoid."""
+    import numpy as np
+    from conftest import load_libsvm
+    from difacto_amd import capi
+    from oracle import bindings as ob, tolerance as T
+    model = os.path.join(tmp_path, "model.bin")
+    exe = os.path.join(built, "difacto")
+    r = subprocess.run([exe, "argfile=" + os.path.join(ROOT, "example", "rcv1_fm.conf"), "model_out=" + model],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    conf = os.path.join(tmp_path, "predict.conf")
+    text = open(os.path.join(ROOT, "example", "rcv1_predict.conf")).read().replace("batch_size = 100", "batch_size = 13")
+    open(conf, "w").write(text + "\nnum_jobs_per_epoch = 3\n")
+    pred = os.path.join(tmp_path, "pred.txt")
+    r = subprocess.run([exe, "argfile=" + conf, "model_in=" + model, "pred_out=" + pred], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    print(r.stderr[-2000:])
+    assert r.returncode == 0 and "predicted 100 examples" in r.stderr
+    got = np.loadtxt(pred, dtype=np.float32)
+    assert got.shape == (100,)
+    # the oracle's FMLoss::Predict on the saved model's weights
+    off, idx, val, lab = load_libsvm(DATA)
+    O = ob.Oracle()
+    loc = O.localize(off, idx)
+    ctx = capi.Context(0)
+    tb = capi.Table(ctx, 1 << 17, V_dim=8, init_mode=capi.INIT_REFRAND)
+    tb.load(model)
+    vals, lens = tb.pull(loc["feaids"])
+    tb.close()
+    ctx.close()
+    wp, vp = O.get_pos(lens)
+    want = O.fm_predict(8, loc["offset"], loc["index"], val, vals, wp, vp)
+    w64, V64, _ = T.dense_rows(vals, lens, 8)
+    _, floor = T.predict_bound(T.design(loc["offset"], loc["index"], val, loc["U"]), w64, V64)
+    T.check(got, want, floor + 1e-7 * np.abs(want), "task=predict logits vs FMLoss::Predict")  # + the %.9g text round trip
+    assert np.abs(want).max() > 0.05   # a trained model, not zeros
+    # probabilities
+    r = subprocess.run([exe, "argfile=" + conf, "model_in=" + model, "pred_out=" + pred, "pred_prob=1"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0
+    prob = np.loadtxt(pred, dtype=np.float32)
+    np.testing.assert_allclose(prob, 1.0 / (1.0 + np.exp(-got.astype(np.float64))), rtol=2e-6)
+    # a prediction task without a model is refused (sgd_param.h:24-28)
+    r = subprocess.run([exe, "argfile=" + conf, "pred_out=" + pred], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "needs model_in" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_refuses_roles_other_than_worker_and_a_missing_rank(built, tmp_path):
+    """a dmlc launch starts a scheduler and servers beside the workers; here every process with DMLC_ROLE set
+    would have joined as rank 0.  Other roles and DMLC_NUM_WORKER > 1 without DIFACTO_RANK are refused with a message."""
+    args = [os.path.join(built, "difacto"), "argfile=" + _hash_conf(tmp_path, 1)]
+    for env_add, msg in ((dict(DMLC_ROLE="scheduler", DMLC_NUM_WORKER="2"), "runs workers only"),
+                         (dict(DMLC_ROLE="server", DMLC_NUM_WORKER="1", DIFACTO_RANK="0"), "runs workers only"),
+                         (dict(DMLC_ROLE="worker", DMLC_NUM_WORKER="2"), "needs DIFACTO_RANK")):
+        env = {k: v for k, v in os.environ.items() if k not in ("DIFACTO_RANK", "DMLC_ROLE", "DMLC_NUM_WORKER")}
+        env.update(env_add, DIFACTO_DEVICE="0")
+        r = subprocess.run(args, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert r.returncode != 0 and msg in r.stderr, (env_add, r.stderr[-800:])
