@@ -54,8 +54,12 @@ def parse_args():
     ap.add_argument("--l1", type=float, default=None)
     ap.add_argument("--v-threshold", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic batches cycled through")
-    ap.add_argument("--min-time", type=float, default=0.5, help="repeat the K-step region until this many seconds are timed")
-    ap.add_argument("--max-reps", type=int, default=400)
+    ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step region until this many seconds are timed")
+    ap.add_argument("--max-reps", type=int, default=20000)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N=1, preset c3: skip the `secondary` block (c3-refdefaults and c5-slice, each run as a child process "
+                         "after the headline measurement has released the GPU)")
+    ap.add_argument("--secondary-min-time", type=float, default=1.0)
     ap.add_argument("--no-prefill", action="store_true", help="start from an empty model instead of a warm one")
     ap.add_argument("--cpu-batches", type=int, default=-1, help="batches in the CPU baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip per-kernel HIP-event timing")
@@ -100,20 +104,48 @@ def parse_args():
 TIMING_EVERY = int(os.environ.get("DFH_TIMING_EVERY", "4"))  # forward/backward are timed on every n-th step of the timed region
 
 
-def pmc_traffic(kernel, preset):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this preset
-    (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/rNN_pmc_hbm_traffic[_<preset>].json, collected
-    with `rocprofv3 --pmc ... -- python bench.py`), or None"""
-    suffix = "" if preset == "c3" else "_" + preset.replace("-", "_")
+def pmc_traffic(kernels, preset):
+    """(HBM bytes per launch, source file) of the first of `kernels` found in the newest committed rocprofv3 PMC
+    passes of this preset (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/rNN_pmc_hbm_traffic[_<preset>].json,
+    collected with `rocprofv3 --pmc ... -- python bench.py`, NOT measured in this run), or (None, None)"""
+    suffix = "" if preset in ("c3", "c3-refdefaults") else "_" + preset.replace("-", "_")
+    if isinstance(kernels, str):
+        kernels = [kernels]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic%s.json" % suffix)), reverse=True):
         try:
             d = json.load(open(path))
-            for name, v in d.items():
-                if name.startswith(kernel):
-                    return v["hbm_bytes_per_launch"]
+            for kernel in kernels:
+                for name, v in d.items():
+                    if name.startswith(kernel):
+                        return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError, AttributeError):
             continue
-    return None
+    return None, None
+
+
+def secondary_lines(args):
+    """the other single-GPU lines of SURVEY 8(d), each by a child process of this same file (own table, own
+    measurement, own roofline blocks): c3 with the reference's default hyper-parameters and one GPU's share of C5
+    (V_dim 128).  Run after the headline measurement has released its 21 GB; a failure is reported, not fatal."""
+    import subprocess
+    out = {}
+    for preset in ("c3-refdefaults", "c5-slice"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--preset", preset, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--min-time", str(args.secondary_min_time), "--cpu-batches", "0", "--no-secondary"]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            keep = ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repetitions", "timed_region_s_total",
+                    "dominant_kernel", "roofline", "roofline_backward", "roofline_step", "kernel_ms_per_step")
+            e = {k: d.get(k) for k in keep}
+            e["config"] = {k: d["config"].get(k) for k in ("workload", "rows_per_step", "unique_keys_per_batch", "model_keys",
+                                                           "table_bytes", "hyper")}
+            e["wall_seconds"] = time.time() - t0
+            out[preset] = e
+        except Exception as ex:  # noqa: BLE001 — the headline line must survive anything here
+            out[preset] = dict(error=repr(ex)[:300], wall_seconds=time.time() - t0)
+    return out
 
 
 def host_info():
@@ -385,8 +417,9 @@ def main():
     if timing and timing["forward"][1] > 0:
         fwd_ms = timing["forward"][0] / timing["forward"][1]
         achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
+        tr, tr_src = pmc_traffic("k_forward<", args.preset)
         roofline = dict(bound="hbm", kernel="k_forward", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic("k_forward<", args.preset),
+                        frac=achieved / HBM_PEAK_GBPS, traffic=tr, traffic_source=tr_src,
                         algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms,
                         launches_timed=int(timing["forward"][1]))
     # the same for the longest kernel of the step, the fused backward/update.  algorithmic = SURVEY 8d's
@@ -398,12 +431,29 @@ def main():
         nec = U_mean * (3 + 2 * k) * 4 * 2
         bwd_bytes = B * s_mean * k * 4 + nec
         ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9
-        roofline_bwd = dict(bound="hbm", kernel="k_backward_all", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic("k_backward_all<", args.preset),
+        tr, tr_src = pmc_traffic(["void dfh::k_update_fused<", "k_update_fused<", "k_backward_all<"], args.preset)
+        roofline_bwd = dict(bound="hbm", kernel="k_update_fused", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
+                            frac=ach / HBM_PEAK_GBPS, traffic=tr, traffic_source=tr_src,
                             algorithmic_bytes_per_launch=bwd_bytes, hbm_necessary_bytes_per_launch=nec,
                             achieved_hbm_necessary=nec / (bwd_ms * 1e-3) / 1e9,
                             frac_hbm_necessary=nec / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             avg_launch_ms=bwd_ms, launches_timed=int(timing["backward"][1]))
+    secondary = None
+    if args.preset == "c3" and not args.no_secondary:
+        # release the headline run's table and batches first: the C5 slice takes most of the HBM
+        for b in bts:
+            b.close()
+        for d in dev:
+            for x in d[:4]:
+                if x is not None:
+                    x.close()
+        tbytes = table.bytes()
+        table.close()
+        ctx.close()
+        torch.cuda.empty_cache()
+        secondary = secondary_lines(args)
+    else:
+        tbytes = table.bytes()
     nb = args.cpu_batches
     cpu = None
     if nb != 0:
@@ -427,19 +477,22 @@ def main():
         "config": {"workload": names[args.preset], "preset": args.preset,
                    "rows_per_step": B, "nnz_per_row": s_mean, "unique_keys_per_batch": U_mean,
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
-                   "model_keys": int(nkeys), "table_bytes": table.bytes(), "prefilled": not args.no_prefill, "hyper": hyper,
+                   "model_keys": int(nkeys), "table_bytes": tbytes, "prefilled": not args.no_prefill, "hyper": hyper,
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
                    "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,
         "value_note": "median of `repetitions` timed regions of `steps` steps each"
                       + (" — DIAGNOSTIC RUN without the Localizer in the step (--no-relocalize), not the metric" if args.no_relocalize else ""),
+        "dominant_kernel": "k_update_fused (fused CalcGrad + Push/update): roofline_backward; `roofline` is the gather "
+                           "kernel BASELINE.json's metric names (k_forward)",
         "roofline": roofline,
         "roofline_backward": roofline_bwd,
         "roofline_step": dict(bound="hbm", bytes_per_example=r_step, achieved=ex_per_s * r_step / 1e9, peak=HBM_PEAK_GBPS,
                               unit="GB/s", frac=ex_per_s * r_step / 1e9 / HBM_PEAK_GBPS,
                               note="SURVEY 8d R_step = s(1+k)4 + s k 4 + u(3+2k)8 with the measured u = U/B"),
         "cpu_baseline": cpu,
+        "secondary": secondary,
         "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "kernel_ms_per_step": breakdown,
         "kernel_ms_per_step_note": "separate instrumented pass after the timed region (HIP events around every kernel group)",

@@ -41,8 +41,11 @@ struct dfh_ctx {
   // k_update_fused (fused update on the resident table): 1 = on (default), 0 = k_backward_all's fused form;
   // caps on the blocks of its four roles
   int upd_kernel = 1;
-  int upd_hot_blocks = 256, upd_mid_blocks = 512, upd_few_blocks = 512, upd_single_blocks = 4096;
-  int upd_interleave = 2;      // every n-th block of the launch is a list-role block (0 / 1: list roles first)
+  // (C3 on MI355X, profiles/r03_update_roles.txt: alone, hot needs >= 1024 blocks to reach 17 us, mid 1024 for 16 us,
+  // few 1024 for 20 us, the singles 37 us from 1280 blocks on; together 512 / 512 / 1024, list roles first, is the best
+  // found: 58.7 us; more list blocks cost more in block dispatch than they save in chain length)
+  int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
+  int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
   // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
   // consumer of these events is a stream of this device
   int event_flags = 1;

@@ -84,6 +84,19 @@ struct UpdArgs {
   dfh_updater_param p;
 };
 
+// Streaming (nt) loads of everything that is read ONCE per launch — occurrence lists, row words, segment bounds, list
+// entries, model rows and their headers: what should stay in an XCD's 4 MB L2 while 150 MB of rows pass through it is
+// XV (2.56 MB at C3 size, gathered row by row by every role) and the slopes, nothing else.  -DDFH_UPD_NT=0 turns the
+// hints on the small arrays off (A/B).
+#ifndef DFH_UPD_NT
+#define DFH_UPD_NT 1
+#endif
+__device__ __forceinline__ uint32_t ldu_s(const uint32_t* p) { return DFH_UPD_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ float ldf_s(const float* p) { return DFH_UPD_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ uint32_t ld_rowword(const uint2* p) {  // .x of {row | flags, w}
+  return DFH_UPD_NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)) : p->x;
+}
+
 // SGDUpdater::Update(kGradient) for one key whose sums are complete: executed by the L lanes of ONE
 // group (the caller masks the others).  h0 = {w, has_V, sqrt_g, z}; vv / ac: this lane's V and
 // accumulator slices; g4: sum of (XV p) x over the occurrences.
@@ -118,7 +131,8 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
         a.need_init[u] = 1;
       }
     }
-    st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));  // one 16 B store
+    if (DFH_UPD_NT) st4_nt(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));  // one 16 B store
+    else st4(reinterpret_cast<float*>(hp), make_float4(w_new, __uint_as_float(hv), sqrt_g, z));
   }
   if (has_v && sub_ok) {
     float4 nv = vv, na = ac;
@@ -146,7 +160,7 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
 __device__ __forceinline__ void upd_load_row(const UpdArgs& a, uint32_t r, int sub, bool sub_ok, int kp, float4& h0, float4& vv,
                                              float4& ac) {
   const float* va = a.va + (size_t)r * (size_t)(2 * kp) + (sub_ok ? sub * 4 : 0);
-  h0 = ld4(reinterpret_cast<const float*>(a.hdr + r));
+  h0 = DFH_UPD_NT ? ld4_nt(reinterpret_cast<const float*>(a.hdr + r)) : ld4(reinterpret_cast<const float*>(a.hdr + r));
   vv = ld4_nt(va);
   ac = ld4_nt(va + kp);
 }
@@ -173,8 +187,8 @@ __device__ __forceinline__ KeySums upd_tile_sums(const UpdArgs& a, uint32_t beg,
   s.gw = 0.f; s.xxp = 0.f; s.gv = make_float4(0.f, 0.f, 0.f, 0.f);
   for (uint32_t base = beg + w0 * 64u; base < end; base += wstep * 64u) {
     const uint32_t j = min(base + lane, end - 1);  // lanes past the end re-read the last occurrence; their x is 0
-    const uint32_t row = a.s_row[j];
-    const float x = (HAS_VAL ? a.s_val[j] : 1.0f) * upd_mask(base + lane < end);
+    const uint32_t row = ldu_s(a.s_row + j);
+    const float x = (HAS_VAL ? ldf_s(a.s_val + j) : 1.0f) * upd_mask(base + lane < end);
     const float p = a.slope[row];
     s.gw += p * x;          // spmv.h:160-163
     s.xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
@@ -237,10 +251,10 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
     if (co.x == 0) continue;
     const uint32_t* __restrict__ ent = a.seg.hot_ent + co.y;
     for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
-      const uint32_t u = ent[q];
+      const uint32_t u = ldu_s(ent + q);
       if (!key_in(a.rg, u)) continue;  // uniform per block
-      const uint32_t beg = a.col_ptr[u], end = a.col_ptr[u + 1];
-      const uint32_t r = a.uw[u].x & kRowMask;
+      const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
+      const uint32_t r = ld_rowword(a.uw + u) & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
       __syncthreads();  // the previous key's partials have been consumed
       if (grp == 0) {
@@ -285,10 +299,10 @@ __device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, ui
     if (co.x == 0) continue;
     const uint32_t* __restrict__ ent = a.seg.mid_ent + co.y;
     for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
-      const uint32_t u = ent[q];
+      const uint32_t u = ldu_s(ent + q);
       if (!key_in(a.rg, u)) continue;  // uniform per wave
-      const uint32_t beg = a.col_ptr[u], end = a.col_ptr[u + 1];
-      const uint32_t r = a.uw[u].x & kRowMask;
+      const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
+      const uint32_t r = ld_rowword(a.uw + u) & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, 0u, 1u, grp, sub, sub_ok, k, kp);
       // the key's row is fetched after the sums: one more round trip for a segment of 9+ occurrences,
       // 12 registers fewer alive through the tile
@@ -321,11 +335,11 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
     for (uint32_t q0 = tm.sub * G; q0 < n; q0 += tm.size * G) {
       // round trip 1: the key, its row word, its segment
       const uint32_t q = q0 + grp;
-      const uint32_t u = ent[min(q, n - 1)];
+      const uint32_t u = ldu_s(ent + min(q, n - 1));
       const bool act = q < n && key_in(a.rg, u);
-      const uint32_t rw = a.uw[u].x;
-      const uint32_t beg = a.col_ptr[u];
-      const uint32_t len_all = a.col_ptr[u + 1] - beg;
+      const uint32_t rw = ld_rowword(a.uw + u);
+      const uint32_t beg = ldu_s(a.col_ptr + u);
+      const uint32_t len_all = ldu_s(a.col_ptr + u + 1) - beg;
       const uint32_t len = act ? len_all : 0u;
       const uint32_t last = beg + max(len_all, 1u) - 1u;
       // a group without a key of its own (list exhausted, key of another rank) reads row 0 and drops it
@@ -341,8 +355,8 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
 #pragma unroll
         for (int d = 0; d < FD; ++d) {  // occurrences past the segment: its last one again, factor 0
           const uint32_t jj = min(beg + j0 + d, last);
-          rows[d] = a.s_row[jj];
-          xs[d] = (HAS_VAL ? a.s_val[jj] : 1.0f) * upd_mask(j0 + d < len);
+          rows[d] = ldu_s(a.s_row + jj);
+          xs[d] = (HAS_VAL ? ldf_s(a.s_val + jj) : 1.0f) * upd_mask(j0 + d < len);
         }
         float ps[FD];
         float4 av[FD];
@@ -382,9 +396,9 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
     for (uint32_t base = beg; base < end; base += 64u) {
       const bool valid = base + lane < end;
       const uint32_t j = min(base + lane, end - 1);
-      const uint32_t u = a.index[j];
-      const float x = HAS_VAL ? a.value[j] : 1.0f;
-      const uint32_t rw = a.uw[u].x;
+      const uint32_t u = ldu_s(a.index + j);
+      const float x = HAS_VAL ? ldf_s(a.value + j) : 1.0f;
+      const uint32_t rw = ld_rowword(a.uw + u);
       const bool single = valid && (rw & (kSingleRow | kRemoteRow)) == kSingleRow && key_in(a.rg, u);
       const unsigned long long mask = __ballot(single);
       const int n1 = __popcll(mask);
