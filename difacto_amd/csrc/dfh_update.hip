@@ -84,12 +84,12 @@ struct UpdArgs {
   dfh_updater_param p;
 };
 
-// Streaming (nt) loads of everything that is read ONCE per launch — occurrence lists, row words, segment bounds, list
-// entries, model rows and their headers: what should stay in an XCD's 4 MB L2 while 150 MB of rows pass through it is
-// XV (2.56 MB at C3 size, gathered row by row by every role) and the slopes, nothing else.  -DDFH_UPD_NT=0 turns the
-// hints on the small arrays off (A/B).
+// Model rows (V, accumulators) are loaded and stored with streaming (nt) hints.  Measured dead end, kept as
+// -DDFH_UPD_NT=1: the same hints on everything else that is read once per launch (occurrence lists, row words, segment
+// bounds, list entries, the 16 B header loads / stores) so that only XV and the slopes would stay in an XCD's 4 MB L2:
+// 60.8 against 58.9 us stand-alone, 82.5 against 84.4 M examples/sec on one box, HBM-side traffic unchanged (213 MB).
 #ifndef DFH_UPD_NT
-#define DFH_UPD_NT 1
+#define DFH_UPD_NT 0
 #endif
 __device__ __forceinline__ uint32_t ldu_s(const uint32_t* p) { return DFH_UPD_NT ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ float ldf_s(const float* p) { return DFH_UPD_NT ? __builtin_nontemporal_load(p) : *p; }
