@@ -78,12 +78,12 @@ def parse_args():
                     help="diagnostic (NOT the metric): localize every batch object once and time lookup + forward + backward alone")
     ap.add_argument("--uniform-ranges", action="store_true",
                     help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
-    ap.add_argument("--exchange", choices=["sync", "overlap"], default="sync",
-                    help="N>1: one minibatch at a time (zero staleness, the headline), or two in flight with the exchange "
-                         "hidden behind compute (staleness 1, what the reference's batch tracker does, sgd_learner.cc:219-223)")
+    ap.add_argument("--exchange", choices=["sync", "overlap"], default="overlap",
+                    help="N>1: two minibatches in flight with the exchange hidden behind compute (staleness <= 1, what the "
+                         "reference's batch tracker does, sgd_learner.cc:219-223; the default), or one at a time (zero staleness)")
     ap.add_argument("--transport", choices=["native", "torch"], default="native",
                     help="N>1: the exchange inside libdifacto_hip.so (dfh_shard_step, RCCL ncclSend/ncclRecv; the product path) or "
-                         "the Python harness over torch.distributed (difacto_amd/sharded.py; also offers --exchange overlap)")
+                         "the test harness over torch.distributed (tests/sharded_harness.py)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     args = ap.parse_args()
@@ -260,10 +260,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         return subprocess.call(cmd)
     if args.gpus > 1 or world > 1 or args.force_sharded:
-        from difacto_amd import sharded
-        if args.transport == "native" and args.exchange == "sync":
+        if args.transport == "native":
+            from difacto_amd import sharded
             return sharded.bench_main_native(args, rank, world, local_rank, args.hyper)
-        return sharded.bench_main(args, rank, world, local_rank, args.hyper)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sharded_harness   # the torch.distributed transport: test infrastructure, not the product path
+        return sharded_harness.bench_main(args, rank, world, local_rank, args.hyper)
 
     import torch  # device plumbing only: barrier-equivalent sync + sanity that a GPU exists
     if not torch.cuda.is_available():

@@ -29,7 +29,9 @@ SYMBOLS = [
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
+    "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
 ]
+SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
 K_COUNT = 7
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
 
@@ -170,6 +172,13 @@ def lib():
     L.dfh_shard_owned_range.argtypes = [vp, vp, PP(u64), PP(u64)]
     L.dfh_shard_step.argtypes = [vp, vp, i32, i32, PP(i32)]
     L.dfh_shard_prefetch_counts.argtypes = [vp, vp]
+    L.dfh_shard_pull_host.argtypes = [vp, vp, C.c_size_t, vp, PP(C.c_size_t), vp, PP(C.c_size_t)]
+    L.dfh_shard_push_host.argtypes = [vp, vp, C.c_size_t, i32, vp, C.c_size_t, vp, C.c_size_t]
+    L.dfh_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
+    L.dfh_shard_balanced_splits.argtypes = [vp, vp, C.c_size_t, vp]
+    L.dfh_shard_set_exchange.argtypes = [vp, i32]
+    L.dfh_shard_set_timing.argtypes = [vp, i32]
+    L.dfh_shard_get_timing.argtypes = [vp, i32, vp, PP(u64)]
     _lib = L
     return L
 
@@ -612,6 +621,21 @@ class Comm:
         _ck(lib().dfh_comm_allreduce_sum(self.h, _p(a), len(a)))
         return a
 
+    def allgather(self, arr):
+        """every rank's array (same dtype and length on every rank) -> [world, len]"""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((lib().dfh_comm_world(self.h),) + a.shape, a.dtype)
+        _ck(lib().dfh_comm_allgather(self.h, _p(a), a.nbytes, _p(out)))
+        return out
+
+    def balanced_splits(self, sample_keys):
+        """collective: split keys (world-1, identical on every rank) at the quantiles of the union of the ranks' key samples"""
+        k = np.ascontiguousarray(sample_keys, np.uint64)
+        w = lib().dfh_comm_world(self.h)
+        out = np.zeros(max(w - 1, 1), np.uint64)
+        _ck(lib().dfh_shard_balanced_splits(self.h, _p(k) if len(k) else None, len(k), _p(out)))
+        return out[:w - 1]
+
     def close(self):
         if self.h:
             lib().dfh_comm_destroy(self.h)
@@ -637,6 +661,38 @@ class Shard:
     def prefetch_counts(self, next_batch):
         """collective, right before step(): the minibatch of the FOLLOWING step (localize queued) or None"""
         _ck(lib().dfh_shard_prefetch_counts(self.h, next_batch.h if next_batch is not None else None))
+
+    def pull_host(self, keys):
+        """collective literal Store::Pull(kWeight) -> (vals ragged, lens)"""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        n, k = len(keys), self.table.V_dim
+        vals = np.zeros(max(n * (1 + k), 1), np.float32)
+        lens = np.zeros(max(n, 1), np.int32)
+        nv, nl = C.c_size_t(0), C.c_size_t(0)
+        _ck(lib().dfh_shard_pull_host(self.h, _p(keys) if n else None, n, _p(vals), C.byref(nv), _p(lens), C.byref(nl)))
+        return vals[:nv.value], lens[:nl.value]
+
+    def push_host(self, keys, val_type, vals, lens=None):
+        """collective literal Store::Push(kFeaCount | kGradient)"""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        vals = np.ascontiguousarray(vals, np.float32)
+        lens = np.zeros(0, np.int32) if lens is None else np.ascontiguousarray(lens, np.int32)
+        _ck(lib().dfh_shard_push_host(self.h, _p(keys) if len(keys) else None, len(keys), val_type, _p(vals) if len(vals) else None,
+                                      len(vals), _p(lens) if len(lens) else None, len(lens)))
+
+    def set_exchange(self, mode):
+        """"sync" (one minibatch at a time, zero staleness) or "overlap" (two in flight, staleness <= 1); between epochs"""
+        _ck(lib().dfh_shard_set_exchange(self.h, {"sync": 0, "overlap": 1}[mode]))
+
+    def set_timing(self, on):
+        _ck(lib().dfh_shard_set_timing(self.h, 1 if on else 0))
+
+    def get_timing(self, reset=True):
+        """-> ({stage: ms}, steps covered)"""
+        ms = np.zeros(len(SHARD_STAGES), np.float64)
+        n = C.c_uint64(0)
+        _ck(lib().dfh_shard_get_timing(self.h, 1 if reset else 0, _p(ms), C.byref(n)))
+        return dict(zip(SHARD_STAGES, ms.tolist())), n.value
 
     def owned_range(self):
         lo, hi = C.c_uint64(0), C.c_uint64(0)

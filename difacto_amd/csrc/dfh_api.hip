@@ -50,9 +50,7 @@ struct dfh_ctx {
   // consumer of these events is a stream of this device
   int event_flags = 1;
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
-  int prep_queue_skip = 0;     // experiment: streams created (and touched once) ahead of the preparation streams, so that
-                               // those land on a different hardware queue / pipe than the main stream's neighbour
-  std::vector<hipStream_t> spare;
+
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
   struct Span { int id; hipEvent_t a, b; };
@@ -667,7 +665,6 @@ int dfh_ctx_destroy(dfh_ctx* c) {
     hipStreamSynchronize(p);
     hipStreamDestroy(p);
   }
-  for (hipStream_t p : c->spare) hipStreamDestroy(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return DFH_OK;
@@ -690,21 +687,8 @@ int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
     int lo = 0, hi = 0;
     DFH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     const int prio = c->prep_priority < 0 ? lo : (c->prep_priority > 0 ? hi : 0);
-    while ((int)c->spare.size() < c->prep_queue_skip) {
-      hipStream_t d = nullptr;
-      DFH_HIP(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
-      rc = ensure_scratch(c, 256);
-      if (rc) return rc;
-      DFH_HIP(hipMemsetAsync(c->scratch, 0, 64, d));  // first use: the stream takes its hardware queue now
-      DFH_HIP(hipStreamSynchronize(d));
-      c->spare.push_back(d);
-    }
     hipStream_t p = nullptr;
     DFH_HIP(hipStreamCreateWithPriority(&p, hipStreamNonBlocking, prio));
-    rc = ensure_scratch(c, 256);
-    if (rc) return rc;
-    DFH_HIP(hipMemsetAsync(c->scratch, 0, 64, p));
-    DFH_HIP(hipStreamSynchronize(p));
     c->preps.push_back(p);
   }
   c->nprep = (unsigned)enable;
@@ -724,10 +708,6 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "bwd_small_blocks") {
     DFH_ARG(value >= 1 && value <= 65536, "bwd_small_blocks must be in [1, 65536]");
     c->bwd_small_blocks = value;
-  } else if (n == "prep_queue_skip") {
-    DFH_ARG(value >= 0 && value <= 8, "prep_queue_skip must be in [0, 8]");
-    DFH_ARG(c->preps.empty(), "prep_queue_skip must be set before dfh_ctx_set_pipeline creates the streams");
-    c->prep_queue_skip = value;
   } else if (n == "upd_kernel") {
     DFH_ARG(value == 0 || value == 1, "upd_kernel must be 0 (k_backward_all) or 1 (k_update_fused)");
     c->upd_kernel = value;

@@ -116,19 +116,23 @@ struct dfh_shard {
   dfh_table* t = nullptr;
   dfh_comm* c = nullptr;
   uint64_t* d_splits = nullptr;         // [world-1] first keys of shards 1.. (NULL: uniform ranges)
+  std::vector<uint64_t> h_splits;       // the same on the host, uniform ranges spelled out
   int64_t* d_bounds = nullptr;          // [world+1]
   int64_t* d_cnt = nullptr;             // [2][2*world]: what I send every peer / what every peer sends me
   int64_t* h_cnt = nullptr;             // pinned copy
+  // Two sets of exchange buffers: the sync step uses set 0; the overlapped step (two minibatches in flight)
+  // alternates, one set per minibatch under way.
   // owner side, sized to the keys received in a step
-  uint64_t* r_keys = nullptr;
-  float* r_cnt = nullptr;
-  uint32_t* r_rowid = nullptr;
-  float* r_rows = nullptr;              // rows out, then gradients in
-  size_t r_cap = 0;
+  uint64_t* r_keys[2] = {nullptr, nullptr};
+  float* r_cnt[2] = {nullptr, nullptr};
+  uint32_t* r_rowid[2] = {nullptr, nullptr};
+  float* r_rows[2] = {nullptr, nullptr};   // rows out, then gradients in
+  size_t r_cap[2] = {0, 0};
   // worker side, sized to the batch's unique keys
-  float* w_rows = nullptr;
-  float* w_grads = nullptr;
-  size_t w_cap = 0;
+  float* w_rows[2] = {nullptr, nullptr};
+  size_t w_cap[2] = {0, 0};
+  float* w_grads[2] = {nullptr, nullptr};
+  size_t g_cap[2] = {0, 0};
   uint64_t steps = 0;
   // counts of the FOLLOWING step, exchanged inside the current one (dfh_shard_prefetch_counts)
   dfh_batch* next_b = nullptr;
@@ -136,6 +140,30 @@ struct dfh_shard {
   bool counts_ready = false;          // h_cnt holds the counts of counts_for; cnt_ev marks their arrival
   dfh_batch* counts_for = nullptr;
   hipEvent_t cnt_ev = nullptr;
+  // ---- overlapped exchange (dfh_shard_set_exchange(s, 1)): two minibatches in flight
+  int exchange = 0;                   // 0: sync (one minibatch at a time, zero staleness), 1: overlap (staleness <= 1)
+  hipStream_t cs = nullptr;           // the collectives' own stream (the sync step exchanges on the context's stream)
+  hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr}, ev_rw[2] = {nullptr, nullptr};
+  hipEvent_t ev_f = nullptr, ev_g = nullptr;
+  struct Flight {                     // one minibatch on its way through the stages
+    dfh_batch* b = nullptr;           // NULL: this rank has no minibatch in that step (it still serves its shard)
+    bool described = false;           // the counts exchange is through: the sizes below are valid
+    bool pulled = false;              // K, R, RW are queued: the other owners' rows are on their way to w_rows[slot]
+    bool have = false;
+    std::vector<size_t> send, recv, seg, off;
+    size_t nrecv = 0, U = 0, active = 0;
+    uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu;
+    bool any_own = false, any_remote = false;
+    int slot = 0;
+  } fl[2];
+  int cur = 0;                        // fl[cur]: the minibatch the next step trains; fl[cur ^ 1]: the one after
+  // ---- per-stage timing (dfh_shard_set_timing): counts, L, K, R, RW, F, G, P
+  bool timing = false;
+  struct Span { int id; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> ev_pool;
+  double stage_ms[DFH_SHARD_STAGES] = {0};
+  uint64_t stage_steps = 0;
 };
 
 namespace {
@@ -153,8 +181,8 @@ struct XPart {
 
 // alltoallv of device buffers; nparts parts would share ONE message group (callers pass one part: one send and
 // one receive per peer and group)
-int comm_exchange(dfh_comm* c, const XPart* parts, int nparts) {
-  hipStream_t s = c->ctx->stream;
+int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = nullptr) {
+  hipStream_t s = on ? on : c->ctx->stream;
   const int W = c->world;
   if (c->rccl) {
     RcclApi* a = rccl_api();
@@ -220,9 +248,9 @@ int comm_exchange(dfh_comm* c, const XPart* parts, int nparts) {
   return DFH_OK;
 }
 
-int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b) {
+int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b, hipStream_t on = nullptr) {
   XPart x{d_send, send_b, nullptr, d_recv, recv_b, nullptr};
-  return comm_exchange(c, &x, 1);
+  return comm_exchange(c, &x, 1, on);
 }
 
 template <typename T>
@@ -334,6 +362,59 @@ int dfh_comm_allreduce_sum(dfh_comm* c, double* vals, int n) {
   return DFH_OK;
 }
 
+int dfh_comm_allgather(dfh_comm* c, const void* send, size_t bytes, void* recv) {
+  DFH_ARG(c && send && recv && bytes >= 1 && bytes <= (1u << 24), "dfh_comm_allgather: 1 <= bytes <= 16 MiB of host memory");
+  dfh_ctx* ctx = c->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int W = c->world;
+  const size_t padded = (bytes + 15) & ~(size_t)15;
+  int rc = ensure_scratch(ctx, (size_t)(W + 1) * padded + 512);
+  if (rc) return rc;
+  Carver cv(ctx->scratch);
+  char* d_s = cv.take<char>(padded);
+  char* d_r = cv.take<char>((size_t)W * padded);
+  DFH_HIP(hipMemcpyAsync(d_s, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // the same bytes to every peer: W sends out of one buffer (offsets all zero), W receives side by side
+  std::vector<size_t> cnt(W, bytes), zero(W, 0), roff(W);
+  for (int p = 0; p < W; ++p) roff[p] = (size_t)p * padded;
+  XPart x{d_s, cnt.data(), zero.data(), d_r, cnt.data(), roff.data()};
+  rc = comm_exchange(c, &x, 1);
+  if (rc) return rc;
+  for (int p = 0; p < W; ++p)
+    DFH_HIP(hipMemcpyAsync(static_cast<char*>(recv) + (size_t)p * bytes, d_r + roff[p], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DFH_HIP(hipStreamSynchronize(ctx->stream));
+  return DFH_OK;
+}
+
+int dfh_shard_balanced_splits(dfh_comm* c, const uint64_t* sample_keys, size_t n, uint64_t* splits) {
+  DFH_ARG(c && splits && (n == 0 || sample_keys), "dfh_shard_balanced_splits: NULL argument");
+  const int W = c->world;
+  if (W == 1) return DFH_OK;
+  // a fixed-size message per rank: {count, keys[S]} — S evenly spaced keys of the rank's sorted sample
+  constexpr size_t S = 2048;
+  std::vector<uint64_t> mine(sample_keys, sample_keys + n);
+  std::sort(mine.begin(), mine.end());
+  std::vector<uint64_t> msg(1 + S, 0), all((size_t)W * (1 + S));
+  const size_t take = std::min(S, mine.size());
+  msg[0] = take;
+  for (size_t i = 0; i < take; ++i) msg[1 + i] = mine[(i * mine.size()) / take];
+  int rc = dfh_comm_allgather(c, msg.data(), msg.size() * sizeof(uint64_t), all.data());
+  if (rc) return rc;
+  std::vector<uint64_t> uni;
+  for (int p = 0; p < W; ++p) {
+    const uint64_t* m = &all[(size_t)p * (1 + S)];
+    DFH_ARG(m[0] <= S, "dfh_shard_balanced_splits: corrupt sample message");
+    uni.insert(uni.end(), m + 1, m + 1 + m[0]);
+  }
+  std::sort(uni.begin(), uni.end());
+  const uint64_t span = (~0ULL / (uint64_t)W) + 1;
+  for (int d = 1; d < W; ++d) {
+    // the first key of shard d: the d/W quantile of the union (ascending by construction); no sample at all: uniform
+    splits[d - 1] = uni.empty() ? (uint64_t)d * span : uni[((size_t)d * uni.size()) / W];
+  }
+  return DFH_OK;
+}
+
 int dfh_shard_create(dfh_table* t, dfh_comm* c, const uint64_t* splits, dfh_shard** out) {
   DFH_ARG(t && c && out && t->ctx == c->ctx, "dfh_shard_create: table and communicator must share a context");
   if (!(t->v.p.init_mode == DFH_INIT_HASH || t->v.k == 0)) {
@@ -348,6 +429,10 @@ int dfh_shard_create(dfh_table* t, dfh_comm* c, const uint64_t* splits, dfh_shar
   s->t = t;
   s->c = c;
   hipStream_t st = t->ctx->stream;
+  {
+    const uint64_t span = W == 1 ? ~0ULL : (~0ULL / (uint64_t)W) + 1;
+    for (int d = 1; d < W; ++d) s->h_splits.push_back(splits ? splits[d - 1] : (uint64_t)d * span);
+  }
   if (splits && W > 1) {
     DFH_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_splits), (W - 1) * sizeof(uint64_t)));
     DFH_HIP(hipMemcpyAsync(s->d_splits, splits, (W - 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -365,11 +450,20 @@ int dfh_shard_destroy(dfh_shard* s) {
   if (!s) return DFH_OK;
   hipSetDevice(s->t->ctx->device);
   sync_all(s->t->ctx);
-  void* ptrs[] = {s->d_splits, s->d_bounds, s->d_cnt, s->r_keys, s->r_cnt, s->r_rowid, s->r_rows, s->w_rows, s->w_grads};
+  void* ptrs[] = {s->d_splits, s->d_bounds, s->d_cnt, s->r_keys[0], s->r_cnt[0], s->r_rowid[0], s->r_rows[0], s->w_rows[0], s->w_grads[0], s->w_grads[1],
+                  s->r_keys[1], s->r_cnt[1], s->r_rowid[1], s->r_rows[1], s->w_rows[1]};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (s->h_cnt) hipHostFree(s->h_cnt);
   if (s->cnt_ev) hipEventDestroy(s->cnt_ev);
+  for (hipEvent_t e : {s->ev_k[0], s->ev_k[1], s->ev_r[0], s->ev_r[1], s->ev_rw[0], s->ev_rw[1], s->ev_f, s->ev_g})
+    if (e) hipEventDestroy(e);
+  for (auto& sp : s->spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
+  if (s->cs) hipStreamDestroy(s->cs);
   delete s;
   return DFH_OK;
 }
@@ -388,9 +482,9 @@ int dfh_shard_owned_range(dfh_shard* s, const uint64_t* splits, uint64_t* key_lo
 namespace {
 // queue, on the main stream: owner ranges of b's keys -> {keys for every owner, "I have a minibatch"} ->
 // every peer -> pinned host memory
-int queue_counts(dfh_shard* s, dfh_batch* b) {
+int queue_counts(dfh_shard* s, dfh_batch* b, hipStream_t on = nullptr) {
   dfh_comm* c = s->c;
-  hipStream_t st = c->ctx->stream;
+  hipStream_t st = on ? on : c->ctx->stream;
   const int W = c->world;
   const bool have = b != nullptr && b->nnz > 0;
   if (have) {
@@ -402,11 +496,178 @@ int queue_counts(dfh_shard* s, dfh_batch* b) {
                      (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
   DFH_HIP(hipGetLastError());
   std::vector<size_t> cb(W, 2 * sizeof(int64_t));
-  int rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data());
+  int rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data(), st);
   if (rc) return rc;
   DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   return DFH_OK;
 }
+
+// brackets one stage of a step with two events on `st` when per-stage timing is on
+struct StageScope {
+  dfh_shard* s;
+  int id;
+  hipStream_t st;
+  hipEvent_t a = nullptr, b = nullptr;
+  static hipEvent_t get(dfh_shard* s) {
+    if (!s->ev_pool.empty()) {
+      hipEvent_t e = s->ev_pool.back();
+      s->ev_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+  }
+  StageScope(dfh_shard* sh, int stage, hipStream_t stream) : s(sh), id(stage), st(stream) {
+    if (!s->timing) return;
+    a = get(s);
+    b = get(s);
+    if (a && b) (void)hipEventRecord(a, st);
+  }
+  ~StageScope() {
+    if (!a || !b) return;
+    (void)hipEventRecord(b, st);
+    s->spans.push_back({id, a, b});
+  }
+};
+
+// sizes of a minibatch's exchange from the counts that have arrived in h_cnt
+void flight_sizes(dfh_shard* s, dfh_shard::Flight& f, dfh_batch* b, int slot) {
+  const int W = s->c->world, me = s->c->rank;
+  f.b = b;
+  f.have = b != nullptr && b->nnz > 0;
+  f.send.assign(W, 0);
+  f.recv.assign(W, 0);
+  f.seg.assign(W + 1, 0);
+  f.off.assign(W + 1, 0);
+  f.active = 0;
+  for (int p = 0; p < W; ++p) {
+    f.send[p] = (size_t)s->h_cnt[2 * p];
+    f.recv[p] = (size_t)s->h_cnt[2 * W + 2 * p];
+    f.active += s->h_cnt[2 * W + 2 * p + 1] != 0 ? 1 : 0;
+    f.off[p + 1] = f.off[p] + f.send[p];  // owner p's keys are ranks [off[p], off[p+1]) of the minibatch's key list
+  }
+  f.own_lo = (uint32_t)f.off[me];
+  f.own_hi = (uint32_t)f.off[me + 1];
+  f.send[me] = f.recv[me] = 0;  // the rank's own keys are not exchanged
+  f.nrecv = 0;
+  for (int p = 0; p < W; ++p) {
+    f.nrecv += f.recv[p];
+    f.seg[p + 1] = f.seg[p] + f.recv[p];
+  }
+  f.U = f.off[W];
+  f.any_own = f.have && f.own_hi > f.own_lo;
+  f.any_remote = f.have && (f.own_lo > 0 || (size_t)f.own_hi < f.U);
+  f.described = true;
+  f.pulled = false;
+  f.slot = slot;
+}
+
+// the exchange buffers of a flight's slot (growing one waits for everything queued: rare)
+int flight_bufs(dfh_shard* s, const dfh_shard::Flight& f, size_t stride) {
+  const int q = f.slot;
+  int rc;
+  hipStream_t st = s->t->ctx->stream;
+  if (f.nrecv > s->r_cap[q] || (f.any_remote && (f.U > s->w_cap[q] || f.U > s->g_cap[q]))) {
+    if (s->cs) DFH_HIP(hipStreamSynchronize(s->cs));
+    rc = sync_all(s->t->ctx);
+    if (rc) return rc;
+  }
+  if (f.nrecv > s->r_cap[q]) {
+    const size_t cap = f.nrecv + f.nrecv / 2 + 1024;
+    if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) || (rc = grow(&s->r_rowid[q], cap, st)) ||
+        (rc = grow(&s->r_rows[q], cap * stride, st)))
+      return rc;
+    s->r_cap[q] = cap;
+  }
+  if (f.any_remote && f.U > s->w_cap[q]) {
+    const size_t cap = f.U + f.U / 2 + 1024;
+    if ((rc = grow(&s->w_rows[q], cap * stride, st))) return rc;
+    s->w_cap[q] = cap;
+  }
+  if (f.any_remote && f.U > s->g_cap[q]) {
+    const size_t cap = f.U + f.U / 2 + 1024;
+    if ((rc = grow(&s->w_grads[q], cap * stride, st))) return rc;
+    s->g_cap[q] = cap;
+  }
+  return DFH_OK;
+}
+
+void flight_bytes(const dfh_shard::Flight& f, int W, size_t unit, std::vector<size_t>& sb, std::vector<size_t>& rb, std::vector<size_t>& so) {
+  sb.resize(W);
+  rb.resize(W);
+  so.resize(W);
+  for (int p = 0; p < W; ++p) {
+    sb[p] = f.send[p] * unit;
+    rb[p] = f.recv[p] * unit;
+    so[p] = f.off[p] * unit;  // worker-side buffers are indexed by the key's rank u: owner p's slice starts at off[p]
+  }
+}
+
+// K on the collectives' stream: the keys other ranks own (+ their epoch-0 counts) to their owners
+int flight_K(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
+  dfh_comm* c = s->c;
+  const int W = c->world;
+  dfh_batch* b = f.b;
+  StageScope ts(s, DFH_SHARD_STAGE_K, s->cs);
+  if (b && b->ready_pending) DFH_HIP(hipStreamWaitEvent(s->cs, b->ev_ready, 0));  // its Localizer (preparation stream)
+  std::vector<size_t> sb, rb, so;
+  flight_bytes(f, W, sizeof(uint64_t), sb, rb, so);
+  XPart xk{f.have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys[f.slot], rb.data(), nullptr};
+  int rc = comm_exchange(c, &xk, 1, s->cs);
+  if (rc) return rc;
+  if (push_cnt) {
+    if (f.have && !b->has_cnt) {
+      hipLaunchKernelGGL(k_loc_counts, dim3(grid_for_threads(b->nnz, c->ctx)), dim3(256), 0, s->cs, b->d_col_ptr, b->d_U, b->d_feacnt);
+      DFH_HIP(hipGetLastError());
+      b->has_cnt = true;
+    }
+    flight_bytes(f, W, sizeof(float), sb, rb, so);
+    XPart xc{f.have ? b->d_feacnt : nullptr, sb.data(), so.data(), s->r_cnt[f.slot], rb.data(), nullptr};
+    rc = comm_exchange(c, &xc, 1, s->cs);
+    if (rc) return rc;
+  }
+  DFH_HIP(hipEventRecord(s->ev_k[f.slot], s->cs));
+  return DFH_OK;
+}
+
+// R on the main stream (owners resolve the received keys once, count-push, pull), RW on the collectives' stream
+int flight_R_RW(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
+  dfh_comm* c = s->c;
+  dfh_table* t = s->t;
+  const int W = c->world, q = f.slot;
+  hipStream_t st = t->ctx->stream;
+  const size_t stride = dfh_row_stride(t->v.k);
+  int rc;
+  {
+    StageScope ts(s, DFH_SHARD_STAGE_R, st);
+    DFH_HIP(hipStreamWaitEvent(st, s->ev_k[q], 0));
+    if (f.nrecv) {
+      rc = dfh_shard_resolve_multi(t, s->r_keys[q], f.seg.data(), W, q, s->r_rowid[q]);
+      if (rc) return rc;
+      if (push_cnt) {
+        rc = dfh_shard_push_count_multi(t, s->r_rowid[q], s->r_keys[q], f.seg.data(), W, q, s->r_cnt[q]);
+        if (rc) return rc;
+      }
+      rc = dfh_shard_pull_resolved(t, s->r_rowid[q], f.nrecv, s->r_rows[q]);
+      if (rc) return rc;
+    }
+    DFH_HIP(hipEventRecord(s->ev_r[q], st));
+  }
+  {
+    StageScope ts(s, DFH_SHARD_STAGE_RW, s->cs);
+    DFH_HIP(hipStreamWaitEvent(s->cs, s->ev_r[q], 0));
+    std::vector<size_t> sb, rb, so;
+    flight_bytes(f, W, stride * sizeof(float), sb, rb, so);
+    XPart x{s->r_rows[q], rb.data(), nullptr, s->w_rows[q], sb.data(), so.data()};
+    rc = comm_exchange(c, &x, 1, s->cs);
+    if (rc) return rc;
+    DFH_HIP(hipEventRecord(s->ev_rw[q], s->cs));
+  }
+  f.pulled = true;
+  return DFH_OK;
+}
+
+int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* any_active);
 }  // namespace
 
 extern "C" {
@@ -423,6 +684,60 @@ int dfh_shard_prefetch_counts(dfh_shard* s, dfh_batch* b_next) {
   return DFH_OK;
 }
 
+int dfh_shard_set_exchange(dfh_shard* s, int mode) {
+  DFH_ARG(s && (mode == 0 || mode == 1), "dfh_shard_set_exchange: mode 0 (sync) or 1 (overlap)");
+  if (s->fl[0].pulled || s->fl[1].pulled || s->counts_ready) {
+    set_error("dfh_shard_set_exchange: a minibatch is under way (call it between epochs)");
+    return DFH_ERR_STATE;
+  }
+  dfh_ctx* ctx = s->t->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  int rc = sync_all(ctx);
+  if (rc) return rc;
+  if (mode == 1 && !s->cs) {
+    DFH_HIP(hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking));
+    // these events order two streams of ONE device: no system-scope fence at the record
+    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+    for (hipEvent_t* e : {&s->ev_k[0], &s->ev_k[1], &s->ev_r[0], &s->ev_r[1], &s->ev_rw[0], &s->ev_rw[1], &s->ev_f, &s->ev_g})
+      DFH_HIP(hipEventCreateWithFlags(e, evf));
+  }
+  if (s->cs) DFH_HIP(hipStreamSynchronize(s->cs));
+  s->exchange = mode;
+  s->fl[0] = dfh_shard::Flight();
+  s->fl[1] = dfh_shard::Flight();
+  s->cur = 0;
+  s->next_armed = false;
+  return DFH_OK;
+}
+
+int dfh_shard_set_timing(dfh_shard* s, int enable) {
+  DFH_ARG(s, "dfh_shard_set_timing: NULL shard");
+  s->timing = enable != 0;
+  return DFH_OK;
+}
+
+int dfh_shard_get_timing(dfh_shard* s, int reset, double* ms, uint64_t* steps) {
+  DFH_ARG(s && ms, "dfh_shard_get_timing: NULL argument");
+  DFH_HIP(hipSetDevice(s->t->ctx->device));
+  if (s->cs) DFH_HIP(hipStreamSynchronize(s->cs));
+  int rc = sync_all(s->t->ctx);
+  if (rc) return rc;
+  for (auto& sp : s->spans) {
+    float e = 0;
+    if (hipEventElapsedTime(&e, sp.a, sp.b) == hipSuccess) s->stage_ms[sp.id] += e;
+    s->ev_pool.push_back(sp.a);
+    s->ev_pool.push_back(sp.b);
+  }
+  s->spans.clear();
+  for (int i = 0; i < DFH_SHARD_STAGES; ++i) {
+    ms[i] = s->stage_ms[i];
+    if (reset) s->stage_ms[i] = 0;
+  }
+  if (steps) *steps = s->stage_steps;
+  if (reset) s->stage_steps = 0;
+  return DFH_OK;
+}
+
 int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* any_active) {
   DFH_ARG(s, "dfh_shard_step: NULL shard");
   dfh_table* t = s->t;
@@ -436,6 +751,8 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   if (is_train) {
     if (int rca = require_aux(t, "dfh_shard_step(is_train)")) return rca;
   }
+  if (s->exchange == 1 && c->world > 1) return shard_step_overlap(s, b, is_train, push_cnt, any_active);
+  if (s->timing) ++s->stage_steps;
   DFH_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int W = c->world, me = c->rank;
@@ -458,8 +775,11 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       DFH_HIP(hipEventSynchronize(s->cnt_ev));
     } else {
       DFH_ARG(!s->counts_ready, "dfh_shard_step: the batch differs from the one announced to dfh_shard_prefetch_counts");
-      rc = queue_counts(s, b);
-      if (rc) return rc;
+      {
+        StageScope ts(s, DFH_SHARD_STAGE_COUNTS, st);
+        rc = queue_counts(s, b);
+        if (rc) return rc;
+      }
       DFH_HIP(hipStreamSynchronize(st));
     }
     s->counts_ready = false;
@@ -489,17 +809,22 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     return b ? main_end(b) : DFH_OK;
   }
   // ---- buffers
-  if (nrecv > s->r_cap) {
+  if (nrecv > s->r_cap[0]) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys, cap, st)) || (rc = grow(&s->r_cnt, cap, st)) || (rc = grow(&s->r_rowid, cap, st)) ||
-        (rc = grow(&s->r_rows, cap * stride, st)))
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], cap, st)) ||
+        (rc = grow(&s->r_rows[0], cap * stride, st)))
       return rc;
-    s->r_cap = cap;
+    s->r_cap[0] = cap;
   }
-  if (any_remote && U > s->w_cap) {
+  if (any_remote && U > s->w_cap[0]) {
     const size_t cap = U + U / 2 + 1024;
-    if ((rc = grow(&s->w_rows, cap * stride, st)) || (rc = grow(&s->w_grads, cap * stride, st))) return rc;
-    s->w_cap = cap;
+    if ((rc = grow(&s->w_rows[0], cap * stride, st))) return rc;
+    s->w_cap[0] = cap;
+  }
+  if (any_remote && U > s->g_cap[0]) {
+    const size_t cap = U + U / 2 + 1024;
+    if ((rc = grow(&s->w_grads[0], cap * stride, st))) return rc;
+    s->g_cap[0] = cap;
   }
   std::vector<size_t> sb(W), rb(W), so(W), sb2(W), rb2(W), so2(W);
   auto bytes = [&](size_t unit, std::vector<size_t>& sbv, std::vector<size_t>& rbv, std::vector<size_t>& sov) {
@@ -512,6 +837,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   const uint32_t n_own = own_hi - own_lo;  // meaningless for W == 1 (the kernels clamp to *d_U)
   // ---- L: this rank's own keys: rows + Push(kFeaCount) on its own table, {row, w} per key for the forward
   if (any_own) {
+    StageScope ts(s, DFH_SHARD_STAGE_L, st);
     const bool counts = push_cnt != 0;
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
                        W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
@@ -522,8 +848,9 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   // ---- K: the other keys (+ counts in epoch 0) to their owners.  Two message groups, one send and one receive
   // per peer each — the pattern every RCCL release serves (several sends to one peer inside a group are not)
   if (W > 1) {
+    StageScope ts(s, DFH_SHARD_STAGE_K, st);
     bytes(sizeof(uint64_t), sb, rb, so);
-    XPart xk{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys, rb.data(), nullptr};
+    XPart xk{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys[0], rb.data(), nullptr};
     rc = comm_exchange(c, &xk, 1);
     if (rc) return rc;
     if (push_cnt) {
@@ -533,41 +860,44 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
         b->has_cnt = true;
       }
       bytes(sizeof(float), sb2, rb2, so2);
-      XPart xc{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt, rb2.data(), nullptr};
+      XPart xc{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt[0], rb2.data(), nullptr};
       rc = comm_exchange(c, &xc, 1);
       if (rc) return rc;
     }
   }
   // ---- R: owners resolve once, count-push, pull (every source reads the same model version)
   if (nrecv) {
-    rc = dfh_shard_resolve_multi(t, s->r_keys, seg.data(), W, 0, s->r_rowid);
+    StageScope ts(s, DFH_SHARD_STAGE_R, st);
+    rc = dfh_shard_resolve_multi(t, s->r_keys[0], seg.data(), W, 0, s->r_rowid[0]);
     if (rc) return rc;
     if (push_cnt) {
-      rc = dfh_shard_push_count_multi(t, s->r_rowid, s->r_keys, seg.data(), W, 0, s->r_cnt);
+      rc = dfh_shard_push_count_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_cnt[0]);
       if (rc) return rc;
     }
-    rc = dfh_shard_pull_resolved(t, s->r_rowid, nrecv, s->r_rows);
+    rc = dfh_shard_pull_resolved(t, s->r_rowid[0], nrecv, s->r_rows[0]);
     if (rc) return rc;
   }
   // ---- RW: rows back to the workers, each owner's slice to its place among the minibatch's keys
   if (W > 1) {
+    StageScope ts(s, DFH_SHARD_STAGE_RW, st);
     bytes(stride * sizeof(float), sb, rb, so);
-    XPart x{s->r_rows, rb.data(), nullptr, s->w_rows, sb.data(), so.data()};
+    XPart x{s->r_rows[0], rb.data(), nullptr, s->w_rows[0], sb.data(), so.data()};
     rc = comm_exchange(c, &x, 1);
     if (rc) return rc;
   }
   // ---- F: the worker's math: own keys on the table, the others on the pulled rows
   const KeyRange own{own_lo, own_hi, 0u}, others{own_lo, own_hi, 1u};
   if (b) {
+    StageScope ts(s, DFH_SHARD_STAGE_F, st);
     rc = ensure_xv(b, kp);
     if (rc) return rc;
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (any_remote) {
-      hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(U, ctx)), dim3(256), 0, st, s->w_rows, stride, b->d_U, own_lo, own_hi,
+      hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(U, ctx)), dim3(256), 0, st, s->w_rows[0], stride, b->d_U, own_lo, own_hi,
                          b->d_uw);
       DFH_HIP(hipGetLastError());
     }
-    MixSrc mix{any_remote ? s->w_rows + 4 : nullptr, stride};
+    MixSrc mix{any_remote ? s->w_rows[0] + 4 : nullptr, stride};
     rc = launch_forward(b, tsrc, k, kp, b->d_uw, W > 1 ? &mix : nullptr);
     if (rc) return rc;
     if (b->compute_auc) {
@@ -577,12 +907,12 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     BatchView bv = batch_view(b);
     const int pgrid = have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
     if (any_remote) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
-      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows, k), t->v, k, kp, others);
+      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows[0], k), t->v, k, kp, others);
       DFH_HIP(hipGetLastError());
     }
     if (is_train && any_remote) {
       TableView dummy{};
-      rc = launch_backward<false>(b, packed_src(s->w_rows, k), dummy, s->w_grads, stride, k, kp, nullptr, others);
+      rc = launch_backward<false>(b, packed_src(s->w_rows[0], k), dummy, s->w_grads[0], stride, k, kp, nullptr, others);
       if (rc) return rc;
     }
     if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
@@ -611,18 +941,417 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   // ---- G + P: gradients to the owners, applied source rank after source rank
   if (is_train && W > 1) {
     bytes(stride * sizeof(float), sb, rb, so);
-    XPart x{s->w_grads, sb.data(), so.data(), s->r_rows, rb.data(), nullptr};
-    rc = comm_exchange(c, &x, 1);
-    if (rc) return rc;
+    XPart x{s->w_grads[0], sb.data(), so.data(), s->r_rows[0], rb.data(), nullptr};
+    {
+      StageScope ts(s, DFH_SHARD_STAGE_G, st);
+      rc = comm_exchange(c, &x, 1);
+      if (rc) return rc;
+    }
     if (nrecv) {
-      rc = dfh_shard_push_grad_multi(t, s->r_rowid, s->r_keys, seg.data(), W, 0, s->r_rows);
+      StageScope ts(s, DFH_SHARD_STAGE_P, st);
+      rc = dfh_shard_push_grad_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_rows[0]);
       if (rc) return rc;
     }
   } else if (nrecv) {
-    rc = dfh_shard_release(t, s->r_rowid, nrecv, 0);
+    rc = dfh_shard_release(t, s->r_rowid[0], nrecv, 0);
     if (rc) return rc;
   }
   return b ? main_end(b) : DFH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// ---- dfh_shard_step with two minibatches in flight (dfh_shard_set_exchange(s, 1)); world > 1.
+// cur = the minibatch this call trains.  If it was announced to the previous call (dfh_shard_prefetch_counts) its
+// counts, keys and rows were exchanged in there; otherwise (first step of an epoch) they are exchanged now.
+int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* any_active) {
+  dfh_table* t = s->t;
+  dfh_comm* c = s->c;
+  dfh_ctx* ctx = t->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream, cs = s->cs;
+  const int W = c->world;
+  const int k = t->v.k, kp = t->v.kp;
+  const size_t stride = dfh_row_stride(k);
+  int rc;
+  if (s->timing) ++s->stage_steps;
+  static const bool trace = getenv("DFH_SHARD_TRACE") != nullptr;
+  dfh_shard::Flight& cur = s->fl[s->cur];
+  if (trace)
+    fprintf(stderr, "[shard %d] step %llu: b=%p cur{slot %d described %d pulled %d b=%p} armed %d next_b=%p\n", c->rank,
+            (unsigned long long)s->steps, (void*)b, s->cur, (int)cur.described, (int)cur.pulled, (void*)cur.b, (int)s->next_armed,
+            (void*)s->next_b);
+  if (!(cur.described && cur.b == b)) {
+    // not announced: describe it now (its counts over the collectives' stream, one host wait)
+    DFH_ARG(!cur.described || !cur.pulled, "dfh_shard_step: the batch differs from the one announced to dfh_shard_prefetch_counts");
+    if (b && b->ready_pending) DFH_HIP(hipStreamWaitEvent(cs, b->ev_ready, 0));
+    {
+      StageScope ts(s, DFH_SHARD_STAGE_COUNTS, cs);
+      rc = queue_counts(s, b, cs);
+      if (rc) return rc;
+    }
+    DFH_HIP(hipStreamSynchronize(cs));
+    flight_sizes(s, cur, b, s->cur);
+  }
+  if (any_active) *any_active = cur.active != 0 ? 1 : 0;
+  ++s->steps;
+  if (b) b->nrows_seen += (float)b->nrows;
+  // the minibatch after this one, if the caller named it
+  const bool look = s->next_armed;
+  dfh_batch* nb = look ? s->next_b : nullptr;
+  s->next_armed = false;
+  dfh_shard::Flight& nxt = s->fl[s->cur ^ 1];
+  nxt = dfh_shard::Flight();
+  if (cur.active == 0) {
+    // nobody has a minibatch: the epoch is over (nothing can have been announced behind it)
+    cur = dfh_shard::Flight();
+    return b ? main_end(b) : DFH_OK;
+  }
+  rc = flight_bufs(s, cur, stride);
+  if (rc) return rc;
+  if (b) {
+    rc = main_begin(b);  // its Localizer (preparation stream) -> main stream
+    if (rc) return rc;
+  }
+  // ---- L: this rank's own keys: rows + Push(kFeaCount) on its own table, {row, w} per key for the forward.  Runs
+  // after everything the previous step applied: own keys are read with zero staleness.
+  const uint32_t n_own = cur.own_hi - cur.own_lo;
+  if (cur.any_own) {
+    StageScope ts(s, DFH_SHARD_STAGE_L, st);
+    const bool counts = push_cnt != 0;
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
+                       (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo,
+                       (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr, b->d_col_ptr + cur.own_lo,
+                       counts ? 1 : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo);
+    DFH_HIP(hipGetLastError());
+  }
+  if (!cur.pulled) {  // pipeline fill: K, R, RW of this very minibatch, in the sync step's order (after L)
+    rc = flight_K(s, cur, push_cnt);
+    if (rc) return rc;
+    rc = flight_R_RW(s, cur, push_cnt);
+    if (rc) return rc;
+  }
+  // ---- counts of the next minibatch: on their way while F is queued and runs
+  if (look) {
+    if (nb && nb->ready_pending) DFH_HIP(hipStreamWaitEvent(cs, nb->ev_ready, 0));
+    StageScope ts(s, DFH_SHARD_STAGE_COUNTS, cs);
+    rc = queue_counts(s, nb, cs);
+    if (rc) return rc;
+    DFH_HIP(hipEventRecord(s->cnt_ev, cs));
+  }
+  // ---- F: the worker's math: own keys on the table, the others on the pulled rows
+  const KeyRange own{cur.own_lo, cur.own_hi, 0u}, others{cur.own_lo, cur.own_hi, 1u};
+  const int q = cur.slot;
+  if (b) {
+    StageScope ts(s, DFH_SHARD_STAGE_F, st);
+    rc = ensure_xv(b, kp);
+    if (rc) return rc;
+    DFH_HIP(hipStreamWaitEvent(st, s->ev_rw[q], 0));  // the rows of the other owners have arrived
+    const RowSrc tsrc = table_src(t, b->d_urow);
+    if (cur.any_remote) {
+      hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, s->w_rows[q], stride, b->d_U, cur.own_lo,
+                         cur.own_hi, b->d_uw);
+      DFH_HIP(hipGetLastError());
+    }
+    MixSrc mix{cur.any_remote ? s->w_rows[q] + 4 : nullptr, stride};
+    rc = launch_forward(b, tsrc, k, kp, b->d_uw, &mix);
+    if (rc) return rc;
+    if (b->compute_auc) {
+      rc = launch_auc(b);
+      if (rc) return rc;
+    }
+    BatchView bv = batch_view(b);
+    const int pgrid = cur.have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
+    if (cur.any_remote) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
+      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows[q], k), t->v, k, kp, others);
+      DFH_HIP(hipGetLastError());
+    }
+    if (is_train && cur.any_remote) {
+      TableView dummy{};
+      rc = launch_backward<false>(b, packed_src(s->w_rows[q], k), dummy, s->w_grads[q], stride, k, kp, nullptr, others);
+      if (rc) return rc;
+    }
+  }
+  if (is_train) DFH_HIP(hipEventRecord(s->ev_f, st));  // the gradient rows are complete: G may start ...
+  if (b) {  // ... while the own keys are updated in place
+    StageScope ts(s, DFH_SHARD_STAGE_F, st);
+    const RowSrc tsrc = table_src(t, b->d_urow);
+    if (is_train && cur.any_own) {  // the fused in-place update accumulates the own keys' penalty itself
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw);
+      if (rc) return rc;
+    } else if (cur.any_own) {
+      BatchView bv = batch_view(b);
+      const int pgrid = cur.have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
+      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
+      DFH_HIP(hipGetLastError());
+    }
+  }
+  // ---- the next minibatch's sizes (the one host wait; the device is busy with F), then its keys
+  bool ahead = false;
+  if (look) {
+    DFH_HIP(hipEventSynchronize(s->cnt_ev));
+    flight_sizes(s, nxt, nb, s->cur ^ 1);
+    ahead = nxt.active != 0;
+    if (trace)
+      fprintf(stderr, "[shard %d]   next: active %zu U %zu nrecv %zu own [%u, %u) -> ahead %d\n", c->rank, nxt.active, nxt.U, nxt.nrecv,
+              nxt.own_lo, nxt.own_hi, (int)ahead);
+    if (ahead) {
+      rc = flight_bufs(s, nxt, stride);
+      if (rc) return rc;
+      rc = flight_K(s, nxt, push_cnt);  // small; travels while F computes
+      if (rc) return rc;
+    }
+  }
+  // ---- G: gradient rows to the owners (into the buffer their rows came from)
+  std::vector<size_t> sb, rb, so;
+  if (is_train) {
+    StageScope ts(s, DFH_SHARD_STAGE_G, cs);
+    DFH_HIP(hipStreamWaitEvent(cs, s->ev_f, 0));
+    flight_bytes(cur, W, stride * sizeof(float), sb, rb, so);
+    XPart x{s->w_grads[q], sb.data(), so.data(), s->r_rows[q], rb.data(), nullptr};
+    rc = comm_exchange(c, &x, 1, cs);
+    if (rc) return rc;
+    DFH_HIP(hipEventRecord(s->ev_g, cs));
+  }
+  // ---- R, RW of the next minibatch: the owners pull while this step's gradients travel — before they are applied
+  // (staleness 1 for the rows of other owners) — and the rows travel while they are applied
+  if (ahead) {
+    rc = flight_R_RW(s, nxt, push_cnt);
+    if (rc) return rc;
+  }
+  // ---- P: the other sources' gradients, applied source rank after source rank
+  if (is_train) {
+    StageScope ts(s, DFH_SHARD_STAGE_P, st);
+    DFH_HIP(hipStreamWaitEvent(st, s->ev_g, 0));
+    if (cur.nrecv) {
+      rc = dfh_shard_push_grad_multi(t, s->r_rowid[q], s->r_keys[q], cur.seg.data(), W, q, s->r_rows[q]);
+      if (rc) return rc;
+    }
+  } else if (cur.nrecv) {
+    rc = dfh_shard_release(t, s->r_rowid[q], cur.nrecv, q);
+    if (rc) return rc;
+  }
+  cur = dfh_shard::Flight();
+  if (look) s->cur ^= 1;  // the announced minibatch (described, maybe pulled) is the next call's
+  return b ? main_end(b) : DFH_OK;
+}
+}  // namespace
+
+namespace {
+// ---- the literal, call-by-call Store::Pull / Push on the sharded model (dfh_shard_pull_host / dfh_shard_push_host)
+struct HostCall {
+  std::vector<size_t> send, recv, seg, soff;  // keys per owner / per source, prefix sums
+  size_t nrecv = 0;
+};
+
+// who owns what of `keys` (ascending), and how much every rank sends this one: the W x W count matrix is gathered
+int host_call_sizes(dfh_shard* s, const uint64_t* keys, size_t n, HostCall* h) {
+  dfh_comm* c = s->c;
+  const int W = c->world, me = c->rank;
+  for (size_t i = 1; i < n; ++i) DFH_ARG(keys[i] > keys[i - 1], "keys must be strictly ascending (a Localizer's output)");
+  h->send.assign(W, 0);
+  h->soff.assign(W + 1, 0);
+  for (int p = 0; p < W; ++p) {
+    const uint64_t* e = p + 1 < W ? std::lower_bound(keys, keys + n, s->h_splits[p]) : keys + n;
+    h->soff[p + 1] = (size_t)(e - keys);
+    h->send[p] = h->soff[p + 1] - h->soff[p];
+  }
+  std::vector<uint64_t> mine(h->send.begin(), h->send.end()), all((size_t)W * W);
+  int rc = dfh_comm_allgather(c, mine.data(), (size_t)W * sizeof(uint64_t), all.data());
+  if (rc) return rc;
+  h->recv.assign(W, 0);
+  h->seg.assign(W + 1, 0);
+  for (int p = 0; p < W; ++p) {
+    h->recv[p] = (size_t)all[(size_t)p * W + me];
+    h->seg[p + 1] = h->seg[p] + h->recv[p];
+  }
+  h->nrecv = h->seg[W];
+  return DFH_OK;
+}
+
+int host_call_bufs(dfh_shard* s, size_t nrecv, size_t n, size_t stride) {
+  hipStream_t st = s->t->ctx->stream;
+  int rc;
+  if (nrecv > s->r_cap[0]) {
+    const size_t cap = nrecv + nrecv / 2 + 1024;
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], cap, st)) ||
+        (rc = grow(&s->r_rows[0], cap * stride, st)))
+      return rc;
+    s->r_cap[0] = cap;
+  }
+  if (n > s->w_cap[0]) {
+    const size_t cap = n + n / 2 + 1024;
+    if ((rc = grow(&s->w_rows[0], cap * stride, st))) return rc;
+    s->w_cap[0] = cap;
+  }
+  return DFH_OK;
+}
+
+void bytes_of(const HostCall& h, int W, size_t unit, std::vector<size_t>& sb, std::vector<size_t>& rb) {
+  sb.resize(W);
+  rb.resize(W);
+  for (int p = 0; p < W; ++p) {
+    sb[p] = h.send[p] * unit;
+    rb[p] = h.recv[p] * unit;
+  }
+}
+
+int host_call_guard(dfh_shard* s, const char* who) {
+  if (s->fl[0].pulled || s->fl[1].pulled || s->counts_ready) {
+    set_error(std::string(who) + ": a minibatch of dfh_shard_step is under way");
+    return DFH_ERR_STATE;
+  }
+  return DFH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dfh_shard_pull_host(dfh_shard* s, const uint64_t* keys, size_t n, float* vals, size_t* nvals, int* lens, size_t* nlens) {
+  DFH_ARG(s && nvals && nlens && (n == 0 || (keys && vals && lens)), "dfh_shard_pull_host: NULL argument");
+  if (int g = host_call_guard(s, "dfh_shard_pull_host")) return g;
+  dfh_table* t = s->t;
+  dfh_comm* c = s->c;
+  dfh_ctx* ctx = t->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int W = c->world, k = t->v.k;
+  const size_t stride = dfh_row_stride(k);
+  *nvals = 0;
+  *nlens = k == 0 ? 0 : n;  // sgd_updater.cc:40
+  if (int rck = check_keys(keys, n)) return rck;
+  HostCall h;
+  int rc = host_call_sizes(s, keys, n, &h);
+  if (rc) return rc;
+  rc = host_call_bufs(s, h.nrecv, n, stride);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, padded<uint64_t>(std::max<size_t>(n, 1)));
+  if (rc) return rc;
+  uint64_t* d_keys = static_cast<uint64_t*>(ctx->scratch);
+  if (n) DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  std::vector<size_t> sb, rb;
+  bytes_of(h, W, sizeof(uint64_t), sb, rb);
+  XPart xk{d_keys, sb.data(), nullptr, s->r_keys[0], rb.data(), nullptr};
+  rc = comm_exchange(c, &xk, 1);
+  if (rc) return rc;
+  if (h.nrecv) {  // owners: SGDUpdater::Get for every requester (sgd_updater.cc:32-56)
+    rc = dfh_shard_resolve(t, s->r_keys[0], h.nrecv, s->r_rowid[0]);
+    if (rc) return rc;
+    rc = dfh_shard_pull_resolved(t, s->r_rowid[0], h.nrecv, s->r_rows[0]);
+    if (rc) return rc;
+  }
+  bytes_of(h, W, stride * sizeof(float), sb, rb);
+  XPart xr{s->r_rows[0], rb.data(), nullptr, s->w_rows[0], sb.data(), nullptr};
+  rc = comm_exchange(c, &xr, 1);
+  if (rc) return rc;
+  std::vector<float> rows(std::max<size_t>(n, 1) * stride);
+  if (n) DFH_HIP(hipMemcpyAsync(rows.data(), s->w_rows[0], n * stride * sizeof(float), hipMemcpyDeviceToHost, st));
+  DFH_HIP(hipStreamSynchronize(st));
+  rc = check_table_err(t);
+  if (rc) return rc;
+  size_t p = 0;
+  for (size_t i = 0; i < n; ++i) {  // ragged layout of SGDUpdater::Get (sgd_updater.cc:46-53)
+    const float* r = rows.data() + i * stride;
+    vals[p++] = r[0];
+    if (r[1] != 0.0f) {
+      memcpy(vals + p, r + 4, sizeof(float) * (size_t)k);
+      p += (size_t)k;
+      lens[i] = k + 1;
+    } else if (k != 0) {
+      lens[i] = 1;
+    }
+  }
+  *nvals = p;
+  return DFH_OK;
+}
+
+int dfh_shard_push_host(dfh_shard* s, const uint64_t* keys, size_t n, int val_type, const float* vals, size_t nvals, const int* lens,
+                        size_t nlens) {
+  DFH_ARG(s && (n == 0 || (keys && vals)), "dfh_shard_push_host: NULL argument");
+  DFH_ARG(val_type == DFH_FEA_COUNT || val_type == DFH_GRADIENT, "dfh_shard_push_host: unknown val_type (sgd_updater.cc:99)");
+  if (int g = host_call_guard(s, "dfh_shard_push_host")) return g;
+  dfh_table* t = s->t;
+  dfh_comm* c = s->c;
+  dfh_ctx* ctx = t->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int W = c->world, k = t->v.k;
+  const size_t stride = dfh_row_stride(k);
+  if (int rck = check_keys(keys, n)) return rck;
+  const bool grad = val_type == DFH_GRADIENT;
+  std::vector<float> rows;
+  if (grad) {
+    if (int rca = require_aux(t, "dfh_shard_push_host(kGradient)")) return rca;
+    const bool w_only = nlens == 0;
+    if (w_only) {
+      DFH_ARG(nvals == n, "kGradient: CHECK_EQ(values.size(), size) (sgd_updater.cc:79)");
+    } else {
+      DFH_ARG(nlens == n && lens, "kGradient: CHECK_EQ(lens.size(), size) (sgd_updater.cc:81)");
+    }
+    rows.assign(std::max<size_t>(n, 1) * stride, 0.0f);
+    size_t p = 0;
+    for (size_t i = 0; i < n; ++i) {
+      float* r = rows.data() + i * stride;
+      DFH_ARG(p < nvals, "kGradient: values shorter than lens imply (sgd_updater.cc:96)");
+      r[0] = vals[p++];
+      if (!w_only && lens[i] > 1) {
+        DFH_ARG(lens[i] == k + 1, "kGradient: CHECK_EQ(lens[i], V_dim+1) (sgd_updater.cc:91)");
+        DFH_ARG(p + (size_t)k <= nvals, "kGradient: values shorter than lens imply (sgd_updater.cc:96)");
+        r[1] = 1.0f;
+        memcpy(r + 4, vals + p, sizeof(float) * (size_t)k);
+        p += (size_t)k;
+      }
+    }
+    DFH_ARG(p == nvals, "kGradient: CHECK_EQ(p, values.size()) (sgd_updater.cc:96)");
+  } else {
+    DFH_ARG(nvals == n, "kFeaCount: CHECK_EQ(fea_ids.size(), values.size()) (sgd_updater.cc:63)");
+  }
+  HostCall h;
+  int rc = host_call_sizes(s, keys, n, &h);
+  if (rc) return rc;
+  rc = host_call_bufs(s, h.nrecv, n, stride);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, padded<uint64_t>(std::max<size_t>(n, 1)) + padded<float>(std::max<size_t>(n, 1)));
+  if (rc) return rc;
+  Carver cv(ctx->scratch);
+  uint64_t* d_keys = cv.take<uint64_t>(std::max<size_t>(n, 1));
+  float* d_cnt = cv.take<float>(std::max<size_t>(n, 1));
+  if (n) DFH_HIP(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  std::vector<size_t> sb, rb;
+  bytes_of(h, W, sizeof(uint64_t), sb, rb);
+  XPart xk{d_keys, sb.data(), nullptr, s->r_keys[0], rb.data(), nullptr};
+  rc = comm_exchange(c, &xk, 1);
+  if (rc) return rc;
+  if (grad) {
+    if (n) DFH_HIP(hipMemcpyAsync(s->w_rows[0], rows.data(), n * stride * sizeof(float), hipMemcpyHostToDevice, st));
+    bytes_of(h, W, stride * sizeof(float), sb, rb);
+    XPart xg{s->w_rows[0], sb.data(), nullptr, s->r_rows[0], rb.data(), nullptr};
+    rc = comm_exchange(c, &xg, 1);
+    if (rc) return rc;
+    DFH_HIP(hipStreamSynchronize(st));  // `rows` leaves scope
+  } else {
+    if (n) DFH_HIP(hipMemcpyAsync(d_cnt, vals, n * sizeof(float), hipMemcpyHostToDevice, st));
+    bytes_of(h, W, sizeof(float), sb, rb);
+    XPart xc{d_cnt, sb.data(), nullptr, s->r_cnt[0], rb.data(), nullptr};
+    rc = comm_exchange(c, &xc, 1);
+    if (rc) return rc;
+  }
+  if (h.nrecv) {  // owners: SGDUpdater::Update, the sources one after the other in ascending rank order
+    rc = dfh_shard_resolve_multi(t, s->r_keys[0], h.seg.data(), W, 0, s->r_rowid[0]);
+    if (rc) return rc;
+    if (grad) {
+      rc = dfh_shard_push_grad_multi(t, s->r_rowid[0], s->r_keys[0], h.seg.data(), W, 0, s->r_rows[0]);
+      if (rc) return rc;
+    } else {
+      rc = dfh_shard_push_count_multi(t, s->r_rowid[0], s->r_keys[0], h.seg.data(), W, 0, s->r_cnt[0]);
+      if (rc) return rc;
+      rc = dfh_shard_release(t, s->r_rowid[0], h.nrecv, 0);
+      if (rc) return rc;
+    }
+  }
+  DFH_HIP(hipStreamSynchronize(st));
+  return check_table_err(t);
 }
 
 }  // extern "C"

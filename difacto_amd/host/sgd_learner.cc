@@ -44,6 +44,22 @@ KWArgs SGDLearner::Init(const KWArgs& kwargs) {
   remain = store_->Init(remain);
   loss_ = Loss::Create(param_.loss, blk_nthreads_);
   remain = loss_->Init(remain);
+  if (auto* ss = dynamic_cast<ShardedDeviceStore*>(store_)) {
+    // the key ranges of the shards: balanced on a sample of the keys this rank is going to see (the first minibatches
+    // of its first data part), gathered over the ranks
+    std::vector<feaid_t> sample;
+    if (GetUpdater()->device_param().shard_ranges == "balanced" && store_->NumWorkers() > 1) {
+      sgd::Job job;
+      job.type = param_.task == "predict" ? sgd::Job::kPrediction : sgd::Job::kTraining;
+      const int n = store_->NumWorkers() * param_.num_jobs_per_epoch;
+      BatchReader reader(JobData(job), param_.data_format, store_->Rank(), n, param_.batch_size, 0, 1.0f);
+      while (sample.size() < (1u << 18) && reader.Next()) {
+        const auto& blk = reader.Value();
+        for (size_t i = blk.offset[0]; i < blk.offset[blk.size]; ++i) sample.push_back(ReverseBytes(blk.index[i]));
+      }
+    }
+    ss->CreateShard(sample);
+  }
   if (param_.model_in.size()) LoadModel();
   return remain;
 }
@@ -177,11 +193,10 @@ void SGDLearner::Process(const std::string& args, std::string* rets) {
 }
 
 void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
-  if (dynamic_cast<ShardedDeviceStore*>(store_)) {
-    CHECK(GetUpdater()->device_param().device_path != "literal") << "the sharded store has no one-sided Push / Pull";
+  if (GetUpdater()->device_param().device_path == "literal" && job.type != sgd::Job::kPrediction) {
+    IterateDataLiteral(job, prog);  // sharded store too: its Push / Pull are collective, the loop keeps the ranks in step
+  } else if (dynamic_cast<ShardedDeviceStore*>(store_)) {
     IterateDataSharded(job, prog);
-  } else if (GetUpdater()->device_param().device_path == "literal" && job.type != sgd::Job::kPrediction) {
-    IterateDataLiteral(job, prog);
   } else {
     IterateDataFused(job, prog);
   }
@@ -418,35 +433,53 @@ void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress
   const bool push_cnt = train && job.epoch == 0;
   BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
                      train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
-  while (reader.Next()) {
+  // the sharded store's Push / Pull are collective: every rank makes the same calls until no rank has a minibatch
+  // left; a rank whose part of the data is exhausted goes on with empty arrays
+  auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
+  bool more = true;
+  for (;;) {
+    const bool have = more && reader.Next();
+    more = have;
+    if (ss) {
+      double any = have ? 1.0 : 0.0;
+      DFH_CALL(dfh_comm_allreduce_sum(ss->comm(), &any, 1));
+      if (any == 0.0) break;
+    } else if (!have) {
+      break;
+    }
     dmlc::data::RowBlockContainer<unsigned> data;
     auto feaids = std::make_shared<std::vector<feaid_t>>();
     auto feacnt = std::make_shared<std::vector<real_t>>();
-    Localizer lc(-1, blk_nthreads_);
-    lc.Compact(reader.Value(), &data, feaids.get(), push_cnt ? feacnt.get() : nullptr);
+    if (have) {
+      Localizer lc(-1, blk_nthreads_);
+      lc.Compact(reader.Value(), &data, feaids.get(), push_cnt ? feacnt.get() : nullptr);
+    }
     SArray<feaid_t> keys(feaids);
     if (push_cnt) store_->Wait(store_->Push(keys, Store::kFeaCount, SArray<real_t>(feacnt), {}));
     SArray<real_t> values;
     SArray<int> lengths;
     store_->Wait(store_->Pull(keys, Store::kWeight, &values, &lengths));
-    auto blk = data.GetBlock();
-    progress->nrows += blk.size;
-    SArray<real_t> pred(blk.size);
-    SArray<int> w_pos, V_pos;
-    GetPos(lengths, &w_pos, &V_pos);
-    std::vector<SArray<char>> inputs = {SArray<char>(values), SArray<char>(w_pos), SArray<char>(V_pos)};
-    loss_->Predict(blk, inputs, &pred);
-    progress->loss += loss_->Evaluate(blk.label, pred);
-    progress->penalty += EvaluatePenalty(values, w_pos, V_pos);
-    float auc_n = 0;
-    DFH_CALL(dfh_auc_times_n(DeviceContext::Get(), blk.label, pred.data(), pred.size(), &auc_n));
-    progress->auc += auc_n;
-    if (train) {
-      SArray<real_t> grads(values.size());
-      inputs.push_back(SArray<char>(pred));
-      loss_->CalcGrad(blk, inputs, &grads);
-      store_->Wait(store_->Push(keys, Store::kGradient, grads, lengths));
+    SArray<real_t> grads;
+    if (have) {
+      auto blk = data.GetBlock();
+      progress->nrows += blk.size;
+      SArray<real_t> pred(blk.size);
+      SArray<int> w_pos, V_pos;
+      GetPos(lengths, &w_pos, &V_pos);
+      std::vector<SArray<char>> inputs = {SArray<char>(values), SArray<char>(w_pos), SArray<char>(V_pos)};
+      loss_->Predict(blk, inputs, &pred);
+      progress->loss += loss_->Evaluate(blk.label, pred);
+      progress->penalty += EvaluatePenalty(values, w_pos, V_pos);
+      float auc_n = 0;
+      DFH_CALL(dfh_auc_times_n(DeviceContext::Get(), blk.label, pred.data(), pred.size(), &auc_n));
+      progress->auc += auc_n;
+      if (train) {
+        grads.resize(values.size());
+        inputs.push_back(SArray<char>(pred));
+        loss_->CalcGrad(blk, inputs, &grads);
+      }
     }
+    if (train) store_->Wait(store_->Push(keys, Store::kGradient, grads, lengths));
   }
 }
 

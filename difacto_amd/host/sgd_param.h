@@ -82,7 +82,15 @@ struct DeviceParam : public dmlc::Parameter<DeviceParam> {
   std::string V_init;
   /*! \brief "fused": the whole worker step on device; "literal": Store/Loss calls with host arrays */
   std::string device_path;
+  /*! \brief sharded store: "balanced" cuts the key space at the quantiles of a sample of the data's keys (every rank
+   *  samples its own part, the samples are gathered); "uniform": owner = key / ceil(2^64 / ranks) */
+  std::string shard_ranges;
+  /*! \brief sharded store: "overlap" keeps two minibatches in flight like the reference's batch tracker
+   *  (sgd_learner.cc:219-223; rows pulled from other owners are at most one minibatch stale), "sync" one (zero staleness) */
+  std::string shard_exchange;
   DMLC_DECLARE_PARAMETER(DeviceParam) {
+    DMLC_DECLARE_FIELD(shard_ranges).set_default("balanced");
+    DMLC_DECLARE_FIELD(shard_exchange).set_default("overlap");
     DMLC_DECLARE_FIELD(table_capacity).set_default(1ULL << 22);
     DMLC_DECLARE_FIELD(V_init).set_default("refrand");
     DMLC_DECLARE_FIELD(device_path).set_default("fused");

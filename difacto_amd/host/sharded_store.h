@@ -135,19 +135,60 @@ class ShardedDeviceStore : public Store {
       }
       DFH_CALL(dfh_comm_create_rccl(ctx, rank_, world_, id, &comm_));
     }
-    DFH_CALL(dfh_shard_create(up->table(), comm_, nullptr, &shard_));
     LOG(INFO) << "sharded store: rank " << rank_ << " of " << world_ << " connected ("
               << (files_ ? "file transport" : "RCCL") << ")";
     return kwargs;
   }
 
-  int Push(const SArray<feaid_t>&, int, const SArray<real_t>&, const SArray<int>&, const std::function<void()>&) override {
-    LOG(FATAL) << "the sharded store is collective: one-sided Push is not available (use device_path=fused)";
-    return 0;
+  /**
+   * \brief cuts the key space and creates this rank's shard.  COLLECTIVE; called once by the learner after Init,
+   * before a model is loaded.  sample: reversed keys of (the beginning of) this rank's part of the data, any number,
+   * for shard_ranges = balanced (dfh_shard_balanced_splits: the quantiles of the union of all ranks' samples);
+   * ignored for uniform ranges.
+   */
+  void CreateShard(const std::vector<feaid_t>& sample) {
+    CHECK(!shard_) << "the shard exists already";
+    auto* up = CHECK_NOTNULL(dynamic_cast<DeviceSGDUpdater*>(CHECK_NOTNULL(updater_.get())));
+    const auto& dp = up->device_param();
+    CHECK(dp.shard_ranges == "balanced" || dp.shard_ranges == "uniform") << "shard_ranges = balanced | uniform";
+    CHECK(dp.shard_exchange == "overlap" || dp.shard_exchange == "sync") << "shard_exchange = overlap | sync";
+    std::vector<uint64_t> splits(world_ > 1 ? world_ - 1 : 1, 0);
+    const bool balanced = dp.shard_ranges == "balanced" && world_ > 1;
+    if (balanced) DFH_CALL(dfh_shard_balanced_splits(comm_, sample.data(), sample.size(), splits.data()));
+    DFH_CALL(dfh_shard_create(up->table(), comm_, balanced ? splits.data() : nullptr, &shard_));
+    if (dp.shard_exchange == "overlap") DFH_CALL(dfh_shard_set_exchange(shard_, 1));
+    uint64_t lo = 0, hi = 0;
+    DFH_CALL(dfh_shard_owned_range(shard_, balanced ? splits.data() : nullptr, &lo, &hi));
+    LOG(INFO) << "sharded store: rank " << rank_ << " owns the reversed keys [" << lo << ", " << (hi ? std::to_string(hi) : "2^64")
+              << ") (" << dp.shard_ranges << " ranges), exchange = " << dp.shard_exchange;
   }
-  int Pull(const SArray<feaid_t>&, int, SArray<real_t>*, SArray<int>*, const std::function<void()>&) override {
-    LOG(FATAL) << "the sharded store is collective: one-sided Pull is not available (use device_path=fused)";
-    return 0;
+
+  /**
+   * \brief the literal Store::Push / Pull (include/difacto/store.h:53-73) on the sharded model: keys routed to their owners,
+   * rows / acknowledgements back (dfh_shard_push_host / dfh_shard_pull_host).  COLLECTIVE: every rank makes the same
+   * sequence of calls (a rank without a minibatch passes empty arrays) — what SGDLearner's literal worker loop does.
+   * Synchronous: the arrays are consumed, and on_complete has run, on return.
+   */
+  int Push(const SArray<feaid_t>& fea_ids, int val_type, const SArray<real_t>& vals, const SArray<int>& lens,
+           const std::function<void()>& on_complete) override {
+    DFH_CALL(dfh_shard_push_host(CHECK_NOTNULL(shard_), fea_ids.data(), fea_ids.size(), val_type, vals.data(), vals.size(), lens.data(),
+                                 lens.size()));
+    if (on_complete) on_complete();
+    return time_++;
+  }
+  int Pull(const SArray<feaid_t>& fea_ids, int val_type, SArray<real_t>* vals, SArray<int>* lens,
+           const std::function<void()>& on_complete) override {
+    CHECK_EQ(val_type, Store::kWeight);
+    auto* up = CHECK_NOTNULL(dynamic_cast<DeviceSGDUpdater*>(CHECK_NOTNULL(updater_.get())));
+    const size_t n = fea_ids.size();
+    CHECK_NOTNULL(vals)->resize(n * (1 + up->param().V_dim));
+    CHECK_NOTNULL(lens)->resize(n);
+    size_t nvals = 0, nlens = 0;
+    DFH_CALL(dfh_shard_pull_host(CHECK_NOTNULL(shard_), fea_ids.data(), n, vals->data(), &nvals, lens->data(), &nlens));
+    vals->resize(nvals);
+    lens->resize(nlens);
+    if (on_complete) on_complete();
+    return time_++;
   }
   void Wait(int time) override {}
   int Rank() override { return rank_; }
@@ -159,6 +200,7 @@ class ShardedDeviceStore : public Store {
 
  private:
   int rank_ = 0, world_ = 1;
+  int time_ = 0;
   dfh_comm* comm_ = nullptr;
   dfh_shard* shard_ = nullptr;
   std::unique_ptr<FileExchange> files_;

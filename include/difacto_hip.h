@@ -321,6 +321,15 @@ int dfh_comm_rank(dfh_comm* c);
 int dfh_comm_world(dfh_comm* c);
 /* sum of n <= 64 host doubles over the ranks (same result on every rank): progress merging, votes */
 int dfh_comm_allreduce_sum(dfh_comm* c, double* vals, int n);
+/* every rank's `bytes` host bytes to every rank: recv holds world * bytes, in rank order.  COLLECTIVE. */
+int dfh_comm_allgather(dfh_comm* c, const void* send, size_t bytes, void* recv);
+/* Split keys that balance the shards on the DATA instead of on the key space: every rank hands in a sample of the
+ * reversed keys it will see (n may differ per rank, 0 allowed); the samples are gathered and splits[world-1] receives
+ * the (identical on every rank) quantiles of their union — the argument for dfh_shard_create.  With feature-group ids
+ * in the low bits of an id (EncodeFeaGrpID, include/difacto/base.h:60-63) ReverseBytes moves them to the top of the
+ * key and a uniform cut of the key space is badly skewed (39 criteo slots over 8 shards: one shard 2.3x the
+ * average).  COLLECTIVE.  With no key in any sample the uniform split keys are returned. */
+int dfh_shard_balanced_splits(dfh_comm* c, const uint64_t* sample_keys, size_t n, uint64_t* splits);
 
 /* this rank's shard of the model + the exchange buffers.  splits: world-1 ascending first keys of
  * shards 1.., identical on every rank, or NULL for the uniform ranges.  The table must use
@@ -345,6 +354,40 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
  * what the reference's batch tracker achieves by keeping two minibatches in flight
  * (sgd_learner.cc:219-223), here without staleness.  No-op with one rank. */
 int dfh_shard_prefetch_counts(dfh_shard* s, dfh_batch* b_next);
+/* How dfh_shard_step moves the rows.  0 (default) = sync: one minibatch at a time, every exchange on the context's
+ * stream, zero staleness.  1 = overlap: TWO minibatches in flight, what the reference's batch tracker does
+ * (src/sgd/sgd_learner.cc:219-223: the next minibatch is issued while one is pending, so its Pull may be served
+ * before the previous Push has landed).  Inside dfh_shard_step(b) the minibatch named by the preceding
+ * dfh_shard_prefetch_counts has its counts, keys and rows exchanged on a second stream while b computes:
+ *     collectives' stream:  counts(t+1)  K(t+1)              G(t)            RW(t+1)
+ *     main stream:          L(t) F(t) [gradient rows | own keys updated in place]  R(t+1)        P(t)
+ * so the gradients of t travel while the owners pull for t+1, and the rows of t+1 travel while the gradients of t
+ * are applied.  Staleness: the keys a rank owns itself are read with zero staleness (L(t+1) runs after P(t)); rows
+ * pulled from other owners miss the gradients the OTHER ranks computed in step t (staleness 1, exactly one
+ * minibatch), and contain the owner's own step-t update.  Every table operation runs on the main stream in program
+ * order: nothing races on a row, every pulled row is one consistent version of its key.  The announced minibatch
+ * is pulled (and its epoch-0 counts pushed) with the push_cnt of the call it rides in: the flag is a property of the
+ * job (src/sgd/sgd_learner.cc:201-202), keep it constant from one announcement to the step.  Call between steps only
+ * (no minibatch under way); COLLECTIVE in effect: every rank must use the same mode. */
+int dfh_shard_set_exchange(dfh_shard* s, int mode);
+/* Per-stage device time of the steps since the last reset (HIP events around every stage; they cost the streams a
+ * few microseconds each: for a diagnostic pass, not for the timed run).  ms[DFH_SHARD_STAGES]: counts, L (own keys'
+ * lookup), K, R, RW, F (forward + backward / own update), G, P; *steps = steps covered. */
+enum { DFH_SHARD_STAGE_COUNTS = 0, DFH_SHARD_STAGE_L, DFH_SHARD_STAGE_K, DFH_SHARD_STAGE_R, DFH_SHARD_STAGE_RW, DFH_SHARD_STAGE_F,
+       DFH_SHARD_STAGE_G, DFH_SHARD_STAGE_P, DFH_SHARD_STAGES };
+int dfh_shard_set_timing(dfh_shard* s, int enable);
+int dfh_shard_get_timing(dfh_shard* s, int reset, double* ms, uint64_t* steps);
+
+/* The literal Store::Pull / Store::Push (include/difacto/store.h:53-73) against the SHARDED model, with host arrays in the
+ * layout of dfh_pull / dfh_push: what the reference's worker loop calls once per minibatch when it runs call by call
+ * (device_path = literal) instead of through dfh_shard_step.  keys: ascending, unique (a Localizer's output).
+ * COLLECTIVE: every rank makes the same sequence of calls with the same val_type; a rank with nothing to ask passes
+ * n = 0 and still serves its shard.  One exchange each way per call, everything on the context's stream, synchronous.
+ * Pushes from several ranks to one key are applied in ascending rank order (FTRL / AdaGrad are not linear: the order is
+ * part of the result, and fixed). */
+int dfh_shard_pull_host(dfh_shard* s, const uint64_t* keys, size_t n, float* vals, size_t* nvals, int* lens, size_t* nlens);
+int dfh_shard_push_host(dfh_shard* s, const uint64_t* keys, size_t n, int val_type, const float* vals, size_t nvals, const int* lens,
+                        size_t nlens);
 
 /* raw device memory for hosts without a HIP runtime of their own */
 int dfh_malloc(dfh_ctx* ctx, size_t bytes, void** dptr);

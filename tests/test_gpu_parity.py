@@ -799,6 +799,7 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
     import torch
     import torch.distributed as dist
     from difacto_amd import sharded
+    import sharded_harness
     created = not dist.is_initialized()
     if created:
         torch.cuda.set_device(0)
@@ -809,8 +810,8 @@ def test_sharded_hip_backend_world1_matches_fused(capi, oracle):
         kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
         batches = [random_batch(rng, 150, 2 ** 64 - 1 if i else 500, 25, binary=(i == 1)) for i in range(3)]
         max_nnz = max(int(b["offset"][-1]) for b in batches)
-        be = sharded.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
-        w = sharded.ShardedWorker(be)
+        be = sharded_harness.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
+        w = sharded_harness.ShardedWorker(be)
         ctx = capi.Context(0)
         tb = capi.Table(ctx, 1 << 15, V_dim=8, **kw)
         bt = capi.Batch(ctx, 150, max_nnz)
@@ -849,6 +850,7 @@ def test_sharded_hip_backend_world1_overlap_over_rccl(capi, oracle):
     import torch
     import torch.distributed as dist
     from difacto_amd import sharded
+    import sharded_harness
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from sharded_testlib import emulate_single_store
     created = not dist.is_initialized()
@@ -861,8 +863,8 @@ def test_sharded_hip_backend_world1_overlap_over_rccl(capi, oracle):
         kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
         batches = [random_batch(rng, 150, 600, 25, binary=(i % 2 == 1)) for i in range(7)]  # shared keys: staleness shows
         max_nnz = max(int(b["offset"][-1]) for b in batches)
-        be = sharded.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
-        w = sharded.ShardedWorker(be, exchange="overlap")
+        be = sharded_harness.HipBackend(0, 8, 1 << 15, kw, 150, max_nnz)
+        w = sharded_harness.ShardedWorker(be, exchange="overlap")
         preds = []
         for i in range(2):
             w.submit(batches[i], True, i < 3)

@@ -240,3 +240,37 @@ def test_cli_refuses_roles_other_than_worker_and_a_missing_rank(built, tmp_path)
         env.update(env_add, DIFACTO_DEVICE="0")
         r = subprocess.run(args, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
         assert r.returncode != 0 and msg in r.stderr, (env_add, r.stderr[-800:])
+
+
+@pytest.mark.gpu
+def test_cli_literal_path_on_the_sharded_store(built, tmp_path):
+    """device_path=literal on the sharded store: the worker loop makes the reference's own calls (Push(kFeaCount), Pull,
+    Loss::Predict / CalcGrad, Push(kGradient)) and the store routes them to the owners (dfh_shard_push_host /
+    dfh_shard_pull_host).  One rank: the trajectory of the plain literal run.  Two ranks over the file transport: both
+    report the same merged progress and the loss falls."""
+    text = open(_hash_conf(tmp_path, 3, 25)).read().replace("device_path = fused", "device_path = literal")
+    conf = os.path.join(tmp_path, "literal.conf")
+    open(conf, "w").write(text)
+    exe = os.path.join(built, "difacto")
+    plain = subprocess.run([exe, "argfile=" + conf], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env = dict(os.environ, DMLC_ROLE="worker", DMLC_NUM_WORKER="1", DIFACTO_RANK="0", DIFACTO_DEVICE="0")
+    one = subprocess.run([exe, "argfile=" + conf], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    print(one.stderr[-1500:])
+    assert plain.returncode == 0 and one.returncode == 0
+    a, b = _losses(plain.stderr), _losses(one.stderr)
+    # two different kernels apply the pushes (k_push_grad: a wave per key; k_push_grad_multi: a lane group per key): the
+    # trajectories agree to accumulated rounding, not bit for bit
+    assert len(a) == len(b) >= 2 and all(abs(x - y) <= 1e-3 * abs(x) for x, y in zip(a, b)), (a, b)
+    rv = os.path.join(tmp_path, "rv_lit")
+    os.makedirs(rv)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, DMLC_ROLE="worker", DMLC_NUM_WORKER="2", DIFACTO_RANK=str(r), DIFACTO_DEVICE="0", DIFACTO_COMM="file",
+                   DIFACTO_RENDEZVOUS=rv)
+        procs.append(subprocess.Popen([exe, "argfile=" + conf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        print(err[-1500:])
+        assert p.returncode == 0
+    l0, l1 = _losses(outs[0][1]), _losses(outs[1][1])
+    assert len(l0) >= 2 and l0 == l1 and l0[-1] < l0[0], (l0, l1)

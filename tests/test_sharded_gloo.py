@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_dir, kind, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from difacto_amd.sharded import ShardedWorker
+    from sharded_harness import ShardedWorker
     from sharded_testlib import OracleBackend
     be = OracleBackend(V_DIM, HYPER)
     splits = _splits(kind)

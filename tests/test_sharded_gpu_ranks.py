@@ -33,15 +33,16 @@ def _worker(rank, world, port, out_dir, exchange):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from difacto_amd import sharded
+    import sharded_harness
     batches = make_batches(rank)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
-    be = sharded.HipBackend(0, V_DIM, 1 << 16, HYPER, ROWS, max_nnz)
+    be = sharded_harness.HipBackend(0, V_DIM, 1 << 16, HYPER, ROWS, max_nnz)
     from difacto_amd.synth import reverse_bytes_np
     splits = None
     if world == 4:  # one of the two cases runs with split keys balanced on the data instead of uniform ranges
         ids = np.concatenate([b["index"] for r in range(world) for b in make_batches(r)])
         splits = sharded.balanced_splits(reverse_bytes_np(ids), world)
-    w = sharded.ShardedWorker(be, stage_through_host=True, splits=splits, exchange=exchange)
+    w = sharded_harness.ShardedWorker(be, stage_through_host=True, splits=splits, exchange=exchange)
     ahead = 2 if exchange == "overlap" else 1
     preds, infos = [], []
     for i in range(min(ahead, len(batches))):
