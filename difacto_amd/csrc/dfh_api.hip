@@ -280,6 +280,10 @@ int check_table_err(dfh_table* t) {
     set_error("gradient carries V for a key whose V is not allocated (reference CHECK(e.V != nullptr))");
     return DFH_ERR_ARG;
   }
+  if (e & 8u) {
+    set_error("key index: a claimed slot never received its row id (find_or_insert gave up waiting)");
+    return DFH_ERR_STATE;
+  }
   return DFH_OK;
 }
 

@@ -81,27 +81,38 @@ __device__ __forceinline__ float hash_init_value(uint64_t key, int j, unsigned s
 // all row words = ~0).  A row id is the whole message: rows are zero until an update writes them.
 __device__ __forceinline__ uint32_t find_or_insert(const TableView& t, uint64_t key) {
   uint64_t h = splitmix64(key) & t.hmask;
-  for (;;) {
+  // Two lanes of ONE wavefront may carry the same new key (k_resolve_multi: several source ranks), and lanes of a
+  // wavefront make progress together: a lane waiting for a row id must not keep the winner of its slot from storing it.
+  // Every iteration is therefore straight-line: (1) claim, (2) the winners publish, (3) everyone looks — in program
+  // order, no early exit between them, so that (2) of a winner always precedes (3) of the lanes that share its
+  // wavefront.  The wait is bounded: a slot whose row id never appears sets error bit 3 instead of hanging the device.
+  for (uint32_t spins = 0;;) {
     uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool won = false;
     if (k == kEmptyKey) {
-      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
-                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
-      if (old == kEmptyKey) {
-        uint32_t r = atomicAdd(t.nrows, 1u);
-        if (r >= t.capacity) {
-          atomicOr(t.err, 1u);
-          r = t.capacity - 1;  // keep memory safe; the host reports DFH_ERR_CAPACITY
-        }
-        __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return r;
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key),
+                                               (unsigned long long)kEmptyKey, (unsigned long long)key);
+      won = old == kEmptyKey;
+      k = won ? key : (uint64_t)old;
+    }
+    uint32_t r = kNoRow;
+    if (won) {
+      r = atomicAdd(t.nrows, 1u);
+      if (r >= t.capacity) {
+        atomicOr(t.err, 1u);
+        r = t.capacity - 1;  // keep memory safe; the host reports DFH_ERR_CAPACITY
       }
-      k = old;
+      __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (k == key) {
-      uint32_t r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!won) r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (r != kNoRow) return r;
+      if (++spins > (1u << 22)) {  // seconds: the winner of this slot is gone
+        atomicOr(t.err, 8u);
+        return 0u;
+      }
       __builtin_amdgcn_s_sleep(1);
-      continue;  // the winner of this slot is between its CAS and its store
+      continue;  // the winner of this slot (another wavefront) is between its CAS and its store
     }
     h = (h + 1) & t.hmask;
   }

@@ -33,6 +33,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -165,20 +166,24 @@ class LibsvmChunkParser : public ChunkParser {
     while (p < eol && (*p == ' ' || *p == '\t')) ++p;
     if (p >= eol || *p == '#' || *p == '\r') return;
     char* e;
-    const float label = strtof(p, &e);  // numbers never span lines; the file's last lines are NUL-terminated (TextChunks)
-    CHECK(e != p) << "bad libsvm line: " << std::string(p, eol - p);
+    // strtof / strtoull skip leading white space, a newline included: a number must start where we stand and end inside
+    // the line, or the next line's label would be taken for a missing value
+    const float label = strtof(p, &e);  // the file's last lines are NUL-terminated (TextChunks)
+    CHECK(e != p && e <= eol) << "bad libsvm line: " << std::string(p, eol - p);
     p = e;
     out->label.push_back(label);
     for (;;) {
       while (p < eol && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
       if (p >= eol) break;
       const feaid_t id = strtoull(p, &e, 10);
-      CHECK(e != p) << "bad libsvm token in: " << std::string(p, eol - p);
+      CHECK(e != p && e <= eol) << "bad libsvm token in: " << std::string(p, eol - p);
       p = e;
       float v = 1.0f;
       if (p < eol && *p == ':') {
         ++p;
+        CHECK(p < eol && !isspace(static_cast<unsigned char>(*p))) << "libsvm feature " << id << " has no value after ':'";
         v = strtof(p, &e);
+        CHECK(e != p && e <= eol) << "bad libsvm value of feature " << id;
         p = e;
       }
       out->index.push_back(id);
@@ -337,11 +342,17 @@ inline void DecompressRowBlock(const char* data, size_t size, RowChunk* blk) {
   CHECK_EQ(read_int(), static_cast<int>(sizeof(feaid_t))) << "wrong indextype";
   const int nrows = read_int();
   CHECK_GE(nrows, 0);
+  // sizes read from the file are not trusted: an LZ4 block expands at most 255 x, so the bytes that are left
+  // bound every array that may follow
+  const size_t max_out = (size - cur) * 255 + 64;
+  CHECK_LE(static_cast<size_t>(nrows) * sizeof(real_t), max_out) << "corrupt compressed row block: " << nrows << " rows in " << size << " bytes";
   blk->label.resize(nrows);
   if (!inflate(blk->label.data(), nrows * sizeof(real_t))) blk->label.clear();
   blk->offset.resize(nrows + 1);
   CHECK(inflate(blk->offset.data(), (nrows + 1) * sizeof(size_t))) << "compressed row block without offsets";
+  for (int i = 0; i < nrows; ++i) CHECK_LE(blk->offset[i], blk->offset[i + 1]) << "corrupt compressed row block: offsets decrease at row " << i;
   const size_t nnz = blk->offset[nrows] - blk->offset[0];
+  CHECK_LE(nnz * sizeof(real_t), max_out) << "corrupt compressed row block: " << nnz << " nonzeros in " << size << " bytes";
   if (blk->offset[0] != 0) for (auto& o : blk->offset) o -= blk->offset[0];
   blk->index.resize(nnz);
   if (!inflate(blk->index.data(), nnz * sizeof(feaid_t))) blk->index.clear();
