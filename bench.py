@@ -67,9 +67,6 @@ def parse_args():
     ap.add_argument("--prep-streams", type=int, default=1,
                     help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
                          "keeps 2 in flight)")
-    ap.add_argument("--no-prep-pairs", dest="prep_pairs", action="store_false",
-                    help="prepare one minibatch per set of Localizer launches instead of two (dfh_localize_multi / "
-                         "dfh_batch_lookup_multi: every launch of the preparation stream serves minibatches t+2 and t+3)")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
     ap.add_argument("--later-epoch", action="store_true",
@@ -332,44 +329,26 @@ def main():
         name, val = kv.split("=", 1)
         ctx.set_option(name, int(val))
     ctx.set_pipeline(depth)
-    # pairs: every set of launches on the preparation stream serves TWO minibatches (t+2 and t+3 while t and t+1 train)
-    pairs = bool(args.prep_pairs and depth == 1 and not args.no_relocalize)
-    ahead = 2 if pairs else max(depth, 1)
+    ahead = max(depth, 1)
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
-    bts = [capi.Batch(ctx, B, max_nnz) for _ in range(5 if pairs else ahead + (2 if depth else 1))]
+    bts = [capi.Batch(ctx, B, max_nnz) for _ in range(ahead + (2 if depth else 1))]
     bt = bts[0]
 
-    def attach(i):
+    def prep(i):
         o, x, l, v, nr, nz = dev[i % nd]
         b = bts[i % len(bts)]
         b.attach_device(nr, nz, o.ptr, x.ptr, None if v is None else v.ptr, l.ptr)  # inputs are resident in HBM: no copy
-        return b
-
-    def prep(i):
-        b = attach(i)
         b.localize()
         if args.prep_lookup and depth:   # one stream: the step's own lookup probes and pushes in one pass
             b.lookup(table)
 
-    def prep_pair(i):
-        bs = [attach(i), attach(i + 1)]
-        capi.localize_multi(bs)
-        if args.prep_lookup:
-            capi.lookup_multi(table, bs)
-
     def step(i):
-        if pairs:
-            if i % 2 == 0:
-                prep_pair(i + 2)
-        elif not args.no_relocalize or i + ahead < len(bts):
+        if not args.no_relocalize or i + ahead < len(bts):
             prep(i + ahead)
         bts[i % len(bts)].sgd_step(table, is_train=True, push_cnt=not args.later_epoch)
 
-    if pairs:
-        prep_pair(0)
-    else:
-        for i in range(ahead):
-            prep(i)
+    for i in range(ahead):
+        prep(i)
     done = 0
     for i in range(args.warmup):
         step(done)
@@ -502,7 +481,6 @@ def main():
                    "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
                    "model_keys": int(nkeys), "table_bytes": tbytes, "prefilled": not args.no_prefill, "hyper": hyper,
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
-                   "minibatches_per_prep_launch": 2 if pairs else 1,
                    "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,

@@ -29,7 +29,7 @@ SYMBOLS = [
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
-    "dfh_localize_multi", "dfh_batch_lookup_multi", "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
+    "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
 ]
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
 K_COUNT = 7
@@ -172,8 +172,6 @@ def lib():
     L.dfh_shard_owned_range.argtypes = [vp, vp, PP(u64), PP(u64)]
     L.dfh_shard_step.argtypes = [vp, vp, i32, i32, PP(i32)]
     L.dfh_shard_prefetch_counts.argtypes = [vp, vp]
-    L.dfh_localize_multi.argtypes = [vp, i32, u64]
-    L.dfh_batch_lookup_multi.argtypes = [vp, vp, i32]
     L.dfh_shard_pull_host.argtypes = [vp, vp, C.c_size_t, vp, PP(C.c_size_t), vp, PP(C.c_size_t)]
     L.dfh_shard_push_host.argtypes = [vp, vp, C.c_size_t, i32, vp, C.c_size_t, vp, C.c_size_t]
     L.dfh_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
@@ -642,18 +640,6 @@ class Comm:
         if self.h:
             lib().dfh_comm_destroy(self.h)
             self.h = None
-
-
-def localize_multi(batches, max_index=2 ** 64 - 1):
-    """Localizer::Compact for one or two loaded minibatches in one set of launches (dfh_localize_multi)"""
-    arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
-    _ck(lib().dfh_localize_multi(arr, len(batches), max_index))
-
-
-def lookup_multi(table, batches):
-    """the key-index probe for one or two localized minibatches in one launch (dfh_batch_lookup_multi)"""
-    arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
-    _ck(lib().dfh_batch_lookup_multi(table.h, arr, len(batches)))
 
 
 class Shard:

@@ -1815,86 +1815,6 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
   return DFH_OK;
 }
 
-namespace {
-// bucket count of the sample sort for this minibatch: the stored splitters' while the average bucket stays in a sane
-// range (they describe the data distribution, not this minibatch), else sized for this minibatch and bootstrapped from
-// a sample (*cold).  0: too large for the sample sort (library radix sort).
-int loc_buckets(const dfh_batch* b, bool* cold) {
-  const uint32_t N = (uint32_t)b->nnz;
-  *cold = true;
-  if (b->spl_P > 0 && N / (uint32_t)b->spl_P >= (uint32_t)LOC_MIN_AVG && N / (uint32_t)b->spl_P <= (uint32_t)LOC_MAX_AVG) {
-    *cold = false;
-    return b->spl_P;
-  }
-  const size_t P_want = (N + LOC_AVG_BUCKET - 1) / LOC_AVG_BUCKET;
-  int P = P_want <= (size_t)LOC_MAX_BUCKETS ? (int)std::max<size_t>(1, P_want) : 0;
-  if (P == 0 && N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
-  return P;
-}
-
-LocJob loc_job(dfh_batch* b, uint64_t max_index, int P) {
-  LocJob J;
-  LocView& v = J.v;
-  v.raw = b->d_raw;
-  v.n = (uint32_t)b->nnz;
-  v.max_index = max_index;
-  v.P = P;
-  v.ntiles = (int)((b->nnz + LOC_TILE - 1) / LOC_TILE);
-  v.force_global = b->force_sort_fallback ? 1 : 0;
-  v.smp_key = b->d_smp_key;
-  v.smp_pos = b->d_smp_pos;
-  v.smp_rank = b->d_smp_rank;
-  v.spl_key = b->d_spl_key;
-  v.spl_pos = b->d_spl_pos;
-  v.packed = b->d_packed;
-  v.run_off = b->d_run_off;
-  v.btotal = b->d_btotal;
-  v.bstart = b->d_bstart;
-  v.bkeys = b->d_keys;
-  v.bpos = b->d_bpos;
-  v.skeys = b->d_skeys;
-  v.spos = b->d_spos;
-  v.first_key = b->d_first_key;
-  v.last_key = b->d_last_key;
-  v.nheads = b->d_nheads;
-  v.lh = b->d_lh;
-  J.nrows = (uint32_t)b->nrows;
-  J.offset = b->d_offset;
-  J.rowid = b->d_pos;
-  J.value = b->has_value ? b->d_value : (const float*)nullptr;
-  J.feaids = b->d_feaids;
-  J.col_ptr = b->d_col_ptr;
-  J.index = b->d_index;
-  J.s_row = b->d_s_row;
-  J.s_val = b->d_s_val;
-  J.d_U = b->d_U;
-  J.sl.mid = b->d_mid;
-  J.sl.mid_ent = b->d_mid_ent;
-  J.sl.hot = b->d_hot;
-  J.sl.hot_ent = b->d_hot_ent;
-  J.sl.few = b->d_few;
-  J.sl.few_ent = b->d_few_ent;
-  return J;
-}
-
-#ifndef DFH_LOC_GRID_CAP
-#define DFH_LOC_GRID_CAP 1024
-#endif
-// the four launches of the sample sort for nj (1 or 2) minibatches whose splitters are in place, on stream s
-void loc_launch(const LocJobs& js, int nj, hipStream_t s) {
-  int tiles = 0, P = 0;
-  for (int i = 0; i < nj; ++i) {
-    tiles = std::max(tiles, js.j[i].v.ntiles);
-    P = std::max(P, js.j[i].v.P);
-  }
-  const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
-  hipLaunchKernelGGL(k_loc_count, dim3(tiles, nj), dim3(LOC_TILE_THREADS), 0, s, js);
-  hipLaunchKernelGGL(k_loc_scatter, dim3(tiles, nj), dim3(LOC_TILE_THREADS), 0, s, js);
-  hipLaunchKernelGGL(k_loc_sort, dim3(gsort, nj), dim3(LOC_SORT_THREADS), 0, s, js);
-  hipLaunchKernelGGL(k_loc_emit, dim3(gsort, nj), dim3(LOC_EMIT_THREADS), 0, s, js);
-}
-}  // namespace
-
 int dfh_localize(dfh_batch* b, uint64_t max_index) {
   DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
   DFH_ARG(max_index != 0, "max_index must be nonzero");
@@ -1917,22 +1837,72 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   }
   const int g = grid_for_threads(N, c);
   TimeScope* tsp = new TimeScope(c, DFH_K_LOCALIZE, s);
+  // bucket count: the stored splitters' while the average bucket stays in a sane range (they
+  // describe the data distribution, not this minibatch), else sized for this minibatch and
+  // bootstrapped from a sample
+  int P = 0;
   bool cold = true;
-  const int P = loc_buckets(b, &cold);
+  if (b->spl_P > 0 && N / (uint32_t)b->spl_P >= (uint32_t)LOC_MIN_AVG && N / (uint32_t)b->spl_P <= (uint32_t)LOC_MAX_AVG) {
+    P = b->spl_P;
+    cold = false;
+  } else {
+    const size_t P_want = (N + LOC_AVG_BUCKET - 1) / LOC_AVG_BUCKET;
+    P = P_want <= (size_t)LOC_MAX_BUCKETS ? (int)std::max<size_t>(1, P_want) : 0;
+    if (P == 0 && N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
+  }
   if (P > 0 && !b->force_radix) {
     // hand-written sample sort (dfh_localize.hip)
-    LocJobs js;
-    js.j[0] = loc_job(b, max_index, P);
-    js.j[1] = js.j[0];
+    LocView v;
+    v.raw = b->d_raw;
+    v.n = N;
+    v.max_index = max_index;
+    v.P = P;
+    v.ntiles = (int)((N + LOC_TILE - 1) / LOC_TILE);
+    v.force_global = b->force_sort_fallback ? 1 : 0;
+    v.smp_key = b->d_smp_key;
+    v.smp_pos = b->d_smp_pos;
+    v.smp_rank = b->d_smp_rank;
+    v.spl_key = b->d_spl_key;
+    v.spl_pos = b->d_spl_pos;
+    v.packed = b->d_packed;
+    v.run_off = b->d_run_off;
+    v.btotal = b->d_btotal;
+    v.bstart = b->d_bstart;
+    v.bkeys = b->d_keys;
+    v.bpos = b->d_bpos;
+    v.skeys = b->d_skeys;
+    v.spos = b->d_spos;
+    v.first_key = b->d_first_key;
+    v.last_key = b->d_last_key;
+    v.nheads = b->d_nheads;
+    v.lh = b->d_lh;
+    SegListsOut sl;
+    sl.mid = b->d_mid;
+    sl.mid_ent = b->d_mid_ent;
+    sl.hot = b->d_hot;
+    sl.hot_ent = b->d_hot_ent;
+    sl.few = b->d_few;
+    sl.few_ent = b->d_few_ent;
     if (cold && P > 1) {
-      const LocView& v = js.j[0].v;
       const uint32_t S = (uint32_t)P * LOC_OVERSAMPLE;
       const uint32_t nt = (S + 255) / 256;
       hipLaunchKernelGGL(k_ss_sample, dim3(nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    loc_launch(js, 1, s);
+    hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+#ifdef DFH_LOC_USE_SCAN
+    hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
+#endif
+    hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+#ifndef DFH_LOC_GRID_CAP
+#define DFH_LOC_GRID_CAP 1024
+#endif
+    const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
+    hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
+    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
+                       b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                       b->d_s_val, b->d_U, sl);
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
   } else {
@@ -1957,63 +1927,6 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
   b->localized = true;
   b->has_cnt = false;
   return prep_end(b);
-}
-
-// Localizer::Compact for TWO loaded minibatches in ONE set of launches (dfh_localize_multi): the passes of the sample sort
-// are chains of dependent round trips on ~5 MB — a second minibatch rides along for little more than the time of one,
-// and the preparation stream issues half as many launches.  Falls back to one dfh_localize per minibatch whenever one of
-// them is not in the sample sort's steady state (empty, first call, splitters out of range, forced radix path).
-int dfh_localize_multi(dfh_batch** bs, int n, uint64_t max_index) {
-  DFH_ARG(bs && n >= 1 && n <= LOC_MULTI, "dfh_localize_multi: 1 or 2 batches");
-  DFH_ARG(max_index != 0, "max_index must be nonzero");
-  bool fast = n == LOC_MULTI;
-  int Ps[LOC_MULTI] = {0, 0};
-  for (int i = 0; i < n; ++i) {
-    DFH_ARG(bs[i] && bs[i]->nrows > 0, "dfh_localize_multi: no batch loaded");
-    DFH_ARG(bs[i]->ctx == bs[0]->ctx && (i == 0 || bs[i] != bs[0]), "dfh_localize_multi: distinct batches of one context");
-    bool cold = true;
-    Ps[i] = bs[i]->nnz ? loc_buckets(bs[i], &cold) : 0;
-    fast = fast && bs[i]->nnz > 0 && Ps[i] > 0 && !cold && !bs[i]->force_radix;
-  }
-  if (!fast) {
-    for (int i = 0; i < n; ++i) {
-      int rc = dfh_localize(bs[i], max_index);
-      if (rc) return rc;
-    }
-    return DFH_OK;
-  }
-  dfh_ctx* c = bs[0]->ctx;
-  DFH_HIP(hipSetDevice(c->device));
-  int rc = prep_begin(bs[0]);
-  if (rc) return rc;
-  rc = prep_begin(bs[1]);
-  if (rc) return rc;
-  hipStream_t s = prep_of(bs[0]);
-  if (prep_of(bs[1]) != s) {  // their copies were queued on different preparation streams: keep each on its own
-    for (int i = 0; i < n; ++i) {
-      rc = dfh_localize(bs[i], max_index);
-      if (rc) return rc;
-    }
-    return DFH_OK;
-  }
-  LocJobs js;
-  for (int i = 0; i < n; ++i) js.j[i] = loc_job(bs[i], max_index, Ps[i]);
-  {
-    TimeScope ts(c, DFH_K_LOCALIZE, s);
-    loc_launch(js, n, s);
-  }
-  DFH_HIP(hipGetLastError());
-  for (int i = 0; i < n; ++i) {
-    dfh_batch* b = bs[i];
-    b->looked_up = nullptr;
-    b->spl_P = Ps[i];
-    b->seg_nb = (uint32_t)Ps[i];
-    b->localized = true;
-    b->has_cnt = false;
-    rc = prep_end(b);
-    if (rc) return rc;
-  }
-  return DFH_OK;
 }
 
 int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {
@@ -2058,50 +1971,6 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   DFH_HIP(hipGetLastError());
   b->looked_up = t;
   return prep_end(b);
-}
-
-// dfh_batch_lookup for two minibatches in one launch (they must share a preparation stream, as after dfh_localize_multi)
-int dfh_batch_lookup_multi(dfh_table* t, dfh_batch** bs, int n) {
-  DFH_ARG(t && bs && n >= 1 && n <= 2, "dfh_batch_lookup_multi: 1 or 2 batches");
-  bool fast = n == 2;
-  for (int i = 0; i < n; ++i) {
-    DFH_ARG(bs[i] && bs[i]->ctx == t->ctx, "dfh_batch_lookup_multi: bad argument");
-    if (!bs[i]->localized) {
-      set_error("dfh_batch_lookup_multi: batch is not localized");
-      return DFH_ERR_STATE;
-    }
-    fast = fast && bs[i]->nnz > 0;
-  }
-  fast = fast && bs[0] != bs[1] && prep_of(bs[0]) == prep_of(bs[1]);
-  if (!fast) {
-    for (int i = 0; i < n; ++i) {
-      int rc = dfh_batch_lookup(t, bs[i]);
-      if (rc) return rc;
-    }
-    return DFH_OK;
-  }
-  dfh_ctx* c = t->ctx;
-  DFH_HIP(hipSetDevice(c->device));
-  ProbeJobs js;
-  size_t nmax = 0;
-  for (int i = 0; i < n; ++i) {
-    int rc = prep_begin(bs[i]);
-    if (rc) return rc;
-    js.j[i] = ProbeJob{bs[i]->d_feaids, bs[i]->d_U, bs[i]->d_urow};
-    nmax = std::max(nmax, bs[i]->nnz);
-  }
-  {
-    hipStream_t ps = prep_of(bs[0]);
-    TimeScope ts(c, DFH_K_LOOKUP, ps);
-    hipLaunchKernelGGL(k_probe_multi, dim3(grid_for_threads(nmax, c), n), dim3(256), 0, ps, t->v, js);
-  }
-  DFH_HIP(hipGetLastError());
-  for (int i = 0; i < n; ++i) {
-    bs[i]->looked_up = t;
-    int rc = prep_end(bs[i]);
-    if (rc) return rc;
-  }
-  return DFH_OK;
 }
 
 int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index, const float* value,

@@ -288,22 +288,6 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
   }
 }
 
-// the key-index probe of k_lookup alone (rows_known = 0, no count push, no {row, w}) for TWO minibatches in one launch
-// (dfh_batch_lookup_multi): blockIdx.y picks the minibatch
-struct ProbeJob {
-  const uint64_t* keys;
-  const uint32_t* d_n;
-  uint32_t* urow;
-};
-struct ProbeJobs {
-  ProbeJob j[2];
-};
-__global__ void k_probe_multi(TableView t, ProbeJobs js) {
-  const ProbeJob& J = js.j[blockIdx.y];
-  const uint32_t n = *J.d_n;
-  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) J.urow[u] = find_or_insert(t, J.keys[u]);
-}
-
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
 // the pulled-rows buffer belongs to key u; the slots of this rank's own keys [lo, hi) are unused)
 __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,

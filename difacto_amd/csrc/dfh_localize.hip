@@ -111,31 +111,6 @@ struct SegListsOut {
   uint32_t* few_ent;
 };
 
-// Everything one minibatch's four launches need.  The kernels take TWO of them and pick by blockIdx.y: a launch may
-// serve two minibatches at once (dfh_localize_multi) — the passes are chains of dependent round trips on 5 MB of data,
-// far from filling the chip, so a second minibatch rides along for little more than the time of one, and the
-// preparation stream issues half as many launches.
-struct LocJob {
-  LocView v;
-  // count's side job: row of every nnz position
-  uint32_t nrows;
-  const uint32_t* offset;
-  uint32_t* rowid;
-  // emit's outputs
-  const float* value;
-  uint64_t* feaids;
-  uint32_t* col_ptr;
-  uint32_t* index;
-  uint32_t* s_row;
-  float* s_val;
-  uint32_t* d_U;
-  SegListsOut sl;
-};
-constexpr int LOC_MULTI = 2;
-struct LocJobs {
-  LocJob j[LOC_MULTI];
-};
-
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
 // default max_index = 2^64-1 (x % (2^64-1) is x, except the all-ones id which maps to 0)
 __device__ __forceinline__ uint64_t make_key(uint64_t id, uint64_t max_index) {
@@ -263,13 +238,8 @@ __global__ void __launch_bounds__(256) k_loc_splitters(LocView v) {
 // ---------------------------------------------------------------------------------------
 // count: bucket + rank-in-(tile, bucket) of every pair; the tile's runs reserve their places
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocJobs js) {
-  const LocJob& J = js.j[blockIdx.y];
-  const LocView& v = J.v;
-  if ((int)blockIdx.x >= v.ntiles) return;  // the other minibatch of the launch has more tiles
-  const uint32_t nrows = J.nrows;
-  const uint32_t* __restrict__ offset = J.offset;
-  uint32_t* __restrict__ rowid = J.rowid;
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
+                                                                uint32_t* __restrict__ rowid) {
   __shared__ uint64_t sk[LOC_MAX_BUCKETS];
   __shared__ uint32_t sp[LOC_MAX_BUCKETS];
   __shared__ uint32_t hist[LOC_MAX_BUCKETS];
@@ -289,7 +259,7 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocJobs js) {
   // side job, independent of the sort until k_loc_emit: rowid[pos] = row of nnz position pos,
   // this block's share of the rows
   {
-    const uint32_t rpb = (nrows + (uint32_t)v.ntiles - 1) / (uint32_t)v.ntiles;
+    const uint32_t rpb = (nrows + gridDim.x - 1) / gridDim.x;
     const uint32_t r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
       const uint32_t e = offset[r + 1];
@@ -376,9 +346,7 @@ __global__ void __launch_bounds__(256) k_loc_scan(LocView v) {
 
 // ---- scatter into bucket-major order; every block derives the bucket starts from the totals
 // (block 0 publishes them)
-__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocJobs js) {
-  const LocView& v = js.j[blockIdx.y].v;
-  if ((int)blockIdx.x >= v.ntiles) return;
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
   __shared__ uint32_t off[LOC_MAX_BUCKETS];
   __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
   const int P = v.P;
@@ -585,8 +553,7 @@ __device__ __forceinline__ BucketSummary loc_bucket_summary(const uint64_t* sk, 
 }
 
 // ---- sort one bucket; summary of its runs of equal keys (four-launch form)
-__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocJobs js) {
-  const LocView& v = js.j[blockIdx.y].v;
+__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
   __shared__ uint64_t ak[LOC_LDS_CAP];
   __shared__ uint32_t ap[LOC_LDS_CAP];
   __shared__ uint64_t bk[LOC_LDS_CAP];
@@ -712,18 +679,11 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
   }
 }
 
-__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocJobs js) {
-  const LocJob& J = js.j[blockIdx.y];
-  const LocView& v = J.v;
-  const uint32_t* __restrict__ rowid = J.rowid;
-  const float* __restrict__ value = J.value;
-  uint64_t* __restrict__ feaids = J.feaids;
-  uint32_t* __restrict__ col_ptr = J.col_ptr;
-  uint32_t* __restrict__ index = J.index;
-  uint32_t* __restrict__ s_row = J.s_row;
-  float* __restrict__ s_val = J.s_val;
-  uint32_t* __restrict__ d_U = J.d_U;
-  const SegListsOut sl = J.sl;
+__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const uint32_t* __restrict__ rowid,
+                                                                const float* __restrict__ value, uint64_t* __restrict__ feaids,
+                                                                uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
+                                                                uint32_t* __restrict__ s_row, float* __restrict__ s_val,
+                                                                uint32_t* __restrict__ d_U, SegListsOut sl) {
   constexpr int NW = LOC_EMIT_THREADS / 64;
   __shared__ uint32_t wsum[NW], wmax[NW];
   __shared__ uint32_t sh_cont, n_mid, n_hot, n_few;

@@ -202,11 +202,6 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
  * index per nnz — bit-exact with the reference — plus the key-ordered view the
  * backward pass's segmented sum walks. */
 int dfh_localize(dfh_batch* b, uint64_t max_index);
-/* The same for TWO loaded minibatches in one set of launches (each kernel serves both, picked by blockIdx.y): the passes
- * are chains of dependent round trips on a few MB, so the second minibatch costs little more than nothing and the
- * preparation stream issues half as many launches.  Identical results; falls back to one dfh_localize per minibatch when
- * either is not in the sample sort's steady state or they sit on different preparation streams.  n = 1 or 2. */
-int dfh_localize_multi(dfh_batch** bs, int n, uint64_t max_index);
 /* dfh_localize is a pure function of the minibatch, but a batch object remembers the exact quantiles
  * of the last minibatch it localized and partitions the next one with them (consecutive minibatches
  * of one stream share their key distribution); they affect speed only, never the result.
@@ -223,7 +218,6 @@ int dfh_batch_set_option(dfh_batch* b, const char* name, int value);
  * with the preparation work, and the step's own pass over the keys (count push, current w) finds
  * the rows known.  Optional: dfh_sgd_step probes itself when this was not called. */
 int dfh_batch_lookup(dfh_table* t, dfh_batch* b);
-int dfh_batch_lookup_multi(dfh_table* t, dfh_batch** bs, int n);  /* one launch for two minibatches (see dfh_localize_multi) */
 
 /* already-localized batch from the host (what SGDLearner hands its batch thread,
  * src/sgd/sgd_learner.cc:203-212): feaids sorted unique, compact u32 index */

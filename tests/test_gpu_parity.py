@@ -1036,55 +1036,3 @@ def test_golden_lbfgs_trajectories_on_device(capi, ctx, oracle, rcv1, case):
     else:
         got = LB.run(loss_grad, loc["U"], 5, 0.1, 0.01, 5, 19, init=LB.withv_initializer)
         assert np.max(np.abs(np.array(got) - np.array(LB.WITHV_OBJV))) < 1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_localize_multi_two_minibatches_per_launch(capi, oracle, pipelined):
-    """dfh_localize_multi / dfh_batch_lookup_multi: every Localizer launch serves TWO minibatches (blockIdx.y picks the
-    job).  A stream of pairs through two batch objects — different sizes, one with values, stale splitters, a pair that must
-    fall back (first call: cold splitters) — must stay bit-exact against Localizer::Compact, and the steps that follow must
-    train exactly like steps prepared one by one."""
-    from difacto_amd import synth
-    rng = np.random.default_rng(19)
-    gen = synth.CriteoSynth(total_ids=300000, seed=4)
-    ctx = capi.Context(0)
-    if pipelined:
-        ctx.set_pipeline(1)
-    kw = dict(l1=0.01, lr=0.1, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=3)
-    ta = capi.Table(ctx, 1 << 18, V_dim=8, **kw)
-    tb = capi.Table(ctx, 1 << 18, V_dim=8, **kw)
-
-    def valued(nr):
-        b = random_batch(rng, nr, 2 ** 40, 39, empty_rows=False)
-        return b
-
-    pairs = [(gen.batch(2000), gen.batch(2000)), (gen.batch(2000), gen.batch(1500)), (valued(1200), gen.batch(2000)),
-             (gen.batch(2000), gen.batch(2000)), (gen.batch(700), gen.batch(2000))]
-    cap = max(int(b["offset"][-1]) for p in pairs for b in p)
-    A = [capi.Batch(ctx, 2000, cap) for _ in range(2)]   # prepared in pairs
-    S = [capi.Batch(ctx, 2000, cap) for _ in range(2)]   # prepared one by one
-    for p in pairs:
-        for q in range(2):
-            for bt in (A[q], S[q]):
-                bt.load_host(p[q]["offset"], p[q]["index"], p[q]["value"], p[q]["label"])
-        capi.localize_multi(A)
-        capi.lookup_multi(ta, A)
-        for q in range(2):
-            S[q].localize()
-            S[q].lookup(tb)
-        for q in range(2):
-            want = oracle.localize(p[q]["offset"], p[q]["index"])
-            got = A[q].get_localized()
-            assert got["U"] == want["U"] and np.array_equal(got["feaids"], want["feaids"])
-            assert np.array_equal(got["feacnt"], want["feacnt"]) and np.array_equal(got["index"], want["index"])
-            A[q].sgd_step(ta, is_train=True, push_cnt=True)
-            S[q].sgd_step(tb, is_train=True, push_cnt=True)
-            assert np.array_equal(A[q].pred(), S[q].pred())
-    ea, eb = ta.export(), tb.export()
-    oa, ob_ = np.argsort(ea["keys"]), np.argsort(eb["keys"])
-    assert np.array_equal(ea["keys"][oa], eb["keys"][ob_]) and np.array_equal(ea["scal"][oa], eb["scal"][ob_])
-    assert np.array_equal(ea["V"][oa], eb["V"][ob_])
-    for o in A + S + [ta, tb]:
-        o.close()
-    ctx.close()
