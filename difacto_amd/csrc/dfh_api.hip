@@ -481,7 +481,7 @@ int launch_auc(dfh_batch* b) {
 
 // the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
 // step's k_lookup left per unique key
-int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg) {
+int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt) {
   dfh_ctx* c = b->ctx;
   hipStream_t s = c->stream;
   const int L = lanes_for(kp);
@@ -492,6 +492,7 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   a.uw = uw;
   a.col_ptr = b->d_col_ptr;
   a.feaids = b->d_feaids;
+  a.feacnt = (add_cnt && b->has_cnt) ? b->d_feacnt : nullptr;
   a.s_row = b->d_s_row;
   a.s_val = b->has_value ? b->d_s_val : nullptr;
   a.slope = b->d_slope;
@@ -546,8 +547,8 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
 
 template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
-                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr) {
-  if (FUSED && src.urow && uw && b->ctx->upd_kernel) return launch_update_fused(b, tv, k, kp, need, uw, rg);
+                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr, bool add_cnt = false) {
+  if (FUSED && src.urow && uw && b->ctx->upd_kernel) return launch_update_fused(b, tv, k, kp, need, uw, rg, add_cnt);
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
@@ -810,8 +811,8 @@ int dfh_memcpy_d2h(dfh_ctx* c, void* dst, const void* src, size_t bytes) {
 int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out) {
   DFH_ARG(c && p && out, "dfh_table_create: NULL argument");
   DFH_ARG(p->V_dim >= 0 && p->V_dim <= 10000, "V_dim out of range [0, 10000] (FMLossParam, fm_loss.h:25)");
-  // the two top bits of a row word carry flags (kRemoteRow, kSingleRow); 2^30 rows of V_dim 64 would be 560 GB
-  DFH_ARG(capacity_rows >= 1 && capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^30)");
+  // the three top bits of a row word carry flags (kRemoteRow, kSingleRow, kCountLater); 2^29 rows of V_dim 64 would be 300 GB
+  DFH_ARG(capacity_rows >= 1 && capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^29)");
   DFH_ARG(p->lr > 0, "lr must be > 0");
   DFH_ARG(p->init_mode == DFH_INIT_HASH || p->init_mode == DFH_INIT_REFRAND, "bad init_mode");
   DFH_HIP(hipSetDevice(c->device));
@@ -2168,10 +2169,13 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   // stream), so that the forward touches nothing of a row but its V lines.
   const bool pre = b->looked_up == t;
   uint2* uw = b->d_uw;
+  // a training step's update kernel rewrites every key's header: it takes the count push of the keys that have their V
+  // along (k_lookup then only reads them)
+  const bool defer_cnt = push_cnt && is_train && c->upd_kernel != 0;
   {
     TimeScope ts(c, DFH_K_LOOKUP);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
-                       b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? 1 : 0,
+                       b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
                        refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw);
   }
   DFH_HIP(hipGetLastError());
@@ -2188,7 +2192,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   }
   if (is_train) {
     if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
-    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw);
+    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw, defer_cnt);
     if (rc) return rc;
     if (refrand) {
       rc = refrand_flush(t, b->d_feaids, b->d_U, Nb, b->d_urow, b->d_need, b->d_rank, b->d_total);

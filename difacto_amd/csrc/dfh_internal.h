@@ -74,10 +74,11 @@ struct SegLists {
 };
 
 // flag bits of the row word k_lookup / k_uw_remote leave per unique key in uw[]: a table holds fewer
-// than 2^30 rows (dfh_table_create), so the two top bits are free
+// than 2^29 rows (dfh_table_create), so the three top bits are free
 constexpr uint32_t kRemoteRow = 0x80000000u;  // the row is in the pulled-rows buffer, not in the table (sharded store)
 constexpr uint32_t kSingleRow = 0x40000000u;  // the key occurs exactly once in this minibatch
-constexpr uint32_t kRowMask = 0x3FFFFFFFu;
+constexpr uint32_t kCountLater = 0x20000000u; // k_lookup left this key's Push(kFeaCount) to the step's update kernel
+constexpr uint32_t kRowMask = 0x1FFFFFFFu;
 
 // "row source" seen by the forward / backward kernels: either the table
 // itself (rows addressed through urow[u]) or a packed [U x stride] buffer of

@@ -262,9 +262,18 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
     if (push_cnt) {
       float c = cnt ? cnt[u] : (float)(col_ptr[u + 1] - col_ptr[u]);
       RowHdr& h = t.hdr[r];
+      w = h.w;
+      // push_cnt == 2: a training step follows whose update kernel rewrites this header anyway.  A key that HAS its V can
+      // take its count there (k_update_fused adds it): nothing reads fea_cnt of such a key again — it only gates InitV
+      // (sgd_updater.cc:62-73, :122-126) — so the value is the same and this pass stays read-only for it.
+      if (push_cnt == 2 && uw && h.has_V != 0) {
+        if (need_init) need_init[u] = 0u;
+        uw[u] = make_uint2(r | kCountLater | ((col_ptr != nullptr && col_ptr[u + 1] - col_ptr[u] == 1u) ? kSingleRow : 0u),
+                           __float_as_uint(w));
+        continue;
+      }
       float fc = h.fea_cnt + c;
       h.fea_cnt = fc;
-      w = h.w;
       bool init = t.k > 0 && h.has_V == 0 && w != 0 && fc > (float)t.p.V_threshold;
       if (t.p.init_mode == DFH_INIT_HASH) {
         if (init) {
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
           // {row, w} of the key from the batch-local table k_lookup left in L2: no header access;
           // a row without V holds zeros, so its flag is not needed either
           const uint2 e = b.uw[b.index[j]];
-          r = e.x & ~kSingleRow;
+          r = e.x & ~(kSingleRow | kCountLater);
           hv = 1u;
           wsum += __uint_as_float(e.y) * x;
         } else {

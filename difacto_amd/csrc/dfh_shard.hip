@@ -841,8 +841,8 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     const bool counts = push_cnt != 0;
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
                        W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
-                       (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo, counts ? 1 : 0,
-                       (uint32_t*)nullptr, 0, b->d_uw + own_lo);
+                       (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo,
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo);
     DFH_HIP(hipGetLastError());
   }
   // ---- K: the other keys (+ counts in epoch 0) to their owners.  Two message groups, one send and one receive
@@ -916,7 +916,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       if (rc) return rc;
     }
     if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw);
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0);
       if (rc) return rc;
     } else if (any_own) {
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
@@ -1023,7 +1023,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
                        (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr, b->d_col_ptr + cur.own_lo,
-                       counts ? 1 : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo);
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo);
     DFH_HIP(hipGetLastError());
   }
   if (!cur.pulled) {  // pipeline fill: K, R, RW of this very minibatch, in the sync step's order (after L)
@@ -1078,7 +1078,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (is_train && cur.any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw);
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0);
       if (rc) return rc;
     } else if (cur.any_own) {
       BatchView bv = batch_view(b);

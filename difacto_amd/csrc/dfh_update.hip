@@ -62,6 +62,7 @@ struct UpdArgs {
   const uint2* uw;          // [U] {table row | kSingleRow, w} as of this step's k_lookup
   const uint32_t* col_ptr;  // [U + 1] segment starts in the key-ordered view
   const uint64_t* feaids;   // [U]
+  const float* feacnt;      // add_cnt: explicit occurrence counts per key, or NULL (the segment lengths)
   // key-ordered view
   const uint32_t* s_row;    // [nnz]
   const float* s_val;       // [nnz] or NULL
@@ -102,7 +103,8 @@ __device__ __forceinline__ uint32_t ld_rowword(const uint2* p) {  // .x of {row 
 // accumulator slices; g4: sum of (XV p) x over the occurrences.
 template <bool EXACT>
 __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t u, const float4 h0, const float4 vv, const float4 ac,
-                                          float gw, float xxp, float4 g4, int sub, bool sub_ok, int k, int kp, float& pen) {
+                                          float gw, float xxp, float4 g4, int sub, bool sub_ok, int k, int kp, float& pen, float fc,
+                                          float cnt, bool cnt_later) {
   const float w_old = h0.x;
   const bool has_v = k > 0 && __float_as_uint(h0.y) != 0u;
   RowHdr* hp = a.hdr + r;
@@ -118,8 +120,11 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
     float sqrt_g = h0.z, z = h0.w;
     const float w_new = ftrl_update_w(gw, w_old, sqrt_g, z, a.p);
     uint32_t hv = has_v ? 1u : 0u;
-    // lazy InitV when w leaves zero (sgd_updater.cc:122-126); fea_cnt is read only here
-    if (w_old == 0 && w_new != 0 && k > 0 && !has_v && hp->fea_cnt > (float)a.p.V_threshold) {
+    // Push(kFeaCount) of a key that has its V, left to this kernel by k_lookup (sgd_updater.cc:62-73: fea_cnt += cnt; the
+    // InitV test there cannot fire for it)
+    if (cnt_later) hp->fea_cnt = fc + (a.feacnt ? a.feacnt[u] : cnt);
+    // lazy InitV when w leaves zero (sgd_updater.cc:122-126); a key without V had its count pushed by k_lookup
+    if (w_old == 0 && w_new != 0 && k > 0 && !has_v && fc > (float)a.p.V_threshold) {
       if (a.p.init_mode == DFH_INIT_HASH) {
         const uint64_t key = a.feaids[u];
         for (int j = 0; j < kp; ++j) {
@@ -158,8 +163,9 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
 // time.  Lanes with nothing to fetch read a valid address instead (row 0, their group's last row, the
 // row's first slice) and never use what arrives.
 __device__ __forceinline__ void upd_load_row(const UpdArgs& a, uint32_t r, int sub, bool sub_ok, int kp, float4& h0, float4& vv,
-                                             float4& ac) {
+                                             float4& ac, float& fc) {
   const float* va = a.va + (size_t)r * (size_t)(2 * kp) + (sub_ok ? sub * 4 : 0);
+  fc = a.hdr[r].fea_cnt;  // same 128 B line as h0
   h0 = DFH_UPD_NT ? ld4_nt(reinterpret_cast<const float*>(a.hdr + r)) : ld4(reinterpret_cast<const float*>(a.hdr + r));
   vv = ld4_nt(va);
   ac = ld4_nt(va + kp);
@@ -254,7 +260,8 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
       const uint32_t u = ldu_s(ent + q);
       if (!key_in(a.rg, u)) continue;  // uniform per block
       const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
-      const uint32_t r = ld_rowword(a.uw + u) & kRowMask;
+      const uint32_t rw = ld_rowword(a.uw + u);
+      const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
       __syncthreads();  // the previous key's partials have been consumed
       if (grp == 0) {
@@ -267,7 +274,8 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
       __syncthreads();
       if (w == 0 && grp == 0) {
         float4 h0, vv, ac;
-        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
+        float fc;
+        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
         float gw = 0.f, xxp = 0.f;
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -279,7 +287,7 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
             g4.z += part[i][2 + sub * 4 + 2]; g4.w += part[i][2 + sub * 4 + 3];
           }
         }
-        upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen);
+        upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)(end - beg), (rw & kCountLater) != 0u);
       }
     }
   }
@@ -302,14 +310,17 @@ __device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, ui
       const uint32_t u = ldu_s(ent + q);
       if (!key_in(a.rg, u)) continue;  // uniform per wave
       const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
-      const uint32_t r = ld_rowword(a.uw + u) & kRowMask;
+      const uint32_t rw = ld_rowword(a.uw + u);
+      const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, 0u, 1u, grp, sub, sub_ok, k, kp);
       // the key's row is fetched after the sums: one more round trip for a segment of 9+ occurrences,
       // 12 registers fewer alive through the tile
       if (grp == 0) {
         float4 h0, vv, ac;
-        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
-        upd_apply<EXACT>(a, r, u, h0, vv, ac, s.gw, s.xxp, s.gv, sub, sub_ok, k, kp, pen);
+        float fc;
+        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
+        upd_apply<EXACT>(a, r, u, h0, vv, ac, s.gw, s.xxp, s.gv, sub, sub_ok, k, kp, pen, fc, (float)(end - beg),
+                         (rw & kCountLater) != 0u);
       }
     }
   }
@@ -346,7 +357,8 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
       const uint32_t r = (act && (rw & kRemoteRow) == 0u) ? (rw & kRowMask) : 0u;
       // round trip 2: the model row and the first occurrences, back to back
       float4 h0, vv, ac;
-      upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac);
+      float fc;
+      upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
       float gw = 0.f, xxp = 0.f;
       float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (uint32_t j0 = 0; __ballot(j0 < len) != 0ull; j0 += FD) {
@@ -374,7 +386,7 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
           g4.z += (av[d].z * pp) * xx; g4.w += (av[d].w * pp) * xx;
         }
       }
-      if (act) upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen);
+      if (act) upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)len_all, (rw & kCountLater) != 0u);
     }
   }
 }
@@ -407,20 +419,20 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
       // others are packed behind them)
       const int rank = __popcll(mask & ((1ull << lane) - 1ull));
       const int dest = (single ? rank : n1 + (lane - rank)) * 4;
-      const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & kRowMask));
+      const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & (kRowMask | kCountLater)));
       const uint32_t c_u = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)u);
       const float c_x = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(x)));
       for (int t0 = 0; t0 < n1; t0 += RB * G) {
         float4 h0[RB], vv[RB], ac[RB];
         uint32_t rr[RB], uu[RB];
-        float xs[RB];
+        float xs[RB], fcs[RB];
 #pragma unroll
         for (int q = 0; q < RB; ++q) {  // RB * G model rows per round trip; groups past the last key fetch it again
           const int t = min(t0 + q * G + grp, n1 - 1);
           rr[q] = __shfl(c_r, t, 64);
           uu[q] = __shfl(c_u, t, 64);
           xs[q] = __shfl(c_x, t, 64);
-          upd_load_row(a, rr[q], sub, sub_ok, kp, h0[q], vv[q], ac[q]);
+          upd_load_row(a, rr[q] & kRowMask, sub, sub_ok, kp, h0[q], vv[q], ac[q], fcs[q]);
         }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
@@ -429,7 +441,8 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
             // one occurrence: the segmented sums of the other roles with a single term (0 + term)
             const float gw = p * xx, xxp = p * (xx * xx);
             const float4 g4 = make_float4((xvi.x * p) * xx, (xvi.y * p) * xx, (xvi.z * p) * xx, (xvi.w * p) * xx);
-            upd_apply<EXACT>(a, rr[q], uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen);
+            upd_apply<EXACT>(a, rr[q] & kRowMask, uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen, fcs[q], 1.0f,
+                             (rr[q] & kCountLater) != 0u);
           }
         }
       }
