@@ -1860,6 +1860,10 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     v.P = P;
     v.ntiles = (int)((N + LOC_TILE - 1) / LOC_TILE);
     v.force_global = b->force_sort_fallback ? 1 : 0;
+    v.tb = N > 1 ? std::min(16, __builtin_clz(N - 1)) : 16;  // (N - 1) << tb fits 32 bits
+    v.nrows = (uint32_t)b->nrows;
+    v.offset = b->d_offset;
+    v.rowid = b->d_pos;
     v.smp_key = b->d_smp_key;
     v.smp_pos = b->d_smp_pos;
     v.smp_rank = b->d_smp_rank;
@@ -1901,7 +1905,7 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
 #endif
     const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
     hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->d_pos,
+    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
                        b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
                        b->d_s_val, b->d_U, sl);
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters

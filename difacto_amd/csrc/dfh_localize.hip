@@ -79,6 +79,14 @@ struct LocView {
   int P;                  // buckets
   int ntiles;
   int force_global;       // tests: sort every bucket through the global-memory path
+  // The 32-bit tie-break carried through the sort is a TAG: pos << tb | (row of pos) mod 2^tb, tb = clz(N - 1) capped
+  // at 16.  Tags order like positions (pos is unique and sits in the high bits), and k_loc_emit gets the row back from the
+  // tag and `offset` (the rows congruent to the low bits: 2 candidates at C3 size) instead of gathering rowid[pos] from
+  // a 1.5 MB array that every XCD's L2 fetches for itself (12.5 MB of fabric reads per minibatch).
+  int tb;
+  uint32_t nrows;
+  const uint32_t* offset; // [nrows + 1] the minibatch's CSR offsets
+  const uint32_t* rowid;  // [N] row of every position: written by k_loc_count, read (coalesced) by k_loc_scatter
   // bootstrap
   uint64_t* smp_key;      // [P * LOC_OVERSAMPLE] jittered samples of the composite (key, pos)
   uint32_t* smp_pos;
@@ -92,9 +100,9 @@ struct LocView {
   uint32_t* btotal;       // [P] pairs per bucket; zero between calls (k_loc_sort resets it)
   uint32_t* bstart;       // [P + 1]
   uint64_t* bkeys;        // [N] bucket-major keys (unsorted inside a bucket)
-  uint32_t* bpos;         // [N]
+  uint32_t* bpos;         // [N] tags
   uint64_t* skeys;        // [N] sorted keys
-  uint32_t* spos;         // [N] sorted positions
+  uint32_t* spos;         // [N] tags in sorted order
   uint64_t* first_key;    // [P] bucket summaries
   uint64_t* last_key;
   uint32_t* nheads;       // [P] runs of equal keys inside the bucket
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(256) k_ss_sample(LocView v) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
     const uint32_t i = ss_sample_pos(t, stride, v.n);
     v.smp_key[t] = make_key(v.raw[i], v.max_index);
-    v.smp_pos[t] = i;
+    v.smp_pos[t] = i << v.tb;  // a tag with row bits 0: splitters only have to be SOME composite values
     v.smp_rank[t] = 0;
   }
 }
@@ -277,7 +285,9 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
       if (lo[e] < hi[e]) {
         const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
         const int mid = (lo[e] + hi[e]) >> 1;
-        if (comp_less(key[e], i, sk[mid], sp[mid])) hi[e] = mid; else lo[e] = mid + 1;
+        // the pair's own row bits are not known here (another block writes rowid[i]); they only matter for the pair
+        // that IS a splitter, and that one may fall on either side of it
+        if (comp_less(key[e], i << v.tb, sk[mid], sp[mid])) hi[e] = mid; else lo[e] = mid + 1;
       }
     }
   }
@@ -352,12 +362,13 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
   const int P = v.P;
   const uint32_t base = blockIdx.x * LOC_TILE;
   uint64_t raw[LOC_PER_THREAD];
-  uint32_t pk[LOC_PER_THREAD];
+  uint32_t pk[LOC_PER_THREAD], rw[LOC_PER_THREAD];
 #pragma unroll
   for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
-    raw[e] = i < v.n ? v.raw[i] : 0;
-    pk[e] = i < v.n ? v.packed[i] : 0;
+    const uint32_t i = min(base + e * LOC_TILE_THREADS + threadIdx.x, v.n - 1);  // clamped: the loads stay unconditional
+    raw[e] = v.raw[i];
+    pk[e] = v.packed[i];
+    rw[e] = v.rowid[i];
   }
   // exclusive scan of the bucket totals: LOC_BPT consecutive buckets per thread
   const int b0 = threadIdx.x * LOC_BPT;
@@ -387,7 +398,7 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
     if (i < v.n) {
       const uint32_t dst = off[pk[e] >> 16] + (pk[e] & 0xFFFFu);
       v.bkeys[dst] = make_key(raw[e], v.max_index);
-      v.bpos[dst] = i;
+      v.bpos[dst] = (i << v.tb) | (rw[e] & ((1u << v.tb) - 1u));
     }
   }
 }
@@ -610,7 +621,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
 template <int NW>
 __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, uint32_t beg, uint32_t n, const uint64_t* sk,
                                                 const uint32_t* sp, uint32_t cont, uint32_t ubase, uint32_t carry1,
-                                                const uint32_t* __restrict__ rowid, const float* __restrict__ value,
+                                                const float* __restrict__ value,
                                                 uint64_t* __restrict__ feaids, uint32_t* __restrict__ col_ptr,
                                                 uint32_t* __restrict__ index, uint32_t* __restrict__ s_row,
                                                 float* __restrict__ s_val, uint32_t* __restrict__ d_U, const SegListsOut& sl,
@@ -624,13 +635,14 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
     const uint32_t i = beg + t;
     const bool valid = t < n;
     uint64_t key = 0;
-    uint32_t pos = 0;
+    uint32_t tag = 0;
     bool head = false;
     if (valid) {
       key = sk[t];
-      pos = sp[t];
+      tag = sp[t];
       head = t == 0 ? !cont : key != sk[t - 1];
     }
+    const uint32_t pos = tag >> v.tb;
     uint32_t nh, mx;
     const uint32_t ex = block_exclusive_scan<NW>(head ? 1u : 0u, wsum, &nh);
     const uint32_t pm = block_exclusive_max<NW>(head ? i + 1 : 0u, wmax, &mx);
@@ -649,7 +661,11 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
         }
       }
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
-      s_row[i] = rowid[pos];
+      // the row of pos: the largest row congruent to the tag's low bits whose range starts at or before pos
+      uint32_t row = tag & ((1u << v.tb) - 1u);
+      for (uint32_t c = row + (1u << v.tb); c < v.nrows; c += 1u << v.tb)
+        if (v.offset[c] <= pos) row = c;
+      s_row[i] = row;
       if (value) s_val[i] = value[pos];
       if (i == v.n - 1) {  // the end of the minibatch closes the last segment
         *d_U = uid + 1;
@@ -664,7 +680,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
         const uint64_t m = ((uint64_t)i * P + v.n - 1) / v.n;  // smallest m with m * n / P >= i
         if (m >= 1 && m <= P - 1 && (m * v.n) / P == i) {
           v.spl_key[m - 1] = key;
-          v.spl_pos[m - 1] = pos;
+          v.spl_pos[m - 1] = tag;
         }
       }
     }
@@ -679,8 +695,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
   }
 }
 
-__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const uint32_t* __restrict__ rowid,
-                                                                const float* __restrict__ value, uint64_t* __restrict__ feaids,
+__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const float* __restrict__ value, uint64_t* __restrict__ feaids,
                                                                 uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
                                                                 uint32_t* __restrict__ s_row, float* __restrict__ s_val,
                                                                 uint32_t* __restrict__ d_U, SegListsOut sl) {
@@ -725,7 +740,7 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     block_exclusive_scan<NW>(part, wsum, &ubase);
     block_exclusive_max<NW>(carry1, wmax, &carry_all);
     __syncthreads();
-    loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, rowid, value, feaids, col_ptr,
+    loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, value, feaids, col_ptr,
                         index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few);
   }
 }
