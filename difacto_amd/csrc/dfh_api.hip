@@ -1652,7 +1652,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_packed, N, uint32_t);
   DFH_ALLOC(b->d_run_off, b->max_tiles * LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_bstart, LOC_MAX_BUCKETS + 1, uint32_t);
-  DFH_ALLOC(b->d_btotal, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_btotal, LOC_XCDS * LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_nheads, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_lh, LOC_MAX_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
@@ -1689,7 +1689,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipEventCreateWithFlags(&b->ev_free, evf));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
+  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
   DFH_HIP(hipMemsetAsync(b->d_auc_acc, 0, 8 * sizeof(unsigned long long), c->stream));
   // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
   // all-ones makes a stray use fault at once instead of reading some row
@@ -1896,9 +1896,6 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
     hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-#ifdef DFH_LOC_USE_SCAN
-    hipLaunchKernelGGL(k_loc_scan, dim3((P + 63) / 64), dim3(256), 0, s, v);
-#endif
     hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
 #ifndef DFH_LOC_GRID_CAP
 #define DFH_LOC_GRID_CAP 1024

@@ -97,7 +97,11 @@ struct LocView {
   // per call
   uint32_t* packed;       // [N] bucket << 16 | rank-in-(tile, bucket)
   uint32_t* run_off;      // [ntiles * P] offset of every (tile, bucket) run inside its bucket
-  uint32_t* btotal;       // [P] pairs per bucket; zero between calls (k_loc_sort resets it)
+  // [LOC_XCDS][LOC_MAX_BUCKETS] pairs per (XCD group of tiles, bucket); zero between calls (k_loc_sort resets it).
+  // A bucket's area is filled XCD group by XCD group: the ~2-pair runs of the tiles that run on one XCD land next to each
+  // other and merge into whole lines in that XCD's L2 before they are written back (runs of tiles on different XCDs
+  // interleaved in arrival order were written back as one partial line each: 14 MB for 4.7 MB of pairs).
+  uint32_t* btotal;
   uint32_t* bstart;       // [P + 1]
   uint64_t* bkeys;        // [N] bucket-major keys (unsorted inside a bucket)
   uint32_t* bpos;         // [N] tags
@@ -125,6 +129,10 @@ __device__ __forceinline__ uint64_t make_key(uint64_t id, uint64_t max_index) {
   const uint64_t m = (max_index == ~0ULL) ? (id == ~0ULL ? 0ULL : id) : id % max_index;
   return reverse_bytes(m);
 }
+
+// tiles are dealt to the XCDs round robin (workgroup id mod 8); a wrong guess costs write-combining, not correctness
+constexpr int LOC_XCDS = 8;
+__device__ __forceinline__ uint32_t loc_xcd() { return blockIdx.x & (LOC_XCDS - 1); }
 
 __device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t pa, uint64_t kb, uint32_t pb) {
   return ka < kb || (ka == kb && pa < pb);
@@ -305,54 +313,10 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
   // result does not.
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     const uint32_t h = hist[b];
-#ifdef DFH_LOC_USE_SCAN
-    v.run_off[blockIdx.x * P + b] = h;  // per-tile histogram; k_loc_scan turns it into offsets
-#else
-    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[b], h) : 0u;
-#endif
+    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[loc_xcd() * LOC_MAX_BUCKETS + b], h) : 0u;
   }
 }
 
-#ifdef DFH_LOC_USE_SCAN
-// experiment: the deterministic alternative to the atomics — run_off[tile][b] = pairs of bucket b in
-// earlier tiles; btotal[b].  One block per 64 buckets; the block's 4 waves split the tiles.
-__global__ void __launch_bounds__(256) k_loc_scan(LocView v) {
-  __shared__ uint32_t wtot[4][64];
-  const int P = v.P;
-  const int b = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  const int per = (v.ntiles + 3) / 4;
-  const int t_beg = w * per, t_end = min(v.ntiles, t_beg + per);
-  uint32_t* __restrict__ ro = v.run_off;
-  uint32_t sum = 0;
-  if (b < P) {
-    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
-      uint32_t h[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? ro[(t0 + q) * P + b] : 0u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sum += h[q];
-    }
-  }
-  wtot[w][threadIdx.x & 63] = sum;
-  __syncthreads();
-  uint32_t run = 0;
-  for (int q = 0; q < w; ++q) run += wtot[q][threadIdx.x & 63];
-  if (b < P) {
-    for (int t0 = t_beg; t0 < t_end; t0 += 8) {
-      uint32_t h[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = (t0 + q < t_end) ? ro[(t0 + q) * P + b] : 0u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (t0 + q < t_end) ro[(t0 + q) * P + b] = run;
-        run += h[q];
-      }
-    }
-    if (w == 3) v.btotal[b] = run;
-  }
-}
-#endif
 
 // ---- scatter into bucket-major order; every block derives the bucket starts from the totals
 // (block 0 publishes them)
@@ -376,8 +340,19 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
   uint32_t sum = 0;
 #pragma unroll
   for (int q = 0; q < LOC_BPT; ++q) {
-    tt[q] = b0 + q < P ? v.btotal[b0 + q] : 0u;
-    ro[q] = b0 + q < P ? v.run_off[blockIdx.x * P + b0 + q] : 0u;
+    // loads on a clamped bucket, masked afterwards: nine independent loads in flight instead of nine guarded ones
+    const int bb = min(b0 + q, P - 1);
+    const uint32_t in = b0 + q < P ? 1u : 0u;
+    tt[q] = 0;
+    ro[q] = v.run_off[blockIdx.x * P + bb];
+#pragma unroll
+    for (int x = 0; x < LOC_XCDS; ++x) {
+      const uint32_t h = v.btotal[x * LOC_MAX_BUCKETS + bb];
+      tt[q] += h;
+      ro[q] += (x < (int)loc_xcd() ? 1u : 0u) * h;  // the groups before this tile's
+    }
+    tt[q] *= in;
+    ro[q] *= in;
     sum += tt[q];
   }
   uint32_t total;
@@ -576,7 +551,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     __syncthreads();  // LDS of the previous bucket is done with
     const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
     const uint32_t n = end - beg;
-    if (threadIdx.x == 0) v.btotal[b] = 0;  // consumed by k_loc_scatter: ready for the next call
+    if (threadIdx.x < LOC_XCDS) v.btotal[threadIdx.x * LOC_MAX_BUCKETS + b] = 0;  // consumed by k_loc_scatter: ready for the next call
     if (n == 0) {
       if (threadIdx.x == 0) {
         v.nheads[b] = 0;
