@@ -1671,7 +1671,7 @@ __global__ void __launch_bounds__(256) k_warm_start(TableView t, const uint64_t*
     if (lane == 0) r = find_or_insert(t, key);
     r = __shfl(r, 0, 64);
     if (lane == 0) {
-      RowHdr h;
+      RowHdr h = {};
       h.w = w0;
       h.has_V = t.k > 0 ? 1u : 0u;
       h.sqrt_g = 0.f;
@@ -1879,7 +1879,7 @@ __global__ void k_export(TableView t, uint64_t nslots, uint64_t cap, uint64_t* k
 __global__ void k_import(TableView t, uint64_t n, const uint64_t* keys, const float* scal, const int* has_V, const float* V) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t r = find_or_insert(t, keys[i]);
-    RowHdr h;
+    RowHdr h = {};
     h.fea_cnt = scal[i * 4 + 0];
     h.w = scal[i * 4 + 1];
     h.sqrt_g = scal[i * 4 + 2];
