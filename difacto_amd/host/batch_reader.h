@@ -494,6 +494,62 @@ class Reader {
 };
 
 /*! \brief BatchReader (src/reader/batch_reader.{h,cc}) */
+/**
+ * The shuffle buffer's permutation.  The reference calls std::random_shuffle (batch_reader.cc:47), i.e. libstdc++'s
+ * loop `swap(v[i], v[rand() % (i + 1)])` over the process-wide glibc rand() in its default state (seed 1) — its runs
+ * are reproducible because nothing else in that process draws from rand().  In this process other libraries do (the HIP
+ * runtime and RCCL, from their own threads), so the same call gave a different permutation on every run.  RefRand
+ * restates glibc's default generator (random_r TYPE_3: additive feedback r[i] = r[i-3] + r[i-31] over 31 words filled
+ * by the Lehmer step 16807 x mod 2^31-1, the first 310 outputs discarded, result = word >> 1) as a private,
+ * process-wide stream: the permutations are the reference's and the same on every run.  host_tests.cc checks the
+ * stream against rand() after srand(1) and the shuffle against std::random_shuffle.
+ */
+class RefRand {
+ public:
+  explicit RefRand(unsigned seed = 1) { Seed(seed); }
+  void Seed(unsigned seed) {
+    int32_t r[34];
+    r[0] = static_cast<int32_t>(seed ? seed : 1);
+    for (int i = 1; i < 31; ++i) {
+      const int64_t x = (16807LL * r[i - 1]) % 2147483647LL;
+      r[i] = static_cast<int32_t>(x < 0 ? x + 2147483647LL : x);
+    }
+    for (int i = 0; i < 31; ++i) st_[i] = static_cast<uint32_t>(r[i]);
+    f_ = 3;
+    b_ = 0;
+    for (int i = 0; i < 310; ++i) Next();
+  }
+  /*! \brief the next value of rand(): 0 .. RAND_MAX (2^31 - 1) */
+  int Next() {
+    st_[f_] += st_[b_];
+    const int out = static_cast<int>(st_[f_] >> 1);
+    f_ = f_ == 30 ? 0 : f_ + 1;
+    b_ = b_ == 30 ? 0 : b_ + 1;
+    return out;
+  }
+  /*! \brief libstdc++'s std::random_shuffle(first, last) driven by this stream */
+  template <typename T>
+  void Shuffle(std::vector<T>* v) {
+    for (size_t i = 1; i < v->size(); ++i) {
+      const size_t j = static_cast<size_t>(Next()) % (i + 1);
+      if (i != j) std::swap((*v)[i], (*v)[j]);
+    }
+  }
+  /*! \brief the process-wide stream of the batch readers (the reference's rand() state outlives its readers too) */
+  static RefRand* Global() {
+    static RefRand g;
+    return &g;
+  }
+  static std::mutex* GlobalLock() {
+    static std::mutex m;
+    return &m;
+  }
+
+ private:
+  uint32_t st_[31];
+  int f_ = 3, b_ = 0;
+};
+
 class BatchReader {
  public:
   BatchReader(const std::string& uri, const std::string& format, unsigned part_index, unsigned num_parts, unsigned batch_size,
@@ -551,7 +607,10 @@ class BatchReader {
             rdp_.resize(in_blk_.size);
             for (size_t i = 0; i < in_blk_.size; ++i) rdp_[i] = static_cast<unsigned>(i);
           }
-          std::random_shuffle(rdp_.begin(), rdp_.end());  // as the reference: libstdc++'s rand()-driven shuffle
+          {  // the reference's std::random_shuffle on its own rand() stream (RefRand above)
+            std::lock_guard<std::mutex> lk(*RefRand::GlobalLock());
+            RefRand::Global()->Shuffle(&rdp_);
+          }
           t_shuf_ += Now() - f1;
         }
         start_ = 0;

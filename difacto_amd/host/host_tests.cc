@@ -74,6 +74,26 @@ static void TestLocalizer() {
   EXPECT(s == 478817ULL);
 }
 
+// RefRand is glibc's rand() from its default state, RefRand::Shuffle libstdc++'s std::random_shuffle over it
+static void TestRefRand() {
+  srand(1);
+  RefRand g;
+  for (int i = 0; i < 5000; ++i) EXPECT(g.Next() == rand());
+  srand(12345);
+  g.Seed(12345);
+  for (int i = 0; i < 1000; ++i) EXPECT(g.Next() == rand());
+  std::vector<unsigned> a(1000), b(1000);
+  for (unsigned i = 0; i < 1000; ++i) a[i] = b[i] = i;
+  srand(1);
+  g.Seed(1);
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wdeprecated-declarations"
+  std::random_shuffle(a.begin(), a.end());
+#pragma GCC diagnostic pop
+  g.Shuffle(&b);
+  EXPECT(a == b);
+}
+
 // the minibatch checksums of tests/cpp/batch_reader_test.cc:9-57 (batch_size 37 over the 100 rows)
 static void TestBatchReader() {
   const int label[] = {11, 15, 10};
@@ -291,12 +311,15 @@ int main(int argc, char** argv) {
   }
   g_data = argv[1];
   if (argc > 2 && std::string(argv[2]) == "reader") {  // host-only cases: no device is touched
+    TestRefRand();
+    printf("[%s] %s\n", g_fail ? "FAILED" : "  OK  ", "RefRand = glibc rand() / std::random_shuffle");
     TestBatchReader();
     printf("[%s] %s\n", g_fail ? "FAILED" : "  OK  ", "BatchReader.Read+RandRead+PartRead");
     printf("%s\n", g_fail ? "SOME TESTS FAILED" : "ALL HOST TESTS PASSED");
     return g_fail ? 1 : 0;
   }
   struct { const char* name; std::function<void()> fn; } tests[] = {
+      {"RefRand = glibc rand() / std::random_shuffle", TestRefRand},
       {"BatchReader.Read+RandRead+PartRead", TestBatchReader},
       {"Localizer.Base+BaseHash", TestLocalizer},
       {"FMLoss.NoV", TestFMLossNoV},

@@ -117,7 +117,7 @@ def test_literal_predict_accumulates(ctx, oracle):
 # ------------------------------------------------------------------ device Localizer
 @pytest.mark.parametrize("path", ["sample_sort", "radix", "sample_sort_fallback"])
 @pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same", "criteo_like",
-                                  "bias_feature", "sorted_input", "clustered"])
+                                  "bias_feature", "sorted_input", "clustered", "tall_ragged"])
 def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     rng = np.random.default_rng(11)
     mx = U64MAX
@@ -131,6 +131,8 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
         b = random_batch(rng, 2000, 5000, 39, binary=True, empty_rows=False)
     elif case == "one_row":
         b = random_batch(rng, 1, 50, 30, empty_rows=False)
+    elif case == "tall_ragged":
+        b = random_batch(rng, 30000, 2 ** 40, 20)  # ~300 k pairs over 30 000 rows, many of them empty
     elif case == "criteo_like":
         from difacto_amd import synth
         b = synth.CriteoSynth(total_ids=200000, seed=3).batch(3000)  # 117 k pairs, Zipf duplicates, many buckets

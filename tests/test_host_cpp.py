@@ -105,7 +105,7 @@ def test_cli_sharded_store_one_rank_matches_plain_run(built, tmp_path):
     assert plain.returncode == 0 and shard.returncode == 0
     a, b = _losses(plain.stderr), _losses(shard.stderr)
     assert len(a) == len(b) and len(a) >= 2  # the validation-AUC criterion may stop both runs early
-    assert all(abs(x - y) <= 2e-4 * abs(x) for x, y in zip(a, b)), (a, b)
+    assert all(abs(x - y) <= 2e-5 * abs(x) for x, y in zip(a, b)), (a, b)  # same minibatches (RefRand), same kernels
     assert os.path.getsize(os.path.join(tmp_path, "m.part-0")) > 100
 
 
@@ -164,7 +164,7 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
     common = ["task=train", "learner=sgd", "batch_size=500", "max_num_epochs=3", "V_dim=4", "V_threshold=0", "l1=.01", "lr=.1",
               "V_lr=.05", "V_init=hash", "table_capacity=262144", "stop_rel_objv=0",
               "num_jobs_per_epoch=1",   # one data part: byte-range parts of a text file and of a RecordIO file hold different rows
-              "shuffle=0"]              # file order (the shuffle buffer draws from the process-wide rand(), as the reference's)
+              "shuffle=0"]              # file order: the two readers cut the stream into different shuffle buffers
     runs = []
     for fmt, path in (("criteo", txt), ("rec", rec)):
         r = subprocess.run([os.path.join(built, "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
@@ -174,6 +174,24 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
         runs.append(_losses(r.stderr))
     assert len(runs[0]) == 3 and runs[0] == runs[1], runs
     assert runs[0][-1] < runs[0][0]
+
+
+@pytest.mark.gpu
+def test_cli_runs_are_reproducible(built, tmp_path):
+    """two runs of one command give the same trajectory, shuffle buffer included: the permutation comes from the reader's
+    own restatement of the reference's rand() stream (RefRand, batch_reader.h), not from the process-wide rand(), which
+    the HIP runtime's threads draw from as well; every device kernel on the path is deterministic"""
+    exe = os.path.join(built, "difacto")
+    for path in ("fused", "literal"):
+        text = open(_hash_conf(tmp_path, 3, 25)).read().replace("device_path = fused", "device_path = " + path)
+        conf = os.path.join(tmp_path, "repro_%s.conf" % path)
+        open(conf, "w").write(text)
+        lines = []
+        for _ in range(3):
+            r = subprocess.run([exe, "argfile=" + conf], capture_output=True, text=True, timeout=600, cwd=ROOT)
+            assert r.returncode == 0, r.stderr[-1500:]
+            lines.append([l.split("] ")[-1] for l in r.stderr.splitlines() if "loss = " in l])
+        assert len(lines[0]) >= 3 and lines[0] == lines[1] == lines[2], (path, lines)
 
 
 @pytest.mark.gpu
@@ -259,8 +277,9 @@ def test_cli_literal_path_on_the_sharded_store(built, tmp_path):
     assert plain.returncode == 0 and one.returncode == 0
     a, b = _losses(plain.stderr), _losses(one.stderr)
     # two different kernels apply the pushes (k_push_grad: a wave per key; k_push_grad_multi: a lane group per key): the
-    # trajectories agree to accumulated rounding, not bit for bit
-    assert len(a) == len(b) >= 2 and all(abs(x - y) <= 1e-3 * abs(x) for x, y in zip(a, b)), (a, b)
+    # trajectories agree to accumulated rounding, not bit for bit.  (Before the reader had its own rand() stream the two
+    # processes drew different shuffles and this comparison needed 1e-3.)
+    assert len(a) == len(b) >= 2 and all(abs(x - y) <= 2e-5 * abs(x) for x, y in zip(a, b)), (a, b)
     rv = os.path.join(tmp_path, "rv_lit")
     os.makedirs(rv)
     procs = []

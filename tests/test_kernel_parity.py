@@ -72,6 +72,10 @@ def _case(name, rcv1):
         nnz = len(b["index"])
         b["value"] = (np.sign(rng.normal(size=nnz)) * 10.0 ** rng.uniform(-3, 3, size=nnz)).astype(np.float32)
         return b, 16, 0.004
+    if name == "tall_ragged_k4":
+        # 30 000 rows of 0 .. 20 nonzeros (many empty): ~300 k pairs, so the Localizer's tags keep 13 row bits and
+        # k_loc_emit has to pick every pair's row among four candidates (rows congruent modulo 8192)
+        return random_batch(rng, 30000, 50000, 20), 4, 0.1
     if name == "c3_full_k64":
         return _c3_batch(), 64, 0.1
     if name == "c3_full_k128":
@@ -80,7 +84,7 @@ def _case(name, rcv1):
 
 
 CASES = ["c2_rcv1_k8", "ragged_k0", "ragged_k4", "ragged_k5", "ragged_k64", "ragged_k128", "hot_k64", "adversarial_k16",
-         "c3_full_k64", "c3_full_k128"]
+         "tall_ragged_k4", "c3_full_k64", "c3_full_k128"]
 
 # The tolerance of every comparison here is rtol 1e-5 |ref| + the summation-noise floor of oracle/tolerance.py; the
 # backstop is the fraction of elements inside the PURE rtol 1e-5 (no floor).  PURE_MIN holds, per case and quantity, the
@@ -231,7 +235,8 @@ def _oracle_model(oracle, rng, keys, k, kw, scale, init_mode):
     return so, scal, has.astype(np.int32), V[:, :2 * k] if k else None
 
 
-FUSED_CASES = ["c2_rcv1_k8", "ragged_k0", "ragged_k5", "ragged_k64", "hot_k64", "adversarial_k16", "c3_full_k64", "c3_full_k128"]
+FUSED_CASES = ["c2_rcv1_k8", "ragged_k0", "ragged_k5", "ragged_k64", "hot_k64", "adversarial_k16", "tall_ragged_k4", "c3_full_k64",
+               "c3_full_k128"]
 
 
 @pytest.mark.parametrize("name", FUSED_CASES)
