@@ -207,8 +207,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   const bool train = job.type == sgd::Job::kTraining;
   const bool predict = job.type == sgd::Job::kPrediction;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
-  BatchReader reader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
-                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  // minibatches are cut (permutation + row gather) two ahead on the reader's own thread, the reference's reader /
+  // executor overlap (sgd_learner.cc:196-224)
+  PrefetchSource reader(new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                                        train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f), 2);
   dfh_ctx* ctx = DeviceContext::Get();
   dfh_table* table = GetUpdater()->table();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
@@ -321,8 +323,10 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
   const bool predict = job.type == sgd::Job::kPrediction;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
   auto* ss = CHECK_NOTNULL(dynamic_cast<ShardedDeviceStore*>(store_));
-  BatchReader reader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
-                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  // minibatches are cut (permutation + row gather) two ahead on the reader's own thread, the reference's reader /
+  // executor overlap (sgd_learner.cc:196-224)
+  PrefetchSource reader(new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                                        train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f), 2);
   dfh_ctx* ctx = DeviceContext::Get();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
   auto drain = [&](dfh_batch* b) {
@@ -431,8 +435,9 @@ real_t SGDLearner::EvaluatePenalty(const SArray<real_t>& weights, const SArray<i
 void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool push_cnt = train && job.epoch == 0;
-  BatchReader reader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
-                     train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  PrefetchSource reader(new BatchReader(train ? param_.data_in : param_.data_val, param_.data_format, job.part_idx, job.num_parts,
+                                        param_.batch_size, train ? param_.batch_size * param_.shuffle : 0,
+                                        train ? param_.neg_sampling : 1.0f), 2);
   // the sharded store's Push / Pull are collective: every rank makes the same calls until no rank has a minibatch
   // left; a rank whose part of the data is exhausted goes on with empty arrays
   auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);

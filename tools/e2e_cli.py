@@ -35,9 +35,11 @@ open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
 sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
 common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
           "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
+EXES = os.environ.get("E2E_EXES", "difacto").split(",")   # A/B: several binaries under build/ on the same files
+exe = EXES[0]
 def run(path, fmt):
     t0 = time.time()
-    r = subprocess.run([os.path.join(R, "build", "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
+    r = subprocess.run([os.path.join(R, "build", exe), "data_in=" + path, "data_format=" + fmt] + common,
                        capture_output=True, text=True, timeout=900)
     dt = time.time() - t0
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
@@ -47,18 +49,20 @@ def run(path, fmt):
     return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])
 
 
-for fmt in ("criteo", "libsvm", "rec"):
+for fmt in os.environ.get("E2E_FORMATS", "criteo,libsvm,rec").split(","):
     path = os.path.join(d, "train." + fmt)
     big = os.path.join(d, "train_x%d.%s" % (rep, fmt))
     with open(big, "wb") as out:   # text lines and RecordIO records both concatenate
         blob = open(path, "rb").read()
         for _ in range(rep):
             out.write(blob)
-    # the faster of two runs each: the difference of two wall times is sensitive to a hiccup in either
-    dt1, rc1, line1 = min(run(path, fmt), run(path, fmt))
-    dt2, rc2, line2 = min(run(big, fmt), run(big, fmt))
-    steady = rows * (rep - 1) / max(dt2 - dt1, 1e-9)
-    print(json.dumps(dict(format=fmt, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt1, rows_per_s=rows / dt1, rc=rc1,
-                          line=line1, rows_big=rows * rep, wall_s_big=dt2, rows_per_s_big=rows * rep / dt2, rc_big=rc2,
-                          steady_rows_per_s=steady, steady_mb_per_s=steady * os.path.getsize(path) / rows / 1e6, line_big=line2)))
+    for exe in EXES:
+        # the faster of two runs each: the difference of two wall times is sensitive to a hiccup in either
+        dt1, rc1, line1 = min(run(path, fmt), run(path, fmt))
+        dt2, rc2, line2 = min(run(big, fmt), run(big, fmt))
+        steady = rows * (rep - 1) / max(dt2 - dt1, 1e-9)
+        print(json.dumps(dict(format=fmt, exe=exe, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt1, rows_per_s=rows / dt1,
+                              rc=rc1, line=line1, rows_big=rows * rep, wall_s_big=dt2, rows_per_s_big=rows * rep / dt2, rc_big=rc2,
+                              steady_rows_per_s=steady, steady_mb_per_s=steady * os.path.getsize(path) / rows / 1e6, line_big=line2)),
+              flush=True)
     os.remove(big)
