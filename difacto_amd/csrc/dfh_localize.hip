@@ -13,7 +13,11 @@
 //                  rank inside (tile, bucket); one global atomic per (tile, bucket) reserves the
 //                  run's place inside its bucket — no scan pass: the order of the runs inside a
 //                  bucket is irrelevant, the bucket is sorted next.  Side job: row of every nnz.
-//   k_loc_scatter  bucket starts (block scan of the 1024 totals) + pairs -> bucket-major order
+//   k_loc_scatter  bucket starts (block scan of the 1024 totals) + pairs -> bucket-major order.  From here on a pair is
+//                  (key, TAG), tag = pos << tb | row mod 2^tb: tags order like positions, and emit gets the row of a
+//                  pair back from the tag and the CSR offsets instead of gathering it from a 1.5 MB array (LocView::tb).
+//                  A bucket's area is filled XCD group by XCD group (LocView::btotal), so that the short runs of the
+//                  tiles running on one XCD merge into whole lines in that XCD's L2.
 //   k_loc_sort     one block per bucket: merge sort in LDS by (key, pos) (64-wide runs by ranking,
 //                  then log2(n/64) rounds of merge-by-binary-search); bucket summary
 //   k_loc_emit     one block per bucket: unique ids before the bucket from the summaries, then the
