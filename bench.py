@@ -69,6 +69,9 @@ def parse_args():
                          "keeps 2 in flight)")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
+    ap.add_argument("--fused-probe", action="store_true",
+                    help="A/B: probe the key index inside the Localizer's emit pass (dfh_localize_lookup) instead of in a launch of "
+                         "its own (dfh_batch_lookup); measured 0.4 %% slower: the longer emit pass runs beside the forward")
     ap.add_argument("--later-epoch", action="store_true",
                     help="time the step of epochs after the first (no feature-count push, sgd_learner.cc:214-217) instead of "
                          "the default epoch-0 step, which pushes counts every minibatch (the worst case)")
@@ -338,9 +341,12 @@ def main():
         o, x, l, v, nr, nz = dev[i % nd]
         b = bts[i % len(bts)]
         b.attach_device(nr, nz, o.ptr, x.ptr, None if v is None else v.ptr, l.ptr)  # inputs are resident in HBM: no copy
-        b.localize()
-        if args.prep_lookup and depth:   # one stream: the step's own lookup probes and pushes in one pass
-            b.lookup(table)
+        if args.prep_lookup and depth and args.fused_probe:
+            b.localize(table=table)      # the Localizer's emit pass probes the key index itself
+        else:
+            b.localize()
+            if args.prep_lookup and depth:   # one stream: the step's own lookup probes and pushes in one pass
+                b.lookup(table)
 
     def step(i):
         if not args.no_relocalize or i + ahead < len(bts):

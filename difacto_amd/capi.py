@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_localize_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
@@ -138,6 +138,7 @@ def lib():
     L.dfh_table_warm_start.argtypes = [vp, vp, sz, f32, f32]
     L.dfh_ctx_set_pipeline.argtypes = [vp, i32]
     L.dfh_batch_lookup.argtypes = [vp, vp]
+    L.dfh_localize_lookup.argtypes = [vp, vp, C.c_uint64]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
     L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp, vp]
@@ -466,9 +467,12 @@ class Batch:
         """zero-copy: read the caller's device arrays in place"""
         _ck(lib().dfh_batch_attach_device(self.h, nrows, nnz, _dp(d_offset), _dp(d_index), _dp(d_value), _dp(d_label)))
 
-    def localize(self, max_index=U64MAX):
-        """Localizer::Compact on device"""
-        _ck(lib().dfh_localize(self.h, max_index))
+    def localize(self, max_index=U64MAX, table=None):
+        """Localizer::Compact on device; with a table also the key-index probe (dfh_localize_lookup)"""
+        if table is None:
+            _ck(lib().dfh_localize(self.h, max_index))
+        else:
+            _ck(lib().dfh_localize_lookup(table.h, self.h, max_index))
 
     def set_option(self, name, value):
         _ck(lib().dfh_batch_set_option(self.h, name.encode(), int(value)))

@@ -1816,9 +1816,10 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
   return DFH_OK;
 }
 
-int dfh_localize(dfh_batch* b, uint64_t max_index) {
-  DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
-  DFH_ARG(max_index != 0, "max_index must be nonzero");
+namespace {
+// Localizer::Compact of the loaded minibatch; with a table also the key-index probe of dfh_batch_lookup, done by the
+// emit pass itself (the thread that writes a unique key looks it up: one launch and one event record fewer per minibatch)
+int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   dfh_ctx* c = b->ctx;
   DFH_HIP(hipSetDevice(c->device));
   const uint32_t N = (uint32_t)b->nnz;
@@ -1902,9 +1903,14 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
 #endif
     const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
     hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
-    hipLaunchKernelGGL(k_loc_emit, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
-                       b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                       b->d_s_val, b->d_U, sl);
+    if (probe)
+      hipLaunchKernelGGL(k_loc_emit<true>, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
+                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                         b->d_s_val, b->d_U, sl, probe->v, b->d_urow);
+    else
+      hipLaunchKernelGGL(k_loc_emit<false>, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
+                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
+                         b->d_s_val, b->d_U, sl, TableView{}, (uint32_t*)nullptr);
     b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
   } else {
@@ -1923,12 +1929,30 @@ int dfh_localize(dfh_batch* b, uint64_t max_index) {
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
                        b->d_col_ptr, b->d_U, b->d_mid, b->d_hot, b->d_few, b->d_mid_ent, b->d_hot_ent, b->d_few_ent);
     b->seg_nb = 1;
+    if (probe)  // the library sort's path has no emit pass to carry the probe
+      hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, s, probe->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+                         (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr);
   }
   delete tsp;
   DFH_HIP(hipGetLastError());
   b->localized = true;
   b->has_cnt = false;
+  if (probe) b->looked_up = probe;
   return prep_end(b);
+}
+}  // namespace
+
+int dfh_localize(dfh_batch* b, uint64_t max_index) {
+  DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");
+  DFH_ARG(max_index != 0, "max_index must be nonzero");
+  return localize_impl(b, max_index, nullptr);
+}
+
+int dfh_localize_lookup(dfh_table* t, dfh_batch* b, uint64_t max_index) {
+  DFH_ARG(t && b && t->ctx == b->ctx, "dfh_localize_lookup: bad argument");
+  DFH_ARG(b->nrows > 0, "dfh_localize_lookup: no batch loaded");
+  DFH_ARG(max_index != 0, "max_index must be nonzero");
+  return localize_impl(b, max_index, t);
 }
 
 int dfh_batch_set_option(dfh_batch* b, const char* name, int value) {

