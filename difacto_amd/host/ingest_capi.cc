@@ -15,6 +15,12 @@ long ingest_lz4_decompress(const char* src, size_t src_size, char* dst, size_t d
   return Lz4DecompressBlock(src, src_size, dst, dst_cap);
 }
 
+/*! \brief restarts the process-wide shuffle stream (RefRand) at the reference's default seed */
+void ingest_reset_shuffle_stream() {
+  std::lock_guard<std::mutex> lk(*RefRand::GlobalLock());
+  RefRand::Global()->Seed(1);
+}
+
 /**
  * reads one part of a file through BatchReader and concatenates its minibatches.  Outputs are
  * caller-allocated with the given capacities; returns the number of rows, or -1 when a capacity is
@@ -23,7 +29,11 @@ long ingest_lz4_decompress(const char* src, size_t src_size, char* dst, size_t d
 long ingest_read(const char* uri, const char* format, unsigned part, unsigned nparts, unsigned batch_size, unsigned shuffle,
                  float neg_sampling, size_t row_cap, size_t nnz_cap, size_t* offset, float* label, uint64_t* index, float* value,
                  int* has_value, long* nbatches) {
-  BatchReader reader(uri, format, part, nparts, batch_size, shuffle, neg_sampling);
+  // DIFACTO_INGEST_PREFETCH = n: through PrefetchSource, n minibatches ahead on a reader thread, as the worker loops read
+  const char* pf = getenv("DIFACTO_INGEST_PREFETCH");
+  std::unique_ptr<BatchSource> src(new BatchReader(uri, format, part, nparts, batch_size, shuffle, neg_sampling));
+  if (pf && atoi(pf) > 0) src.reset(new PrefetchSource(src.release(), atoi(pf)));
+  BatchSource& reader = *src;
   size_t rows = 0, nnz = 0;
   long nb = 0;
   offset[0] = 0;

@@ -22,6 +22,7 @@ def ing():
     L.ingest_cityhash64.argtypes = [C.c_char_p, C.c_size_t]
     L.ingest_lz4_decompress.restype = C.c_long
     L.ingest_lz4_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.ingest_reset_shuffle_stream.restype = None
     L.ingest_read.restype = C.c_long
     L.ingest_read.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_size_t, C.c_size_t,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long)]
@@ -199,6 +200,44 @@ def test_libsvm_reader_parts_and_sampling(ing, tmp_path):
     sh = read_all(ing, path, "libsvm", batch=50, shuffle=200)
     assert len(sh["label"]) == 1000 and sorted(sh["index"].tolist()) == sorted(got["index"].tolist())
     assert not np.array_equal(sh["index"], got["index"])
+
+
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_reader_threads_hand_out_the_same_minibatches(ing, tmp_path, monkeypatch, depth):
+    """the worker loops read through PrefetchSource (minibatches cut `depth` ahead on a reader thread; the shuffle buffer
+    itself is assembled one ahead on another): the same minibatches in the same order as the plain BatchReader, for every
+    way a minibatch comes about — a view of a parsed chunk, rows appended across chunks, the shuffle buffer's permutation
+    (the process-wide RefRand stream restarted for each read), negative down-sampling — and for batch sizes that do and
+    do not divide the chunks"""
+    from oracle import ingest as oi
+    rng = np.random.default_rng(17 + depth)
+    text = _criteo_text(rng, 2500)
+    txt = tmp_path / "t.criteo"
+    txt.write_bytes(text)
+    off, lab, idx = oi.parse_criteo(text)
+    recs = [oi.write_crb_record(off[a:a + 251] - off[a], lab[a:a + 250], idx[int(off[a]):int(off[a + 250])]) for a in range(0, 2500, 250)]
+    rec = tmp_path / "t.rec"
+    rec.write_bytes(oi.write_recordio(recs))
+    monkeypatch.setenv("DIFACTO_CHUNK_BYTES", "20000")   # ~60 rows of criteo text per chunk
+    cases = [dict(batch=64), dict(batch=50, shuffle=500), dict(batch=97, shuffle=970, neg=0.6), dict(batch=250), dict(batch=1000, shuffle=1000),
+             dict(batch=7, neg=0.5)]
+    for fmt, path in (("criteo", txt), ("rec", rec)):
+        for kw in cases:
+            monkeypatch.delenv("DIFACTO_INGEST_PREFETCH", raising=False)
+            ing.ingest_reset_shuffle_stream()
+            want = read_all(ing, path, fmt, **kw)
+            monkeypatch.setenv("DIFACTO_INGEST_PREFETCH", str(depth))
+            ing.ingest_reset_shuffle_stream()
+            got = read_all(ing, path, fmt, **kw)
+            assert got["nbatches"] == want["nbatches"] and got["has_value"] == want["has_value"], (fmt, kw)
+            for k in ("offset", "label", "index", "value"):
+                assert np.array_equal(got[k], want[k]), (fmt, kw, k)
+        # and the shuffle really is a different order, the same rows
+        ing.ingest_reset_shuffle_stream()
+        plain = read_all(ing, path, fmt, batch=50)
+        ing.ingest_reset_shuffle_stream()
+        shuf = read_all(ing, path, fmt, batch=50, shuffle=500)
+        assert not np.array_equal(plain["index"], shuf["index"]) and sorted(plain["index"].tolist()) == sorted(shuf["index"].tolist())
 
 
 @pytest.mark.parametrize("threads", [1, 3, 8])
