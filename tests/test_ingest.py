@@ -240,6 +240,26 @@ def test_reader_threads_hand_out_the_same_minibatches(ing, tmp_path, monkeypatch
         assert not np.array_equal(plain["index"], shuf["index"]) and sorted(plain["index"].tolist()) == sorted(shuf["index"].tolist())
 
 
+def test_reader_threads_under_tsan(tmp_path):
+    """the reader's threads (parser pool, shuffle-buffer thread, minibatch thread) under ThreadSanitizer: no report"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "tsan_reader")
+    cc = ["g++", "-fsanitize=thread", "-O1", "-g", "-std=c++14", "-fopenmp", "-Wno-unknown-pragmas", "-Wno-sign-compare",
+          "-DDMLC_LOG_FATAL_THROW=0", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "third_party_shim"),
+          "-I" + os.path.join(ROOT, "difacto_amd", "host"), "-o", exe, os.path.join(ROOT, "tools", "tsan_reader.cc"), "-lpthread"]
+    r = subprocess.run(cc, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, DIFACTO_PARSER_THREADS="3", DIFACTO_CHUNK_BYTES="4096", TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "rcv1_100.libsvm")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.startswith("rows ")
+
+
 @pytest.mark.parametrize("threads", [1, 3, 8])
 def test_parser_pool_keeps_file_order(ing, tmp_path, monkeypatch, threads):
     """the chunks of a part are parsed by a pool of threads (batch_reader.h: Reader) and must reach the

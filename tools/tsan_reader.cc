@@ -1,0 +1,22 @@
+// ThreadSanitizer driver for the reader threads (batch_reader.h: parser pool -> shuffle buffer assembled ahead -> minibatches
+// cut ahead): 20 readers over the rcv1 fixture with and without shuffle buffer / down-sampling, prefetch depth 1..3, some
+// consumers stopping early.  Built and run by tests/test_ingest.py::test_reader_threads_under_tsan:
+//   g++ -fsanitize=thread -O1 -g -std=c++14 -fopenmp -Iinclude -Ithird_party_shim -Idifacto_amd/host tools/tsan_reader.cc -lpthread
+#include <cstdio>
+#include "batch_reader.h"
+using namespace difacto;
+int main(int argc, char** argv) {
+  size_t rows = 0, sum = 0;
+  for (int rep = 0; rep < 20; ++rep) {
+    PrefetchSource r(new BatchReader(argv[1], "libsvm", 0, 1, 7, rep % 2 ? 35 : 0, rep % 3 ? 1.0f : 0.7f), 1 + rep % 3);
+    int n = 0;
+    while (r.Next()) {
+      const auto& b = r.Value();
+      rows += b.size;
+      for (size_t i = b.offset[0]; i < b.offset[b.size]; ++i) sum += b.index[i];
+      if (++n == 5 && rep % 5 == 4) break;   // a consumer that stops early
+    }
+  }
+  printf("rows %zu sum %zu\n", rows, sum);
+  return 0;
+}
