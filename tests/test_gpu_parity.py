@@ -117,7 +117,7 @@ def test_literal_predict_accumulates(ctx, oracle):
 # ------------------------------------------------------------------ device Localizer
 @pytest.mark.parametrize("path", ["sample_sort", "radix", "sample_sort_fallback"])
 @pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same", "criteo_like",
-                                  "bias_feature", "sorted_input", "clustered", "tall_ragged"])
+                                  "bias_feature", "sorted_input", "clustered", "tall_ragged", "max_sample_sort", "over_sample_sort"])
 def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     rng = np.random.default_rng(11)
     mx = U64MAX
@@ -131,6 +131,12 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
         b = random_batch(rng, 2000, 5000, 39, binary=True, empty_rows=False)
     elif case == "one_row":
         b = random_batch(rng, 1, 50, 30, empty_rows=False)
+    elif case in ("max_sample_sort", "over_sample_sort"):
+        # 716 800 pairs is the most the hand-written sample sort takes (1024 buckets of <= 700 on average; 20-bit positions
+        # in the tags); one row more and the library sort's path serves the minibatch
+        from difacto_amd import synth
+        b = synth.CriteoSynth(total_ids=3000000, seed=5).batch(18379 if case == "max_sample_sort" else 18380)
+        assert (int(b["offset"][-1]) <= 716800) == (case == "max_sample_sort")
     elif case == "tall_ragged":
         b = random_batch(rng, 30000, 2 ** 40, 20)  # ~300 k pairs over 30 000 rows, many of them empty
     elif case == "criteo_like":
