@@ -795,7 +795,7 @@ class BatchReader : public BatchSource {
     feaid_t mx = batch_.max_index;
     constexpr size_t kAhead = 12;
     const int nth = nsel >= 2048 ? GatherThreads() : 1;
-#pragma omp parallel for num_threads(nth) schedule(static) reduction(max : mx) if (nth > 1)
+#pragma omp parallel for num_threads(nth) schedule(static) if (nth > 1)
     for (size_t q = 0; q < nsel; ++q) {
       if (q + kAhead < nsel) {
         const size_t pb = in_blk_.offset[sel_[q + kAhead]], pn = in_blk_.offset[sel_[q + kAhead] + 1] - pb;
@@ -805,13 +805,13 @@ class BatchReader : public BatchSource {
       }
       const size_t b = in_blk_.offset[sel_[q]], n = in_blk_.offset[sel_[q] + 1] - b;
       const size_t dst = batch_.offset[r0 + q];
-      const feaid_t* src = in_blk_.index + b;   // offsets are absolute positions into index / value
-      for (size_t x = 0; x < n; ++x) {
-        batch_.index[dst + x] = src[x];
-        mx = std::max(mx, src[x]);
-      }
+      // offsets are absolute positions into index / value
+      memcpy(&batch_.index[dst], in_blk_.index + b, n * sizeof(feaid_t));
       if (in_blk_.value) memcpy(&batch_.value[dst], in_blk_.value + b, n * sizeof(real_t));
     }
+    // RowBlockContainer keeps the largest index it holds: one pass over what was appended (a max inside the copy loop kept
+    // the copy from being a memcpy: tools/gather_host_bench.cc)
+    for (size_t x = nnz_before; x < nnz_before + add; ++x) mx = std::max(mx, batch_.index[x]);
     batch_.max_index = mx;
   }
   static int GatherThreads() {
