@@ -6,19 +6,33 @@
 #ifndef SHIM_DATA_ROW_BLOCK_H_
 #define SHIM_DATA_ROW_BLOCK_H_
 #include <algorithm>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 #include "dmlc/data.h"
 
 namespace dmlc {
 namespace data {
 
+// resize(n) without a value leaves the new elements uninitialised: the readers size an array and then fill every element
+// of it (a gather of 3 MB per minibatch was being zero-filled first)
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <typename U> struct rebind { typedef DefaultInitAllocator<U> other; };
+  DefaultInitAllocator() = default;
+  template <typename U> DefaultInitAllocator(const DefaultInitAllocator<U>&) {}
+  template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+
 template <typename IndexType>
 struct RowBlockContainer {
   std::vector<size_t> offset;
   std::vector<real_t> label;
   std::vector<real_t> weight;
-  std::vector<IndexType> index;
-  std::vector<real_t> value;
+  std::vector<IndexType, DefaultInitAllocator<IndexType>> index;
+  std::vector<real_t, DefaultInitAllocator<real_t>> value;
   IndexType max_index;
 
   RowBlockContainer() { Clear(); }
