@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cctype>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -494,10 +495,36 @@ class Reader {
 };
 
 /*! \brief BatchReader (src/reader/batch_reader.{h,cc}) */
+/*! \brief rows of shuffle buffer number `buf` (1, 2, ..), in minibatch order: how a minibatch is DESCRIBED instead of copied
+ * when the buffers live in device memory and the rows are gathered there (BatchReader::Describe) */
+struct RowSeg {
+  uint64_t buf;
+  std::vector<unsigned> rows;
+};
+
+/*! \brief view of a row container; a described minibatch has offsets and labels but no index / value arrays */
+inline dmlc::RowBlock<feaid_t> ViewOf(const RowChunk& c) {
+  if (!c.index.empty() || c.offset.back() == 0) return c.GetBlock();
+  dmlc::RowBlock<feaid_t> b;
+  b.size = c.offset.size() - 1;
+  b.offset = c.offset.data();
+  b.label = c.label.empty() ? nullptr : c.label.data();
+  b.weight = nullptr;
+  b.index = nullptr;
+  b.value = nullptr;
+  return b;
+}
+
 /*! \brief anything that hands out row blocks one after another (BatchReader, and the thread that runs one ahead) */
 class BatchSource {
  public:
   virtual ~BatchSource() {}
+  /*! \brief the description of Value() when the source describes its minibatches (else empty) */
+  virtual const std::vector<RowSeg>& Aux() const {
+    static const std::vector<RowSeg> none;
+    return none;
+  }
+  virtual void MoveAux(std::vector<RowSeg>* dst) { dst->clear(); }
   /*! \brief next block; false when exhausted.  Value() stays valid until the next call */
   virtual bool Next() = 0;
   virtual const dmlc::RowBlock<feaid_t>& Value() const = 0;
@@ -534,12 +561,19 @@ class PrefetchSource : public BatchSource {
     cv_.wait(lk, [&] { return slots_[tail_ % slots_.size()].full || (done_ && tail_ == head_); });
     Slot& s = slots_[tail_ % slots_.size()];
     if (!s.full) return false;
-    blk_ = s.rows.GetBlock();
+    blk_ = ViewOf(s.rows);
+    aux_ = &s.aux;
     ++tail_;
     held_ = true;
     return blk_.size > 0;
   }
   const dmlc::RowBlock<feaid_t>& Value() const override { return blk_; }
+  const std::vector<RowSeg>& Aux() const override { return aux_ ? *aux_ : BatchSource::Aux(); }
+  void MoveAux(std::vector<RowSeg>* dst) override {
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK(held_);
+    std::swap(slots_[(tail_ - 1) % slots_.size()].aux, *dst);
+  }
   void MoveOut(RowChunk* dst) override {
     std::lock_guard<std::mutex> lk(mu_);
     CHECK(held_);
@@ -551,6 +585,7 @@ class PrefetchSource : public BatchSource {
   struct Slot {
     bool full = false;
     RowChunk rows;
+    std::vector<RowSeg> aux;
   };
   void Work() {
     for (;;) {
@@ -562,7 +597,10 @@ class PrefetchSource : public BatchSource {
         s = &slots_[head_ % slots_.size()];
       }
       const bool ok = inner_->Next();  // outside the lock: this is the work being overlapped
-      if (ok) inner_->MoveOut(&s->rows);
+      if (ok) {
+        inner_->MoveAux(&s->aux);   // before MoveOut: a source may reset its description there
+        inner_->MoveOut(&s->rows);
+      }
       {
         std::lock_guard<std::mutex> lk(mu_);
         if (ok) {
@@ -584,6 +622,7 @@ class PrefetchSource : public BatchSource {
   size_t head_ = 0, tail_ = 0;  // blocks produced / handed out
   bool held_ = false, done_ = false, stop_ = false;
   dmlc::RowBlock<feaid_t> blk_;
+  const std::vector<RowSeg>* aux_ = nullptr;
 };
 
 /**
@@ -657,6 +696,24 @@ class BatchReader : public BatchSource {
     }
   }
 
+  /**
+   * Describe instead of copy (readers with a shuffle buffer only): every buffer is handed to `on_buffer` once, when it becomes
+   * current (serial 1, 2, ..), and a minibatch is its offsets, its labels and the list of (buffer, rows) it is made of
+   * (Aux()) — same permutation, same sampling draws, same minibatch boundaries as the copying reader; the row data is
+   * gathered wherever the buffers were put (the device: sgd_learner.cc's device feed).
+   */
+  typedef std::function<void(const dmlc::RowBlock<feaid_t>& buffer, uint64_t serial)> BufferFn;
+  void Describe(BufferFn on_buffer) {
+    CHECK(shuf_buf_) << "only a reader with a shuffle buffer can describe its minibatches";
+    describe_ = true;
+    on_buffer_ = on_buffer;
+  }
+  const std::vector<RowSeg>& Aux() const override { return segs_; }
+  void MoveAux(std::vector<RowSeg>* dst) override {
+    std::swap(segs_, *dst);
+    segs_.clear();
+  }
+
   /*! \brief next minibatch; false when the part is exhausted (batch_reader.cc:32-77) */
   ~BatchReader() override {
     if (getenv("DIFACTO_PROFILE") && (t_fill_ + t_shuf_ + t_sel_ + t_app_) > 0)
@@ -665,6 +722,7 @@ class BatchReader : public BatchSource {
   }
   bool Next() override {
     batch_.Clear();
+    segs_.clear();
     view_ = false;
     // a whole minibatch inside the current chunk, rows taken as they come: hand out a view of the chunk's
     // arrays instead of copying 39 ids per row (dmlc's RowBlock convention: offset holds absolute positions
@@ -696,6 +754,8 @@ class BatchReader : public BatchSource {
         } else {
           if (!buf_reader_->Next()) break;
           in_blk_ = buf_reader_->Value();
+          ++buf_serial_;
+          if (describe_) on_buffer_(in_blk_, buf_serial_);
           const double f1 = Now();
           t_fill_ += f1 - f0;
           if (rdp_.size() != in_blk_.size) {
@@ -726,7 +786,7 @@ class BatchReader : public BatchSource {
           sel_.push_back(j);
         }
         const double s1 = Now();
-        AppendRows();
+        if (describe_) DescribeRows(); else AppendRows();
         t_sel_ += s1 - s0;
         t_app_ += Now() - s1;
       }
@@ -736,7 +796,7 @@ class BatchReader : public BatchSource {
     for (auto f : batch_.value)
       if (f != 1) { binary = false; break; }
     if (binary) batch_.value.clear();
-    out_blk_ = batch_.GetBlock();
+    out_blk_ = ViewOf(batch_);
     return out_blk_.size > 0;
   }
   const dmlc::RowBlock<feaid_t>& Value() const override { return out_blk_; }
@@ -765,6 +825,24 @@ class BatchReader : public BatchSource {
     slice.index = in_blk_.index + in_blk_.offset[pos];
     slice.value = in_blk_.value ? in_blk_.value + in_blk_.offset[pos] : nullptr;
     PushSlice(slice);
+  }
+  // describe mode: the offsets and labels of rows sel_[] of the current buffer onto batch_, the rows themselves onto segs_
+  void DescribeRows() {
+    if (sel_.empty()) return;
+    const size_t r0 = batch_.label.size(), nsel = sel_.size();
+    batch_.label.resize(r0 + nsel);
+    batch_.offset.resize(batch_.offset.size() + nsel);
+    size_t at = batch_.offset[r0];
+    RowSeg seg;
+    seg.buf = buf_serial_;
+    seg.rows.resize(nsel);
+    for (size_t q = 0; q < nsel; ++q) {
+      at += in_blk_.offset[sel_[q] + 1] - in_blk_.offset[sel_[q]];
+      batch_.offset[r0 + 1 + q] = at;
+      batch_.label[r0 + q] = in_blk_.label[sel_[q]];
+      seg.rows[q] = static_cast<unsigned>(sel_[q]);
+    }
+    segs_.push_back(std::move(seg));
   }
   // rows sel_[] of in_blk_, in that order, onto batch_: what Push(j, 1) per row gives, without the per-row
   // bookkeeping (10 000 single-row slices per minibatch were the slowest thing on the host)
@@ -835,6 +913,10 @@ class BatchReader : public BatchSource {
   std::unique_ptr<Reader> reader_;
   std::unique_ptr<BatchSource> buf_reader_;
   bool view_ = false;  // Value() points into the current chunk, not into batch_
+  bool describe_ = false;
+  BufferFn on_buffer_;
+  uint64_t buf_serial_ = 0;
+  std::vector<RowSeg> segs_;
   size_t start_ = 0, end_ = 0;
   dmlc::RowBlock<feaid_t> in_blk_, out_blk_;
   RowChunk batch_;

@@ -3,6 +3,7 @@
  * for the CPU tests in tests/test_ingest.py (ctypes).  Host only: no device is touched.
  */
 #include <cstring>
+#include <map>
 #include "./batch_reader.h"
 
 using namespace difacto;
@@ -31,15 +32,60 @@ long ingest_read(const char* uri, const char* format, unsigned part, unsigned np
                  int* has_value, long* nbatches) {
   // DIFACTO_INGEST_PREFETCH = n: through PrefetchSource, n minibatches ahead on a reader thread, as the worker loops read
   const char* pf = getenv("DIFACTO_INGEST_PREFETCH");
-  std::unique_ptr<BatchSource> src(new BatchReader(uri, format, part, nparts, batch_size, shuffle, neg_sampling));
+  // DIFACTO_INGEST_DESCRIBE = 1 (with a shuffle buffer): the reader describes its minibatches (BatchReader::Describe) and the
+  // rows are gathered here from copies of the buffers it announced — what the device feed does in HBM
+  const bool describe = getenv("DIFACTO_INGEST_DESCRIBE") && atoi(getenv("DIFACTO_INGEST_DESCRIBE")) > 0 && shuffle > 0;
+  std::mutex bmu;
+  std::map<uint64_t, RowChunk> buffers;
+  std::unique_ptr<BatchReader> br(new BatchReader(uri, format, part, nparts, batch_size, shuffle, neg_sampling));
+  if (describe)
+    br->Describe([&](const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) {
+      std::lock_guard<std::mutex> lk(bmu);
+      RowChunk& c = buffers[serial];
+      c.Clear();
+      dmlc::RowBlock<feaid_t> slice = blk;
+      slice.index = blk.index + blk.offset[0];
+      slice.value = blk.value ? blk.value + blk.offset[0] : nullptr;
+      c.Push(slice);
+      if (serial > 4) buffers.erase(serial - 4);   // a minibatch spans at most two buffers; the reader runs a few ahead
+    });
+  std::unique_ptr<BatchSource> src(br.release());
   if (pf && atoi(pf) > 0) src.reset(new PrefetchSource(src.release(), atoi(pf)));
   BatchSource& reader = *src;
+  RowChunk rebuilt;
   size_t rows = 0, nnz = 0;
   long nb = 0;
   offset[0] = 0;
   *has_value = 0;
   while (reader.Next()) {
-    const auto& b = reader.Value();
+    if (describe) {  // gather the described rows
+      const auto& d = reader.Value();
+      rebuilt.Clear();
+      size_t q = 0;
+      std::lock_guard<std::mutex> lk(bmu);
+      for (const RowSeg& seg : reader.Aux()) {
+        auto it = buffers.find(seg.buf);
+        if (it == buffers.end()) return -2;
+        const RowChunk& c = it->second;
+        for (unsigned r : seg.rows) {
+          const size_t lo = c.offset[r], n = c.offset[r + 1] - lo;
+          if (d.offset[q + 1] - d.offset[q] != n || d.label[q] != c.label[r]) return -3;   // the description's own offsets / labels
+          if (!c.value.empty() && rebuilt.value.size() < rebuilt.index.size()) rebuilt.value.resize(rebuilt.index.size(), 1.0f);
+          rebuilt.index.insert(rebuilt.index.end(), c.index.begin() + lo, c.index.begin() + lo + n);
+          if (!c.value.empty()) rebuilt.value.insert(rebuilt.value.end(), c.value.begin() + lo, c.value.begin() + lo + n);
+          else if (!rebuilt.value.empty()) rebuilt.value.resize(rebuilt.index.size(), 1.0f);
+          rebuilt.label.push_back(c.label[r]);
+          rebuilt.offset.push_back(rebuilt.index.size());
+          ++q;
+        }
+      }
+      if (q != d.size) return -4;
+      bool binary = true;   // the copying reader drops an all-ones value array per minibatch (batch_reader.cc:71-73)
+      for (auto f : rebuilt.value)
+        if (f != 1) { binary = false; break; }
+      if (binary) rebuilt.value.clear();
+    }
+    const auto b = describe ? rebuilt.GetBlock() : reader.Value();
     const size_t bn = b.offset[b.size] - b.offset[0];
     if (rows + b.size > row_cap || nnz + bn > nnz_cap) return -1;
     for (size_t i = 0; i < b.size; ++i) {

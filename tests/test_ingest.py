@@ -240,6 +240,44 @@ def test_reader_threads_hand_out_the_same_minibatches(ing, tmp_path, monkeypatch
         assert not np.array_equal(plain["index"], shuf["index"]) and sorted(plain["index"].tolist()) == sorted(shuf["index"].tolist())
 
 
+@pytest.mark.parametrize("depth", [0, 2])
+def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch, depth):
+    """BatchReader::Describe (what the device feed reads): the shuffle buffers are announced once each and a minibatch is
+    its offsets, labels and (buffer, rows) list; gathering those rows from copies of the buffers must give the copying
+    reader's minibatches exactly — same permutation, same sampling draws, same boundaries, minibatches that straddle two
+    buffers, a last short buffer — directly and through the reader thread"""
+    from oracle import ingest as oi
+    rng = np.random.default_rng(29 + depth)
+    text = _criteo_text(rng, 2300)
+    txt = tmp_path / "t.criteo"
+    txt.write_bytes(text)
+    lines = []
+    for i in range(1700):   # libsvm with real values, some all-ones rows
+        n = int(rng.integers(0, 9))
+        ids = rng.integers(1, 10 ** 9, size=n)
+        vals = np.ones(n) if i % 3 == 0 else np.round(rng.normal(size=n), 2)
+        lines.append(" ".join(["1" if rng.random() < 0.4 else "-1"] + ["%d:%g" % (a, b) for a, b in zip(ids, vals)]))
+    svm = tmp_path / "t.libsvm"
+    svm.write_text("\n".join(lines) + "\n")
+    monkeypatch.setenv("DIFACTO_CHUNK_BYTES", "15000")
+    cases = [dict(batch=50, shuffle=500), dict(batch=97, shuffle=485, neg=0.6), dict(batch=64, shuffle=64), dict(batch=300, shuffle=700),
+             dict(batch=1000, shuffle=1000, neg=0.3)]
+    for fmt, path in (("criteo", txt), ("libsvm", svm)):
+        for kw in cases:
+            monkeypatch.delenv("DIFACTO_INGEST_DESCRIBE", raising=False)
+            monkeypatch.delenv("DIFACTO_INGEST_PREFETCH", raising=False)
+            ing.ingest_reset_shuffle_stream()
+            want = read_all(ing, path, fmt, **kw)
+            monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", "1")
+            if depth:
+                monkeypatch.setenv("DIFACTO_INGEST_PREFETCH", str(depth))
+            ing.ingest_reset_shuffle_stream()
+            got = read_all(ing, path, fmt, **kw)
+            assert got["nbatches"] == want["nbatches"], (fmt, kw)
+            for k in ("offset", "label", "index", "value"):
+                assert np.array_equal(got[k], want[k]), (fmt, kw, k)
+
+
 def test_reader_threads_under_tsan(tmp_path):
     """the reader's threads (parser pool, shuffle-buffer thread, minibatch thread) under ThreadSanitizer: no report"""
     import shutil
