@@ -23,7 +23,7 @@ SYMBOLS = [
     "dfh_batch_progress", "dfh_batch_get_pred", "dfh_row_stride", "dfh_shard_pull", "dfh_shard_push_count",
     "dfh_shard_push_grad", "dfh_batch_forward", "dfh_batch_backward", "dfh_batch_device_keys", "dfh_malloc",
     "dfh_free", "dfh_memcpy_h2d", "dfh_memcpy_d2h", "dfh_ctx_set_timing", "dfh_ctx_get_timing", "dfh_kernel_name",
-    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_localize_lookup", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
+    "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_localize_lookup", "dfh_rowbuf_create", "dfh_rowbuf_destroy", "dfh_rowbuf_load_host", "dfh_batch_gather_rows", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
     "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
@@ -139,6 +139,10 @@ def lib():
     L.dfh_ctx_set_pipeline.argtypes = [vp, i32]
     L.dfh_batch_lookup.argtypes = [vp, vp]
     L.dfh_localize_lookup.argtypes = [vp, vp, C.c_uint64]
+    L.dfh_rowbuf_create.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.dfh_rowbuf_destroy.argtypes = [vp]
+    L.dfh_rowbuf_load_host.argtypes = [vp, C.c_size_t, vp, vp, vp]
+    L.dfh_batch_gather_rows.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
     L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp, vp]
@@ -439,6 +443,26 @@ class Table:
         _ck(lib().dfh_table_check(self.h))
 
 
+class RowBuf:
+    """a shuffle buffer in HBM (dfh_rowbuf): rows are gathered out of it on the device (Batch.gather_rows)"""
+
+    def __init__(self, ctx, max_rows, max_nnz):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _ck(lib().dfh_rowbuf_create(ctx.h, max_rows, max_nnz, C.byref(self.h)))
+
+    def load_host(self, offset, index, value=None):
+        offset = np.ascontiguousarray(offset, np.uint64)
+        index = np.ascontiguousarray(index, np.uint64)
+        value = None if value is None else np.ascontiguousarray(value, np.float32)
+        _ck(lib().dfh_rowbuf_load_host(self.h, len(offset) - 1, _p(offset), _p(index), _p(value)))
+
+    def close(self):
+        if self.h:
+            lib().dfh_rowbuf_destroy(self.h)
+            self.h = None
+
+
 class Batch:
     """a device-resident minibatch + workspace (dfh_batch)"""
 
@@ -479,6 +503,18 @@ class Batch:
 
     def lookup(self, table):
         _ck(lib().dfh_batch_lookup(table.h, self.h))
+
+    def gather_rows(self, offset, label, segments):
+        """dfh_batch_gather_rows: the minibatch = rows `rows` of row buffer `rb` for every (rb, rows) of `segments`, in order;
+        offset / label are the minibatch's own (cumulative row lengths, labels)"""
+        offset = np.ascontiguousarray(offset, np.uint64)
+        label = np.ascontiguousarray(label, np.float32)
+        rows = [np.ascontiguousarray(r, np.uint32) for _, r in segments]
+        n = len(segments)
+        bufs = (C.c_void_p * n)(*[rb.h for rb, _ in segments])
+        ptrs = (C.c_void_p * n)(*[r.ctypes.data for r in rows])
+        cnts = (C.c_size_t * n)(*[len(r) for r in rows])
+        _ck(lib().dfh_batch_gather_rows(self.h, len(label), _p(offset), _p(label), n, bufs, ptrs, cnts))
 
     def load_localized_host(self, offset, index, value, label, feaids, feacnt=None):
         offset = np.ascontiguousarray(offset, np.uint64)

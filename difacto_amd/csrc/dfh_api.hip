@@ -1816,6 +1816,192 @@ int dfh_batch_attach_device(dfh_batch* b, size_t nrows, size_t nnz, const uint32
   return DFH_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Device feed: the shuffle buffer of BatchReader (src/reader/batch_reader.cc:38-52) lives in HBM; a minibatch is gathered
+// out of it by row number on the device (the host sends 4 B per row instead of copying ~300 B per row twice).
+// ---------------------------------------------------------------------------------------
+struct dfh_rowbuf {
+  dfh_ctx* ctx = nullptr;
+  size_t max_rows = 0, max_nnz = 0, nrows = 0, nnz = 0;
+  uint32_t* d_off = nullptr;   // [max_rows + 1]
+  uint64_t* d_idx = nullptr;   // [max_nnz]
+  float* d_val = nullptr;      // [max_nnz]
+  bool has_value = false;
+  hipStream_t up = nullptr;    // uploads: the feed thread's own stream
+  hipEvent_t ev_loaded = nullptr, ev_used = nullptr;
+  std::mutex mu;               // used_pending is set by the thread that gathers, read by the thread that uploads
+  bool used_pending = false;
+  std::vector<uint32_t> off32;
+};
+
+namespace {
+// one wave per row of the minibatch: row rows[q] of the buffer -> positions dst_off[q] .. of the minibatch's arrays
+__global__ void __launch_bounds__(256) k_gather_rows(const uint32_t* __restrict__ src_off, const uint64_t* __restrict__ src_idx,
+                                                     const float* __restrict__ src_val, const uint32_t* __restrict__ rows, uint32_t n,
+                                                     const uint32_t* __restrict__ dst_off, uint64_t* __restrict__ dst_idx,
+                                                     float* __restrict__ dst_val) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < n; q += nw) {
+    const uint32_t r = rows[q];
+    const uint32_t lo = src_off[r], len = src_off[r + 1] - lo, d0 = dst_off[q];
+    for (uint32_t j = lane; j < len; j += 64u) {
+      dst_idx[d0 + j] = src_idx[lo + j];
+      if (dst_val) dst_val[d0 + j] = src_val ? src_val[lo + j] : 1.0f;   // a buffer without values holds ones
+    }
+  }
+}
+}  // namespace
+
+int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** out) {
+  DFH_ARG(c && out && max_rows >= 1 && max_nnz >= 1, "dfh_rowbuf_create: bad argument");
+  DFH_ARG(max_nnz < 0xFFFFFFF0ULL && max_rows < 0xFFFFFFF0ULL, "dfh_rowbuf_create: a row buffer holds fewer than 2^32 rows / nonzeros");
+  DFH_HIP(hipSetDevice(c->device));
+  dfh_rowbuf* rb = new (std::nothrow) dfh_rowbuf();
+  if (!rb) {
+    set_error("dfh_rowbuf_create: out of host memory");
+    return DFH_ERR_HIP;
+  }
+  rb->ctx = c;
+  rb->max_rows = max_rows;
+  rb->max_nnz = max_nnz;
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&rb->d_off), (max_rows + 1) * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&rb->d_idx), max_nnz * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&rb->d_val), max_nnz * sizeof(float))) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&rb->up, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&rb->ev_loaded, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&rb->ev_used, hipEventDisableTiming)) != hipSuccess) {
+    set_error(std::string("dfh_rowbuf_create: ") + hipGetErrorString(e));
+    dfh_rowbuf_destroy(rb);
+    return DFH_ERR_HIP;
+  }
+  *out = rb;
+  return DFH_OK;
+}
+
+int dfh_rowbuf_destroy(dfh_rowbuf* rb) {
+  if (!rb) return DFH_OK;
+  hipSetDevice(rb->ctx->device);
+  sync_all(rb->ctx);
+  if (rb->up) {
+    hipStreamSynchronize(rb->up);
+    hipStreamDestroy(rb->up);
+  }
+  if (rb->ev_loaded) hipEventDestroy(rb->ev_loaded);
+  if (rb->ev_used) hipEventDestroy(rb->ev_used);
+  for (void* p : {(void*)rb->d_off, (void*)rb->d_idx, (void*)rb->d_val})
+    if (p) hipFree(p);
+  delete rb;
+  return DFH_OK;
+}
+
+int dfh_rowbuf_load_host(dfh_rowbuf* rb, size_t nrows, const size_t* offset, const uint64_t* index, const float* value) {
+  DFH_ARG(rb && offset && nrows >= 1 && nrows <= rb->max_rows, "dfh_rowbuf_load_host: bad argument / more rows than the buffer holds");
+  const size_t base = offset[0], nnz = offset[nrows] - base;
+  DFH_ARG(nnz <= rb->max_nnz, "dfh_rowbuf_load_host: more nonzeros than the buffer holds");
+  DFH_ARG(nnz == 0 || index, "dfh_rowbuf_load_host: index is NULL");
+  DFH_HIP(hipSetDevice(rb->ctx->device));
+  bool wait_used;
+  {
+    std::lock_guard<std::mutex> lk(rb->mu);
+    wait_used = rb->used_pending;
+    rb->used_pending = false;
+  }
+  if (wait_used) DFH_HIP(hipEventSynchronize(rb->ev_used));  // the gathers out of the previous contents have run
+  rb->off32.resize(nrows + 1);
+  for (size_t i = 0; i <= nrows; ++i) {
+    DFH_ARG(offset[i] >= base && (i == 0 || offset[i] >= offset[i - 1]), "dfh_rowbuf_load_host: offsets must not decrease");
+    rb->off32[i] = (uint32_t)(offset[i] - base);
+  }
+  DFH_HIP(hipMemcpyAsync(rb->d_off, rb->off32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, rb->up));
+  if (nnz) DFH_HIP(hipMemcpyAsync(rb->d_idx, index + base, nnz * sizeof(uint64_t), hipMemcpyHostToDevice, rb->up));
+  if (nnz && value) DFH_HIP(hipMemcpyAsync(rb->d_val, value + base, nnz * sizeof(float), hipMemcpyHostToDevice, rb->up));
+  DFH_HIP(hipEventRecord(rb->ev_loaded, rb->up));
+  DFH_HIP(hipStreamSynchronize(rb->up));   // the caller's arrays are free again
+  rb->nrows = nrows;
+  rb->nnz = nnz;
+  rb->has_value = value != nullptr;
+  return DFH_OK;
+}
+
+int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg, dfh_rowbuf* const* bufs,
+                          const uint32_t* const* rows, const size_t* seg_rows) {
+  DFH_ARG(b && offset && label && nseg >= 1 && bufs && rows && seg_rows, "dfh_batch_gather_rows: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows, "dfh_batch_gather_rows: nrows out of range");
+  std::vector<uint32_t> off32;
+  int rc = to_u32_offsets(offset, nrows, &off32);
+  if (rc) return rc;
+  const size_t nnz = off32[nrows];
+  DFH_ARG(nnz <= b->max_nnz, "dfh_batch_gather_rows: nnz exceeds max_nnz");
+  size_t total = 0;
+  bool any_value = false;
+  for (int g = 0; g < nseg; ++g) {
+    DFH_ARG(bufs[g] && bufs[g]->ctx == b->ctx && (seg_rows[g] == 0 || rows[g]), "dfh_batch_gather_rows: bad segment");
+    total += seg_rows[g];
+    any_value = any_value || bufs[g]->has_value;
+  }
+  DFH_ARG(total == nrows, "dfh_batch_gather_rows: the segments must hold nrows rows");
+  DFH_HIP(hipSetDevice(b->ctx->device));
+  phase_begin(b);
+  rc = prep_begin(b);
+  if (rc) return rc;
+  hipStream_t s = prep_of(b);
+  b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
+  // offsets, labels and row numbers through the batch's pinned staging (the row numbers where load_host puts the ids)
+  const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
+               o_val = o_idx + b->max_nnz * 8, stage_total = o_val + b->max_nnz * 4;
+  if (!b->h_stage) {
+    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), stage_total, hipHostMallocDefault));
+    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
+  }
+  if (b->staged_pending) {
+    DFH_HIP(hipEventSynchronize(b->ev_staged));
+    b->staged_pending = false;
+  }
+  memcpy(b->h_stage + o_off, off32.data(), (nrows + 1) * 4);
+  memcpy(b->h_stage + o_lab, label, nrows * 4);
+  uint32_t* h_rows = reinterpret_cast<uint32_t*>(b->h_stage + o_idx);
+  size_t at = 0;
+  for (int g = 0; g < nseg; ++g) {
+    for (size_t i = 0; i < seg_rows[g]; ++i) {
+      DFH_ARG(rows[g][i] < bufs[g]->nrows, "dfh_batch_gather_rows: row number beyond the buffer");
+      h_rows[at + i] = rows[g][i];
+    }
+    at += seg_rows[g];
+  }
+  uint32_t* d_rows = b->d_pos;   // scratch until the Localizer writes its row ids there (same stream, later)
+  DFH_HIP(hipMemcpyAsync(b->d_offset, b->h_stage + o_off, (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(b->d_label, b->h_stage + o_lab, nrows * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipMemcpyAsync(d_rows, h_rows, nrows * 4, hipMemcpyHostToDevice, s));
+  DFH_HIP(hipEventRecord(b->ev_staged, s));
+  b->staged_pending = true;
+  at = 0;
+  for (int g = 0; g < nseg; ++g) {
+    dfh_rowbuf* rb = bufs[g];
+    if (seg_rows[g] == 0) continue;
+    DFH_HIP(hipStreamWaitEvent(s, rb->ev_loaded, 0));
+    const unsigned blocks = (unsigned)std::min<size_t>((seg_rows[g] + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, s, rb->d_off, rb->d_idx, rb->has_value ? rb->d_val : (const float*)nullptr,
+                       d_rows + at, (uint32_t)seg_rows[g], b->d_offset + at, b->d_raw, any_value ? b->d_value : (float*)nullptr);
+    DFH_HIP(hipEventRecord(rb->ev_used, s));
+    {
+      std::lock_guard<std::mutex> lk(rb->mu);
+      rb->used_pending = true;
+    }
+    at += seg_rows[g];
+  }
+  DFH_HIP(hipGetLastError());
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = any_value;
+  b->has_cnt = false;
+  b->localized = false;
+  b->looked_up = nullptr;
+  return DFH_OK;
+}
+
 namespace {
 // Localizer::Compact of the loaded minibatch; with a table also the key-index probe of dfh_batch_lookup, done by the
 // emit pass itself (the thread that writes a unique key looks it up: one launch and one event record fewer per minibatch)

@@ -202,18 +202,55 @@ void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
   }
 }
 
+namespace {
+// Device feed: the reader's shuffle buffers in HBM.  The reader thread uploads every buffer once, when it becomes current
+// (BatchReader::Describe), into a ring of device row buffers; the worker loop then sends 4 B per row of a minibatch and the
+// rows are gathered on the device (dfh_batch_gather_rows) instead of being copied twice on the host (into the minibatch,
+// into the pinned staging area).  A slot is reused kRing buffers later: every minibatch that names it has been gathered by
+// then (the reader runs at most three minibatches ahead of the loop), and the upload waits for those gathers on the device.
+struct DeviceFeed {
+  static constexpr int kRing = 6;
+  dfh_ctx* ctx = nullptr;
+  dfh_rowbuf* ring[kRing] = {};
+  size_t cap_rows[kRing] = {}, cap_nnz[kRing] = {};
+  void Upload(const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) {   // on the reader's thread
+    const int s = static_cast<int>(serial % kRing);
+    const size_t nnz = blk.offset[blk.size] - blk.offset[0];
+    if (!ring[s] || blk.size > cap_rows[s] || nnz > cap_nnz[s]) {
+      if (ring[s]) DFH_CALL(dfh_rowbuf_destroy(ring[s]));
+      cap_rows[s] = std::max(cap_rows[s], blk.size);
+      cap_nnz[s] = std::max<size_t>(std::max(cap_nnz[s], nnz + nnz / 4), 1);
+      DFH_CALL(dfh_rowbuf_create(ctx, cap_rows[s], cap_nnz[s], &ring[s]));
+    }
+    DFH_CALL(dfh_rowbuf_load_host(ring[s], blk.size, blk.offset, blk.index, blk.value));
+  }
+  dfh_rowbuf* Of(uint64_t serial) const { return ring[serial % kRing]; }
+  ~DeviceFeed() {
+    for (auto* rb : ring)
+      if (rb) dfh_rowbuf_destroy(rb);
+  }
+};
+}  // namespace
+
 // ---- the fused worker loop: sgd_learner.cc:129-227 on the device
 void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool predict = job.type == sgd::Job::kPrediction;
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
-  // minibatches are cut (permutation + row gather) two ahead on the reader's own thread, the reference's reader /
-  // executor overlap (sgd_learner.cc:196-224)
-  PrefetchSource reader(new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
-                                        train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f), 2);
   dfh_ctx* ctx = DeviceContext::Get();
   dfh_table* table = GetUpdater()->table();
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
+  // minibatches are cut (permutation + row selection) two ahead on the reader's own thread, the reference's reader /
+  // executor overlap (sgd_learner.cc:196-224).  Training with a shuffle buffer: the buffers go to HBM and the rows are
+  // gathered there (device feed; DIFACTO_HOST_FEED=1 keeps the host-side gather)
+  DeviceFeed feed;   // outlives the reader, whose thread uploads into it
+  feed.ctx = ctx;
+  const bool device_feed = train && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
+  BatchReader* batch_reader = new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                                              train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  if (device_feed)
+    batch_reader->Describe([&feed](const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) { feed.Upload(blk, serial); });
+  PrefetchSource reader(batch_reader, 2);
   auto ensure = [&](size_t rows, size_t nnz) {
     if (batch_[0] && batch_[1] && rows <= batch_rows_ && nnz <= batch_nnz_) return;
     for (auto& b : batch_) {
@@ -249,7 +286,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       ensure(blk.size, blk.offset[blk.size] - blk.offset[0]);
     }
     dfh_batch* b = batch_[slot];
-    if (getenv("DIFACTO_TRACE")) {
+    if (getenv("DIFACTO_TRACE") && (blk.index || blk.offset[blk.size] == blk.offset[0])) {
       uint64_t cs = 0;
       double ls = 0;
       for (size_t i = blk.offset[0]; i < blk.offset[blk.size]; ++i) cs += blk.index[i] * (i - blk.offset[0] + 1);
@@ -257,7 +294,21 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       LOG(INFO) << "batch rows " << blk.size << " nnz " << blk.offset[blk.size] - blk.offset[0] << " off0 " << blk.offset[0]
                 << " idxsum " << cs << " labsum " << ls << " value " << (blk.value != nullptr);
     }
-    DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
+    const std::vector<RowSeg>& segs = reader.Aux();
+    if (!segs.empty()) {   // a described minibatch: its rows are gathered out of the device-resident buffers
+      std::vector<dfh_rowbuf*> bufs(segs.size());
+      std::vector<const uint32_t*> rows(segs.size());
+      std::vector<size_t> cnts(segs.size());
+      for (size_t g = 0; g < segs.size(); ++g) {
+        bufs[g] = CHECK_NOTNULL(feed.Of(segs[g].buf));
+        rows[g] = segs[g].rows.data();
+        cnts[g] = segs[g].rows.size();
+      }
+      DFH_CALL(dfh_batch_gather_rows(b, blk.size, blk.offset, blk.label, static_cast<int>(segs.size()), bufs.data(), rows.data(),
+                                     cnts.data()));
+    } else {
+      DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
+    }
     DFH_CALL(dfh_localize(b, ~0ULL));  // Localizer lc(-1, ...), sgd_learner.cc:203
     DFH_CALL(dfh_batch_lookup(table, b));  // (dfh_localize_lookup does both in one pass; measured 0.4 % slower per step)
   };

@@ -225,6 +225,19 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b);
  * kernel), so the worker loops use those. */
 int dfh_localize_lookup(dfh_table* t, dfh_batch* b, uint64_t max_index);
 
+/* Device feed.  BatchReader's shuffle buffer (src/reader/batch_reader.cc:38-52: batch_size x shuffle rows, permuted, cut into
+ * minibatches) held in HBM: the host uploads every buffer once (dfh_rowbuf_load_host, callable from a reader thread: it uses a
+ * stream of its own and returns when the caller's arrays are free) and a minibatch is gathered out of at most a few buffers
+ * by row number on the device (dfh_batch_gather_rows, in place of dfh_batch_load_host): `offset` [nrows + 1] and `label`
+ * [nrows] are the minibatch's own (the host knows the row lengths), segment g takes rows[g][0 .. seg_rows[g]) of bufs[g], in
+ * order.  A buffer without values counts as all ones.  The same minibatch as the host-side gather, byte for byte. */
+typedef struct dfh_rowbuf dfh_rowbuf;
+int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** out);
+int dfh_rowbuf_destroy(dfh_rowbuf* rb);
+int dfh_rowbuf_load_host(dfh_rowbuf* rb, size_t nrows, const size_t* offset, const uint64_t* index, const float* value);
+int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg, dfh_rowbuf* const* bufs,
+                          const uint32_t* const* rows, const size_t* seg_rows);
+
 /* already-localized batch from the host (what SGDLearner hands its batch thread,
  * src/sgd/sgd_learner.cc:203-212): feaids sorted unique, compact u32 index */
 int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint32_t* index,

@@ -752,6 +752,70 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
         o.close()
 
 
+@pytest.mark.parametrize("streams", [0, 1])
+def test_device_row_gather_matches_host_load(capi, oracle, streams):
+    """the device feed (dfh_rowbuf_load_host + dfh_batch_gather_rows): minibatches gathered on the device out of shuffle
+    buffers held in HBM — one buffer, two buffers, a buffer without values beside one with, empty rows, repeated rows —
+    must localize and step exactly like the same minibatch copied on the host and sent with dfh_batch_load_host"""
+    rng = np.random.default_rng(41)
+    bufs_host = [random_batch(rng, 900, 700, 30), random_batch(rng, 500, 700, 12, binary=True), random_batch(rng, 300, 700, 40)]
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=5)
+    ctx = capi.Context(0)
+    ctx.set_pipeline(streams)
+    rbs = []
+    for hb in bufs_host:
+        rb = capi.RowBuf(ctx, len(hb["label"]), max(int(hb["offset"][-1]), 1))
+        rb.load_host(hb["offset"], hb["index"], hb["value"])
+        rbs.append(rb)
+
+    def host_minibatch(segments):
+        off, idx, val, lab = [0], [], [], []
+        anyv = any(bufs_host[g]["value"] is not None for g, _ in segments)
+        for g, rows in segments:
+            hb = bufs_host[g]
+            for r in rows:
+                lo, hi = int(hb["offset"][r]), int(hb["offset"][r + 1])
+                idx.append(hb["index"][lo:hi])
+                if anyv:
+                    val.append(hb["value"][lo:hi] if hb["value"] is not None else np.ones(hi - lo, np.float32))
+                lab.append(hb["label"][r])
+                off.append(off[-1] + hi - lo)
+        return dict(offset=np.array(off, np.uint64), index=np.concatenate(idx) if idx else np.zeros(0, np.uint64),
+                    value=np.concatenate(val).astype(np.float32) if anyv else None, label=np.array(lab, np.float32))
+
+    plans = [[(0, rng.permutation(900)[:200])], [(0, rng.permutation(900)[:120]), (2, rng.permutation(300)[:90])],
+             [(1, rng.permutation(500)[:150])], [(1, rng.permutation(500)[:60]), (0, np.array([5, 5, 7, 5]))],
+             [(2, np.arange(300))]]
+    results = []
+    for device in (False, True):
+        tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_HASH, **kw)
+        bt = capi.Batch(ctx, 400, 400 * 40)
+        out = []
+        for step, segments in enumerate(plans * 2):
+            mb = host_minibatch(segments)
+            if device:
+                bt.gather_rows(mb["offset"], mb["label"], [(rbs[g], rows) for g, rows in segments])
+            else:
+                bt.load_host(mb["offset"], mb["index"], mb["value"], mb["label"])
+            bt.localize()
+            got = bt.get_localized()
+            want = oracle.localize(mb["offset"], mb["index"])
+            assert np.array_equal(got["feaids"], want["feaids"]) and np.array_equal(got["index"], want["index"]), (device, step)
+            bt.sgd_step(tb, is_train=True, push_cnt=step < len(plans))
+            out.append(bt.pred())
+        keys = np.unique(np.concatenate([hb["index"] for hb in bufs_host]))
+        results.append((out, tb.pull(oracle.reverse_bytes(keys))))
+        bt.close()
+        tb.close()
+    (p0, (v0, l0)), (p1, (v1, l1)) = results
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(l0, l1) and np.array_equal(v0, v1)
+    for rb in rbs:
+        rb.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("streams,nbatch,prep_lookup", [(1, 2, True), (2, 4, False), (3, 5, True), (1, 3, "fused"), (2, 4, "fused")])
 def test_pipelined_prep_matches_serial(capi, oracle, streams, nbatch, prep_lookup):
     """preparing later batches on 1..3 preparation streams (with as many or more batch objects in

@@ -195,6 +195,33 @@ def test_cli_runs_are_reproducible(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_device_feed_matches_host_feed(built, tmp_path):
+    """training with a shuffle buffer reads through the device feed (shuffle buffers uploaded once, minibatches gathered on
+    the device by row number); DIFACTO_HOST_FEED=1 keeps the host-side gather.  Same minibatches, so the same losses —
+    several buffers, down-sampling (minibatches that straddle two buffers), values and binary data"""
+    import numpy as np
+    from test_ingest import _criteo_text
+    exe = os.path.join(built, "difacto")
+    rng = np.random.default_rng(33)
+    txt = os.path.join(tmp_path, "train.criteo")
+    open(txt, "wb").write(_criteo_text(rng, 4000))
+    runs = {}
+    cases = [("criteo", ["data_in=" + txt, "data_format=criteo", "batch_size=300", "shuffle=2", "neg_sampling=0.7", "V_dim=4", "V_threshold=0",
+                         "l1=.01", "lr=.1", "V_lr=.05", "V_init=hash", "table_capacity=262144", "max_num_epochs=3", "stop_rel_objv=0",
+                         "num_jobs_per_epoch=2"]),
+             ("rcv1", ["argfile=" + _hash_conf(tmp_path, 3, 25), "shuffle=2"])]
+    for name, args in cases:
+        for feed in ("device", "host"):
+            env = dict(os.environ)
+            if feed == "host":
+                env["DIFACTO_HOST_FEED"] = "1"
+            r = subprocess.run([exe, "task=train", "learner=sgd"] + args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            runs[name, feed] = [l.split("] ")[-1] for l in r.stderr.splitlines() if "loss = " in l]
+        assert len(runs[name, "device"]) >= 3 and runs[name, "device"] == runs[name, "host"], (name, runs[name, "device"], runs[name, "host"])
+
+
+@pytest.mark.gpu
 def test_cli_task_predict_matches_the_oracle(built, tmp_path):
     """task=predict (a TODO in the reference's src/main.cc:61-62; sgd_param.h:24-28 names model_in for it): train with
     model_out, then a second process loads model_in and writes one logit per example to pred_out — several data parts
