@@ -8,12 +8,18 @@ using namespace difacto;
 int main(int argc, char** argv) {
   size_t rows = 0, sum = 0;
   for (int rep = 0; rep < 20; ++rep) {
-    PrefetchSource r(new BatchReader(argv[1], "libsvm", 0, 1, 7, rep % 2 ? 35 : 0, rep % 3 ? 1.0f : 0.7f), 1 + rep % 3);
+    BatchReader* br = new BatchReader(argv[1], "libsvm", 0, 1, 7, rep % 2 ? 35 : 0, rep % 3 ? 1.0f : 0.7f);
+    size_t announced = 0;
+    if (rep % 4 == 3)   // describe mode (what the device feed reads): buffers announced on the reader's thread
+      br->Describe([&announced](const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) { announced += blk.size + serial; });
+    PrefetchSource r(br, 1 + rep % 3);
     int n = 0;
     while (r.Next()) {
       const auto& b = r.Value();
       rows += b.size;
-      for (size_t i = b.offset[0]; i < b.offset[b.size]; ++i) sum += b.index[i];
+      for (const RowSeg& g : r.Aux()) sum += g.rows.size() + g.buf;
+      if (b.index)
+        for (size_t i = b.offset[0]; i < b.offset[b.size]; ++i) sum += b.index[i];
       if (++n == 5 && rep % 5 == 4) break;   // a consumer that stops early
     }
   }
