@@ -78,11 +78,10 @@ struct RowBlockContainer {
     size_t nnz = blk.offset[blk.size] - blk.offset[0];
     if (blk.label != nullptr) label.insert(label.end(), blk.label, blk.label + blk.size);
     if (blk.weight != nullptr) weight.insert(weight.end(), blk.weight, blk.weight + blk.size);
-    size_t base = index.size();
-    index.insert(index.end(), blk.index, blk.index + nnz);  // one pass (converts when I != IndexType), no zero fill
-    IndexType mx = max_index;
-    for (size_t i = 0; i < nnz; ++i) mx = std::max(mx, index[base + i]);
-    max_index = mx;
+    // one pass (converts when I != IndexType), no zero fill.  max_index is NOT maintained for appended blocks: nothing on
+    // this path reads it (the Localizer is given its modulus explicitly, src/sgd/sgd_learner.cc:203) and the scan was a
+    // second pass over every byte the shuffle buffer's assembly copies
+    index.insert(index.end(), blk.index, blk.index + nnz);
     if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
     size_t shift = offset.back();
     for (size_t i = 0; i < blk.size; ++i) {
