@@ -479,12 +479,9 @@ int launch_auc(dfh_batch* b) {
   return DFH_OK;
 }
 
-// the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
-// step's k_lookup left per unique key
-int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt) {
+// argument block of k_update_fused for one localized minibatch
+UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt) {
   dfh_ctx* c = b->ctx;
-  hipStream_t s = c->stream;
-  const int L = lanes_for(kp);
   UpdArgs a;
   a.offset = b->d_offset;
   a.index = b->d_index;
@@ -514,6 +511,17 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   a.rg = rg;
   a.p = tv.p;
   a.ileave = (uint32_t)c->upd_interleave;
+  a.nb_hot = a.nb_mid = a.nb_few = 0;
+  return a;
+}
+
+// the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
+// step's k_lookup left per unique key
+int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt) {
+  dfh_ctx* c = b->ctx;
+  hipStream_t s = c->stream;
+  const int L = lanes_for(kp);
+  UpdArgs a = upd_args(b, tv, k, kp, need, uw, rg, add_cnt);
   // blocks per role (U and the list sizes live on the device; nnz bounds them): surplus blocks find their
   // list exhausted and leave at once
   const size_t nnz = b->nnz, G = 64 / (size_t)L;

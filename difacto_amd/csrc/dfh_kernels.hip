@@ -63,6 +63,14 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(t, reinterpret_cast<nt_float4*>(p));
 }
 
+// acc + a * b the way SpMV does it (src/common/spmv.h:125, :155): an operand `a` that is exactly zero is SKIPPED, not
+// multiplied.  Neutral for finite b; for b = Inf / NaN (a non-finite feature value) it is the difference between the
+// reference's result and NaN: a zero weight (pulled as 0: no entry yet, or clipped by l1) and a slope that underflowed to 0
+// do not see the value at all.  The forward applies the same test to the coordinates of V: a key WITHOUT V is skipped by
+// SpMM (V_pos = -1, spmm.h:108) and is an all-zero row here, so the skip reproduces it (the one case left apart: a V
+// coordinate that is exactly 0.0 in an allocated row times a non-finite value, NaN in the reference, skipped here).
+__device__ __forceinline__ float fma_skip0(float a, float b, float acc) { return a != 0.f ? __builtin_fmaf(a, b, acc) : acc; }
+
 // The sharding-independent V init: must match oracle/difacto_oracle.c:orc_hash_init_value
 __device__ __forceinline__ float hash_init_value(uint64_t key, int j, unsigned seed, float scale) {
   uint64_t a = splitmix64(key ^ (0xD1B54A32D192ED03ULL * ((uint64_t)seed + 1ULL)));
@@ -427,7 +435,7 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
           const uint2 e = b.uw[b.index[j]];
           r = e.x & ~(kSingleRow | kCountLater);
           hv = 1u;
-          wsum += __uint_as_float(e.y) * x;
+          wsum = fma_skip0(__uint_as_float(e.y), x, wsum);  // spmv.h:125
         } else {
           const uint32_t u = b.index[j];
           r = src.urow ? src.urow[u] : u;
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
           // {w, has_V} are adjacent: one 8 B load
           float2 wf = *reinterpret_cast<const float2*>(wp);
           hv = __float_as_uint(wf.y);
-          wsum += wf.x * x;
+          wsum = fma_skip0(wf.x, x, wsum);  // spmv.h:125
         }
       }
       const int cnt = min(64u, end - base);
@@ -464,10 +472,12 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
 #pragma unroll
           for (int q = 0; q < FWD_DEPTH; ++q) {
             const float xx = xs[q];
-            xv.x += v[q].x * xx; xv.y += v[q].y * xx; xv.z += v[q].z * xx; xv.w += v[q].w * xx;
+            // zero coordinates (every coordinate of a key without V) are skipped, see fma_skip0
+            xv.x = fma_skip0(v[q].x, xx, xv.x); xv.y = fma_skip0(v[q].y, xx, xv.y);
+            xv.z = fma_skip0(v[q].z, xx, xv.z); xv.w = fma_skip0(v[q].w, xx, xv.w);
             const float x2 = xx * xx;
-            xxvv.x += (v[q].x * v[q].x) * x2; xxvv.y += (v[q].y * v[q].y) * x2;
-            xxvv.z += (v[q].z * v[q].z) * x2; xxvv.w += (v[q].w * v[q].w) * x2;
+            xxvv.x = fma_skip0(v[q].x * v[q].x, x2, xxvv.x); xxvv.y = fma_skip0(v[q].y * v[q].y, x2, xxvv.y);
+            xxvv.z = fma_skip0(v[q].z * v[q].z, x2, xxvv.z); xxvv.w = fma_skip0(v[q].w * v[q].w, x2, xxvv.w);
           }
         }
       }
@@ -674,8 +684,8 @@ __device__ __forceinline__ KeySums wave_segment_sums(const BatchView& b, uint32_
       row = b.s_row[j];
       x = b.s_val ? b.s_val[j] : 1.0f;
       p = b.slope[row];
-      s.gw += p * x;          // spmv.h:160-163
-      s.xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
+      s.gw = fma_skip0(p, x, s.gw);          // spmv.h:155-163
+      s.xxp = fma_skip0(p, x * x, s.xxp);    // fm_loss.h:171-178 with XX = value^2
     }
     if (want_v) {
       const int cnt = min(64u, end - base);
@@ -844,8 +854,8 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
 #pragma unroll
         for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
           const float pp = ps[q], xx = xs[q];
-          s.gw += pp * xx;
-          s.xxp += pp * (xx * xx);
+          s.gw = fma_skip0(pp, xx, s.gw);
+          s.xxp = fma_skip0(pp, xx * xx, s.xxp);
           s.gv.x += (a[q].x * pp) * xx; s.gv.y += (a[q].y * pp) * xx;
           s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
         }
@@ -961,7 +971,7 @@ __device__ __forceinline__ void small_role_lean(const SmallArgs& a, uint32_t wav
 #pragma unroll
         for (int q = 0; q < BWD_SMALL_DEPTH; ++q) {  // ascending rows: the reference's order (spmm.h:137-156)
           const float pp = ps[h][q], xx = xs[h][q];
-          gw[h] += pp * xx; xxp[h] += pp * (xx * xx);
+          gw[h] = fma_skip0(pp, xx, gw[h]); xxp[h] = fma_skip0(pp, xx * xx, xxp[h]);
           gv[h].x += (av[h][q].x * pp) * xx; gv[h].y += (av[h][q].y * pp) * xx;
           gv[h].z += (av[h][q].z * pp) * xx; gv[h].w += (av[h][q].w * pp) * xx;
         }
@@ -1485,6 +1495,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(uint32_t nrows, const u
         const int pj = w_pos ? w_pos[u] : (int)u;
         if (pj < 0) continue;
         const float xj = weights[pj];
+        if (xj == 0.f) continue;  // spmv.h:125
         wsum += value ? xj * value[j] : xj;
       }
     }
@@ -1544,6 +1555,7 @@ __global__ void __launch_bounds__(256) k_calcgrad_generic(uint32_t ncols, const 
       float gw = 0.f;
       for (uint32_t j = beg; j < end; ++j) {  // SpMV::TransTimes, spmv.h:152-168, ascending rows
         const float p = slope[s_row[j]];
+        if (p == 0.f) continue;  // spmv.h:155
         gw += s_val ? p * s_val[j] : p;
       }
       if (pw >= 0) grad[pw] += gw;
@@ -1553,6 +1565,7 @@ __global__ void __launch_bounds__(256) k_calcgrad_generic(uint32_t ncols, const 
       // every lane recomputes XXp serially (identical value, reference order)
       for (uint32_t j = beg; j < end; ++j) {
         const float p = slope[s_row[j]];
+        if (p == 0.f) continue;  // spmv.h:155
         const float x = s_val ? s_val[j] : 1.0f;
         xxp += p * (x * x);
       }

@@ -196,8 +196,8 @@ __device__ __forceinline__ KeySums upd_tile_sums(const UpdArgs& a, uint32_t beg,
     const uint32_t row = ldu_s(a.s_row + j);
     const float x = (HAS_VAL ? ldf_s(a.s_val + j) : 1.0f) * upd_mask(base + lane < end);
     const float p = a.slope[row];
-    s.gw += p * x;          // spmv.h:160-163
-    s.xxp += p * (x * x);   // fm_loss.h:171-178 with XX = value^2
+    s.gw = fma_skip0(p, x, s.gw);          // spmv.h:155-163: a slope that is exactly 0 is skipped
+    s.xxp = fma_skip0(p, x * x, s.xxp);    // fm_loss.h:171-178 with XX = value^2
     const int cnt = (int)min(64u, end - base);
     for (int t0 = 0; t0 < cnt; t0 += DB * G) {
       float4 av[DB];
@@ -380,8 +380,8 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
 #pragma unroll
         for (int d = 0; d < FD; ++d) {  // ascending rows: the reference's order (spmm.h:137-156)
           const float pp = ps[d], xx = xs[d];
-          gw += pp * xx;
-          xxp += pp * (xx * xx);
+          gw = fma_skip0(pp, xx, gw);
+          xxp = fma_skip0(pp, xx * xx, xxp);
           g4.x += (av[d].x * pp) * xx; g4.y += (av[d].y * pp) * xx;
           g4.z += (av[d].z * pp) * xx; g4.w += (av[d].w * pp) * xx;
         }
@@ -392,9 +392,53 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
 }
 
 // ---- singles: example by example
+// one tile of <= 64 nonzeros of example i: lane l holds nonzero base + l (u = rank of its key, x its value, rw its row
+// word, valid = it exists); p = the example's slope, xvi = this lane's slice of XV_i.  Shared by the singles role of
+// k_update_fused (and, in the round-4 experiment noted at the end of this file, by the forward's epilogue).
+template <int L, bool EXACT, int RB>
+__device__ __forceinline__ void upd_singles_tile(const UpdArgs& a, bool valid, uint32_t u, float x, uint32_t rw, float p, const float4 xvi,
+                                                 int grp, int sub, bool sub_ok, int k, int kp, float& pen) {
+  constexpr int G = 64 / L;
+  const int lane = lane_id();
+  const bool single = valid && (rw & (kSingleRow | kRemoteRow)) == kSingleRow && key_in(a.rg, u);
+  const unsigned long long mask = __ballot(single);
+  const int n1 = __popcll(mask);
+  if (n1 == 0) return;
+  // compact the single-occurrence nonzeros to the low lanes (a permutation of the wave: the
+  // others are packed behind them)
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const int dest = (single ? rank : n1 + (lane - rank)) * 4;
+  const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & (kRowMask | kCountLater)));
+  const uint32_t c_u = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)u);
+  const float c_x = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(x)));
+  for (int t0 = 0; t0 < n1; t0 += RB * G) {
+    float4 h0[RB], vv[RB], ac[RB];
+    uint32_t rr[RB], uu[RB];
+    float xs[RB], fcs[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {  // RB * G model rows per round trip; groups past the last key fetch it again
+      const int t = min(t0 + q * G + grp, n1 - 1);
+      rr[q] = __shfl(c_r, t, 64);
+      uu[q] = __shfl(c_u, t, 64);
+      xs[q] = __shfl(c_x, t, 64);
+      upd_load_row(a, rr[q] & kRowMask, sub, sub_ok, kp, h0[q], vv[q], ac[q], fcs[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      if (t0 + q * G + grp < n1) {
+        const float xx = xs[q];
+        // one occurrence: the segmented sums of the other roles with a single term (0 + term)
+        const float gw = p != 0.f ? p * xx : 0.f, xxp = p != 0.f ? p * (xx * xx) : 0.f;  // spmv.h:155
+        const float4 g4 = make_float4((xvi.x * p) * xx, (xvi.y * p) * xx, (xvi.z * p) * xx, (xvi.w * p) * xx);
+        upd_apply<EXACT>(a, rr[q] & kRowMask, uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen, fcs[q], 1.0f,
+                         (rr[q] & kCountLater) != 0u);
+      }
+    }
+  }
+}
+
 template <int L, bool EXACT, int RB, bool HAS_VAL>
 __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
-  constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L, sub = lane % L;
   const int kp = EXACT ? 4 * L : a.kp, k = a.k;
@@ -411,42 +455,24 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
       const uint32_t u = ldu_s(a.index + j);
       const float x = HAS_VAL ? ldf_s(a.value + j) : 1.0f;
       const uint32_t rw = ld_rowword(a.uw + u);
-      const bool single = valid && (rw & (kSingleRow | kRemoteRow)) == kSingleRow && key_in(a.rg, u);
-      const unsigned long long mask = __ballot(single);
-      const int n1 = __popcll(mask);
-      if (n1 == 0) continue;
-      // compact the single-occurrence nonzeros to the low lanes (a permutation of the wave: the
-      // others are packed behind them)
-      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-      const int dest = (single ? rank : n1 + (lane - rank)) * 4;
-      const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & (kRowMask | kCountLater)));
-      const uint32_t c_u = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)u);
-      const float c_x = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(x)));
-      for (int t0 = 0; t0 < n1; t0 += RB * G) {
-        float4 h0[RB], vv[RB], ac[RB];
-        uint32_t rr[RB], uu[RB];
-        float xs[RB], fcs[RB];
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {  // RB * G model rows per round trip; groups past the last key fetch it again
-          const int t = min(t0 + q * G + grp, n1 - 1);
-          rr[q] = __shfl(c_r, t, 64);
-          uu[q] = __shfl(c_u, t, 64);
-          xs[q] = __shfl(c_x, t, 64);
-          upd_load_row(a, rr[q] & kRowMask, sub, sub_ok, kp, h0[q], vv[q], ac[q], fcs[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {
-          if (t0 + q * G + grp < n1) {
-            const float xx = xs[q];
-            // one occurrence: the segmented sums of the other roles with a single term (0 + term)
-            const float gw = p * xx, xxp = p * (xx * xx);
-            const float4 g4 = make_float4((xvi.x * p) * xx, (xvi.y * p) * xx, (xvi.z * p) * xx, (xvi.w * p) * xx);
-            upd_apply<EXACT>(a, rr[q] & kRowMask, uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen, fcs[q], 1.0f,
-                             (rr[q] & kCountLater) != 0u);
-          }
-        }
-      }
+      upd_singles_tile<L, EXACT, RB>(a, valid, u, x, rw, p, xvi, grp, sub, sub_ok, k, kp, pen);
     }
+  }
+}
+
+// penalty of the pulled weights (sgd_learner.cc:249-273): per-lane fp32 partials (a handful of terms each),
+// widened here; one private slot per block (same-address atomics serialise)
+__device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
+  __shared__ double pen_blk[UPD_NW];
+  const uint32_t w = threadIdx.x >> 6;
+  const double pw = wave_sum_d((double)pen);
+  if (lane_id() == 0) pen_blk[w] = pw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < UPD_NW; ++i) t += pen_blk[i];
+    if (t != 0.0) atomicAdd(&prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
   }
 }
 
@@ -489,19 +515,16 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
     if (DFH_UPD_ROLES & 4)
     upd_few_role<L, EXACT, HAS_VAL>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
   }
-  // penalty of the pulled weights (sgd_learner.cc:249-273): per-lane fp32 partials (a handful of terms each),
-  // widened here; one private slot per block (same-address atomics serialise)
-  __shared__ double pen_blk[UPD_NW];
-  const double pw = wave_sum_d((double)pen);
-  if (lane_id() == 0) pen_blk[w] = pw;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < UPD_NW; ++i) t += pen_blk[i];
-    if (t != 0.0) atomicAdd(&a.prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
-  }
+  upd_flush_penalty(a.prog, pen);
 }
 
+// Measured dead end (round 4; profiles/r04a_fwd_singles_ab.txt): the singles role as the EPILOGUE OF THE
+// FORWARD (k_forward_singles: the wave that owns example i updates the example's single-occurrence keys right after its
+// gather, holding p_i and XV_i in registers; upd_singles_tile on the same values, the list roles left to k_update_fused).
+// Bit-identical, built, removed: 86.9 -> 79.6 M examples/sec (83.5 M at 4 waves per SIMD).  (1) The V lines are NOT
+// L2 hits: the 640 waves resident on an XCD gather 10 KB each = 6.4 MB through a 4 MB L2, so the fused kernel read
+// 153.9 MB against 72.8 (forward) + 45 (accumulator and header lines) = 118 expected; forward + update reads only went
+// 205.1 -> 197.8 MB.  (2) The list roles alone are a 33 us chain of dependent round trips (59 MB at 1.8 TB/s) that used
+// to hide under the singles' streaming: 57.5 + 32.8 us serial against 19.9 + 59.3 us.
 }  // namespace dfh
 #endif  // DFH_UPDATE_HIP_

@@ -7,10 +7,10 @@ device: lane groups + wave reductions) can only agree to the rounding noise of t
 proportional to sum|terms|, not to |result| — a result that cancels to ~0 has no relative accuracy in
 either of them.  So every comparison here is
 
-    |got - ref|  <=  rtol * |ref|  +  floor,      floor = 4 * 2^-24 * sqrt(n) * sum|terms|
+    |got - ref|  <=  rtol * |ref|  +  floor,      floor = C_SIGMA * 2^-24 * sqrt(n) * sum|terms|
 
-(2^-24 = fp32 unit roundoff; sqrt(n): random-walk growth of n roundings; 4: the difference of two
-such sums at ~3 sigma), evaluated sum by sum — see predict_bound / calcgrad_bound.  This module computes sum|terms| and n in float64 from the very
+(2^-24 = fp32 unit roundoff; sqrt(n): random-walk growth of n roundings; C_SIGMA = 1 since round 4 — it was
+4 through round 3, where the worst measured err / tol over all kernel-parity cases was 0.199), evaluated sum by sum — see predict_bound / calcgrad_bound.  This module computes sum|terms| and n in float64 from the very
 inputs both sides were given.  Nothing here is imported by the product (difacto_amd/).
 """
 import numpy as np
@@ -81,7 +81,7 @@ def ragged_from_packed(rows, lens, V_dim):
     return np.concatenate(out).astype(np.float32)
 
 
-C_SIGMA = 4.0  # floor = C_SIGMA * 2^-24 * (random-walk rounding of the sums below)
+C_SIGMA = 1.0  # floor = C_SIGMA * 2^-24 * (random-walk rounding of the sums below); 4.0 until round 3 (worst measured err/tol 0.199 -> 0.8)
 
 
 def predict_bound(D, w, V):

@@ -13,7 +13,7 @@ Shapes: the reference's rcv1 fixture with V_dim 8 (BASELINE config C2), ragged r
 V_dim 0 / 4 / 5 / 64 / 128, a hot-key batch (segments of ~1000 occurrences), and the full-size C3
 minibatch (10 000 rows x 39 slots from the 33 M id space) with V_dim 64 and 128.
 
-Tolerance (oracle/tolerance.py): |got - ref| <= 1e-5 |ref| + floor, floor = 4 * 2^-24 * sqrt(n) *
+Tolerance (oracle/tolerance.py): |got - ref| <= 1e-5 |ref| + floor, floor = C_SIGMA (= 1) * 2^-24 * sqrt(n) *
 sum|terms| of every fp32 sum involved, computed in float64 from the same inputs.  On top of that
 the tests require that most values agree at the pure rtol 1e-5 with no floor at all.
 """

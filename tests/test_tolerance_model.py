@@ -1,5 +1,5 @@
 """CPU check of oracle/tolerance.py, the tolerance the GPU kernel-parity tests use
-(tests/test_kernel_parity.py): |got - ref| <= 1e-5 |ref| + 4 * 2^-24 * sqrt(n) * sum|terms|.
+(tests/test_kernel_parity.py): |got - ref| <= 1e-5 |ref| + C_SIGMA * 2^-24 * sqrt(n) * sum|terms|  (C_SIGMA = 1 since round 4; 4 before).
 
   * it admits what it must: the reference's own fp32 results against exact float64 arithmetic,
     and the reference's results when the same terms are summed in a different order
@@ -44,16 +44,16 @@ def test_floor_admits_reference_rounding_and_reordering(oracle, k, binary):
     T, b, loc, lens, W, wp, vp, D, w64, V64, has = _setup(oracle, k, 100 + k, binary)
     po = oracle.fm_predict(k, loc["offset"], loc["index"], b["value"], W, wp, vp)
     p64, floor_p = T.predict_bound(D, w64, V64)
-    assert T.check(po, p64, floor_p, "oracle logits vs float64") < 0.5
+    assert T.check(po, p64, floor_p, "oracle logits vs float64") < 1.0
     idx_r, val_r = _reversed_rows(loc, b["value"])
     pr = oracle.fm_predict(k, loc["offset"], idx_r, val_r, W, wp, vp)
-    assert T.check(pr, po, floor_p, "logits, nonzeros reversed") < 0.7
+    assert T.check(pr, po, floor_p, "logits, nonzeros reversed") < 1.0
     go = oracle.fm_calcgrad(k, loc["offset"], loc["index"], b["value"], b["label"], W, po, wp, vp)
     gw64, gV64, floor_w, floor_V = T.calcgrad_bound(D, b["label"], po, w64, V64, has)
     gw_o, gV_o, _ = T.dense_rows(go, lens, k)
-    assert T.check(gw_o, gw64, floor_w, "oracle grad_w vs float64") < 0.5
+    assert T.check(gw_o, gw64, floor_w, "oracle grad_w vs float64") < 1.0
     if k:
-        assert T.check(gV_o, gV64, floor_V, "oracle grad_V vs float64") < 0.5
+        assert T.check(gV_o, gV64, floor_V, "oracle grad_V vs float64") < 1.0
     # rows in reverse order: every per-key sum runs backwards (spmv.h:152-168 sums in row order)
     n = len(b["label"])
     off = np.asarray(loc["offset"], np.int64)
@@ -63,9 +63,9 @@ def test_floor_admits_reference_rounding_and_reordering(oracle, k, binary):
     val_p = None if b["value"] is None else b["value"][perm]
     gr = oracle.fm_calcgrad(k, off_r, loc["index"][perm], val_p, b["label"][::-1].copy(), W, po[::-1].copy(), wp, vp)
     gw_r, gV_r, _ = T.dense_rows(gr, lens, k)
-    assert T.check(gw_r, gw_o, floor_w, "grad_w, rows reversed") < 0.7
+    assert T.check(gw_r, gw_o, floor_w, "grad_w, rows reversed") < 1.0
     if k:
-        assert T.check(gV_r, gV_o, floor_V, "grad_V, rows reversed") < 0.7
+        assert T.check(gV_r, gV_o, floor_V, "grad_V, rows reversed") < 1.0
 
 
 def test_floor_is_not_vacuous(oracle):
