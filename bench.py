@@ -53,7 +53,12 @@ def parse_args():
     ap.add_argument("--vdim", type=int, default=None)
     ap.add_argument("--l1", type=float, default=None)
     ap.add_argument("--v-threshold", type=int, default=None)
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic batches cycled through")
+    ap.add_argument("--distinct", type=int, default=256,
+                    help="distinct synthetic batches cycled through (independent of --steps; SURVEY 8d asks for a stream of "
+                         "1 000: 256 x 390 000 ids already revisits a batch only every ~30 ms of device time)")
+    ap.add_argument("--no-auc", action="store_true",
+                    help="A/B: leave BinClassMetric::AUC out of the step (the reference computes it for every minibatch, "
+                         "sgd_learner.cc:153-155; the default step does too)")
     ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step region until this many seconds are timed")
     ap.add_argument("--max-reps", type=int, default=20000)
     ap.add_argument("--no-secondary", action="store_true",
@@ -111,7 +116,7 @@ def pmc_traffic(kernels, preset):
     """(HBM bytes per launch, source file) of the first of `kernels` found in the newest committed rocprofv3 PMC
     passes of this preset (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; profiles/rNN_pmc_hbm_traffic[_<preset>].json,
     collected with `rocprofv3 --pmc ... -- python bench.py`, NOT measured in this run), or (None, None)"""
-    suffix = "" if preset in ("c3", "c3-refdefaults") else "_" + preset.replace("-", "_")
+    suffix = "" if preset in ("c3", "c3-refdefaults") else "_" + preset.replace("-", "_")   # "sharded-w1": the 1-rank sharded path
     if isinstance(kernels, str):
         kernels = [kernels]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic%s.json" % suffix)), reverse=True):
@@ -163,7 +168,7 @@ def host_info():
     return dict(nproc=os.cpu_count(), cpu_model=model)
 
 
-def cpu_baseline(batches, V_dim, nbatches, hyper):
+def cpu_baseline(batches, V_dim, nbatches, hyper, with_auc=True):
     """the reference CPU path (oracle/_ref: the reference's own Localizer / SGDUpdater / FMLoss compiled
     here) — or the C restatement when that build is absent — timed on this box's host cores.  The
     sample is `nbatches` batches of the GPU run's own stream; a first, untimed pass over them fills
@@ -193,7 +198,7 @@ def cpu_baseline(batches, V_dim, nbatches, hyper):
     out = None
     for label, nthreads in (("as_shipped", 2), ("scaled", max(2, min(info["nproc"] or 2, 49)))):
         st = R.store_create(V_dim=V_dim, **hyper)
-        stage = dict(localize=0.0, push_count=0.0, pull=0.0, predict_calcgrad=0.0, evaluate=0.0, push_grad=0.0)
+        stage = dict(localize=0.0, push_count=0.0, pull=0.0, predict_calcgrad=0.0, evaluate_auc=0.0, push_grad=0.0)
         rows = 0
         for timed in (False, True):
             for b in batches[:nbatches]:
@@ -212,6 +217,8 @@ def cpu_baseline(batches, V_dim, nbatches, hyper):
                                                    V_pos, nthreads=nthreads)
                 ts.append(time.perf_counter())
                 R.loss_evaluate(b["label"], pred)
+                if with_auc:
+                    R.auc_times_n(b["label"], pred)   # BinClassMetric::AUC, sgd_learner.cc:153-155
                 ts.append(time.perf_counter())
                 st.push(loc["feaids"], ob.GRADIENT, grad, lens)
                 ts.append(time.perf_counter())
@@ -228,7 +235,8 @@ def cpu_baseline(batches, V_dim, nbatches, hyper):
         else:
             out["scaled_threads"] = res
     out["note"] = ("compute only: the reference's worker loop adds 10 ms sleep-polls (sgd_learner.cc:93,221) that are not "
-                   "reproduced here; AUC excluded on both sides")
+                   "reproduced here; Loss::Evaluate and BinClassMetric::AUC of every minibatch %s on both sides"
+                   % ("included" if with_auc else "(AUC) excluded"))
     return out
 
 
@@ -265,7 +273,9 @@ def main():
     if args.gpus > 1 or world > 1 or args.force_sharded:
         if args.transport == "native":
             from difacto_amd import sharded
-            return sharded.bench_main_native(args, rank, world, local_rank, args.hyper)
+            return sharded.bench_main_native(args, rank, world, local_rank, args.hyper,
+                                             cpu_baseline_fn=lambda hb, k_, nb_, hy_: cpu_baseline(hb, k_, nb_, hy_, with_auc=not args.no_auc),
+                                             pmc_traffic_fn=pmc_traffic)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import sharded_harness   # the torch.distributed transport: test infrastructure, not the product path
         return sharded_harness.bench_main(args, rank, world, local_rank, args.hyper)
@@ -290,14 +300,17 @@ def main():
             args.ids = max(fit, 1_000_000)
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42) if criteo else None
     S = synth.NUM_SLOTS if criteo else 0
-    nd = max(1, min(args.distinct, args.steps + args.warmup))
+    nd = max(1, args.distinct)
+    # the synthetic stream is drawn by a helper thread (numpy releases the GIL) while this one fills the model
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(1)
     if criteo:
         capacity = int(args.ids * 1.02) + 4 * B * S
-        host_batches = [gen.batch(B) for _ in range(nd)]
+        bgen = synth.CriteoSynth(total_ids=args.ids, seed=42)   # its own generator object: `gen` serves the prefill
+        fut_batches = pool.submit(lambda: [bgen.batch(B) for _ in range(nd)])
     else:
         capacity = int(args.ids * 1.5) + 4096
-        host_batches = rcv1_shaped_batches(np.random.default_rng(42), nd, B, args.ids)
-    max_nnz = max(int(hb["offset"][-1]) for hb in host_batches)
+        fut_batches = pool.submit(rcv1_shaped_batches, np.random.default_rng(42), nd, B, args.ids)
     table = capi.Table(ctx, capacity, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
 
     t0 = time.time()
@@ -317,6 +330,9 @@ def main():
                 db.close()
     nkeys = table.size()
     t_prefill = time.time() - t0
+    host_batches = fut_batches.result()
+    pool.shutdown()
+    max_nnz = max(int(hb["offset"][-1]) for hb in host_batches)
 
     dev = []
     for hb in host_batches:
@@ -336,6 +352,9 @@ def main():
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
     bts = [capi.Batch(ctx, B, max_nnz) for _ in range(ahead + (2 if depth else 1))]
     bt = bts[0]
+    if not args.no_auc:
+        for b_ in bts:
+            b_.set_option("compute_auc", 1)   # BinClassMetric::AUC of every minibatch, like the reference's loop
 
     def prep(i):
         o, x, l, v, nr, nz = dev[i % nd]
@@ -468,7 +487,7 @@ def main():
         if nb < 0:
             # ~10-20 s of CPU work: two passes (fill + timed) at two thread settings
             nb = max(2, min(nd, int((60000 if k <= 64 else 30000) / max(B, 1)) if criteo else 50))
-        cpu = cpu_baseline(host_batches, k, nb, hyper)
+        cpu = cpu_baseline(host_batches, k, nb, hyper, with_auc=not args.no_auc)
 
     names = {"c3": "C3: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, FTRL(w)+AdaGrad(V), 1 MI355X" % (args.ids, k),
              "c3-refdefaults": "C3 with the reference's default hyper-parameters (sgd_param.h:95-105: l1=1, V_threshold=10): "
@@ -484,7 +503,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": names[args.preset], "preset": args.preset,
                    "rows_per_step": B, "nnz_per_row": s_mean, "unique_keys_per_batch": U_mean,
-                   "step": "device localize + pull + predict + evaluate + calcgrad + push/update",
+                   "step": "device localize + pull + predict + evaluate + %scalcgrad + push/update" % ("" if args.no_auc else "AUC + "),
+                   "auc_every_minibatch": not args.no_auc,
                    "model_keys": int(nkeys), "table_bytes": tbytes, "prefilled": not args.no_prefill, "hyper": hyper,
                    "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
                    "feature_counts_pushed_every_step": not args.later_epoch},

@@ -30,10 +30,11 @@ SYMBOLS = [
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
+    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck",
 ]
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
-K_COUNT = 7
-K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC = range(7)
+K_COUNT = 8
+K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC, K_AUC = range(8)
 
 
 class UpdaterParam(C.Structure):
@@ -180,6 +181,9 @@ def lib():
     L.dfh_shard_pull_host.argtypes = [vp, vp, C.c_size_t, vp, PP(C.c_size_t), vp, PP(C.c_size_t)]
     L.dfh_shard_push_host.argtypes = [vp, vp, C.c_size_t, i32, vp, C.c_size_t, vp, C.c_size_t]
     L.dfh_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
+    L.dfh_comm_stats.argtypes = [vp, i32, vp, vp, vp]
+    L.dfh_comm_info.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.dfh_comm_selfcheck.argtypes = [vp, C.c_double]
     L.dfh_shard_balanced_splits.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfh_shard_set_exchange.argtypes = [vp, i32]
     L.dfh_shard_set_timing.argtypes = [vp, i32]
@@ -667,6 +671,22 @@ class Comm:
         out = np.zeros((lib().dfh_comm_world(self.h),) + a.shape, a.dtype)
         _ck(lib().dfh_comm_allgather(self.h, _p(a), a.nbytes, _p(out)))
         return out
+
+    def stats(self, reset=False):
+        """(bytes sent to other ranks, bytes received from them, message groups) since the last reset"""
+        a, b, g = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _ck(lib().dfh_comm_stats(self.h, 1 if reset else 0, C.byref(a), C.byref(b), C.byref(g)))
+        return a.value, b.value, g.value
+
+    def info(self):
+        """the bound transport: RCCL version + the file it was bound from, or the host callback"""
+        buf = C.create_string_buffer(512)
+        _ck(lib().dfh_comm_info(self.h, buf, 512))
+        return buf.value.decode()
+
+    def selfcheck(self, timeout_s=60.0):
+        """collective start-up check (first exchange polled with a timeout): raises instead of hanging"""
+        _ck(lib().dfh_comm_selfcheck(self.h, float(timeout_s)))
 
     def balanced_splits(self, sample_keys):
         """collective: split keys (world-1, identical on every rank) at the quantiles of the union of the ranks' key samples"""

@@ -46,6 +46,7 @@ struct dfh_ctx {
   // found: 58.7 us; more list blocks cost more in block dispatch than they save in chain length)
   int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
   int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
+  int auc_in_update = 1;       // a training step's AUC as the first blocks of k_update_fused (1) or a launch of its own (0)
   // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
   // consumer of these events is a stream of this device
   int event_flags = 1;
@@ -463,8 +464,8 @@ int launch_auc(dfh_batch* b) {
   const uint32_t n = (uint32_t)b->nrows;
   if (n <= AUC_PAIRS_MAX_N) {
     // minibatch-sized: pair counting, one hand-written launch (k_auc_pairs)
-    hipLaunchKernelGGL(k_auc_pairs, dim3((n + 255) / 256, (n + AUC_TILE - 1) / AUC_TILE), dim3(256), 0, s, b->d_pred, b->d_label, n,
-                       b->d_auc_acc, b->d_prog + PROG_AUC * PROG_SLOTS);
+    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units(n)), dim3(256), 0, s, b->d_pred, b->d_label, n, b->d_auc_acc,
+                       b->d_prog + PROG_AUC * PROG_SLOTS);
     DFH_HIP(hipGetLastError());
     return DFH_OK;
   }
@@ -512,16 +513,29 @@ UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* nee
   a.p = tv.p;
   a.ileave = (uint32_t)c->upd_interleave;
   a.nb_hot = a.nb_mid = a.nb_few = 0;
+  a.auc_pred = nullptr;
+  a.auc_label = nullptr;
+  a.auc_acc = nullptr;
+  a.auc_out = nullptr;
+  a.nb_auc = 0;
   return a;
 }
 
 // the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
 // step's k_lookup left per unique key
-int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt) {
+int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt,
+                        bool with_auc = false) {
   dfh_ctx* c = b->ctx;
   hipStream_t s = c->stream;
   const int L = lanes_for(kp);
   UpdArgs a = upd_args(b, tv, k, kp, need, uw, rg, add_cnt);
+  if (with_auc) {  // the minibatch's AUC rides in this launch (dfh_sgd_step, compute_auc)
+    a.auc_pred = b->d_pred;
+    a.auc_label = b->d_label;
+    a.auc_acc = b->d_auc_acc;
+    a.auc_out = b->d_prog + PROG_AUC * PROG_SLOTS;
+    a.nb_auc = auc_units((uint32_t)b->nrows);
+  }
   // blocks per role (U and the list sizes live on the device; nnz bounds them): surplus blocks find their
   // list exhausted and leave at once
   const size_t nnz = b->nnz, G = 64 / (size_t)L;
@@ -534,7 +548,7 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
     ea = TimeScope::get(c);
     eb = TimeScope::get(c);
   }
-  const dim3 grid((unsigned)(a.nb_hot + a.nb_mid + a.nb_few + nb_single)), block(UPD_THREADS);
+  const dim3 grid((unsigned)(a.nb_auc + a.nb_hot + a.nb_mid + a.nb_few + nb_single)), block(UPD_THREADS);
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
 #define DFH_UPD(EXACT, HV)                                                                              \
@@ -555,8 +569,14 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
 
 template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
-                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr, bool add_cnt = false) {
-  if (FUSED && src.urow && uw && b->ctx->upd_kernel) return launch_update_fused(b, tv, k, kp, need, uw, rg, add_cnt);
+                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr, bool add_cnt = false, bool* auc_rides = nullptr) {
+  if (FUSED && src.urow && uw && b->ctx->upd_kernel) {
+    // auc_rides: in: the caller wants the minibatch's AUC; out: this launch computed it
+    const bool with_auc = auc_rides && *auc_rides && b->nrows <= AUC_PAIRS_MAX_N && UPD_THREADS == 256;
+    if (auc_rides) *auc_rides = with_auc;
+    return launch_update_fused(b, tv, k, kp, need, uw, rg, add_cnt, with_auc);
+  }
+  if (auc_rides) *auc_rides = false;
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
@@ -728,6 +748,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
     DFH_ARG(value >= 1 && value <= 65536, "upd_*_blocks must be in [1, 65536]");
     (n == "upd_hot_blocks" ? c->upd_hot_blocks : n == "upd_mid_blocks" ? c->upd_mid_blocks : n == "upd_few_blocks" ? c->upd_few_blocks
                                                                                                         : c->upd_single_blocks) = value;
+  } else if (n == "auc_in_update") {
+    DFH_ARG(value == 0 || value == 1, "auc_in_update must be 0 (k_auc_pairs as its own launch) or 1 (a role of k_update_fused)");
+    c->auc_in_update = value;
   } else if (n == "upd_interleave") {
     DFH_ARG(value >= 0 && value <= 64, "upd_interleave must be in [0, 64]");
     c->upd_interleave = value;
@@ -787,7 +810,7 @@ int dfh_ctx_get_timing(dfh_ctx* c, int reset, double* total_ms, uint64_t* calls)
 }
 
 const char* dfh_kernel_name(int id) {
-  static const char* names[DFH_K_COUNT] = {"localize", "lookup", "forward", "backward", "pull_rows", "push_grad", "misc"};
+  static const char* names[DFH_K_COUNT] = {"localize", "lookup", "forward", "backward", "pull_rows", "push_grad", "misc", "auc"};
   return (id >= 0 && id < DFH_K_COUNT) ? names[id] : "?";
 }
 
@@ -2405,14 +2428,24 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   RowSrc src = table_src(t, b->d_urow);
   rc = launch_forward(b, src, k, kp, uw);
   if (rc) return rc;
-  if (b->compute_auc) {
+  // BinClassMetric::AUC of every minibatch (sgd_learner.cc:153-155): in a training step it rides in the update launch
+  // (k_update_fused: the pair counting is VALU work beside a memory-bound kernel), otherwise it is a launch of its own
+  bool auc_rides = b->compute_auc && is_train && c->auc_in_update != 0;
+  if (b->compute_auc && !auc_rides) {
+    TimeScope ts(c, DFH_K_AUC);
     rc = launch_auc(b);
     if (rc) return rc;
   }
   if (is_train) {
     if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
-    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw, defer_cnt);
+    const bool wanted = auc_rides;
+    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw, defer_cnt, &auc_rides);
     if (rc) return rc;
+    if (wanted && !auc_rides) {  // k_backward_all ran (upd_kernel = 0) or the minibatch is beyond the pair-counting size
+      TimeScope ts(c, DFH_K_AUC);
+      rc = launch_auc(b);
+      if (rc) return rc;
+    }
     if (refrand) {
       rc = refrand_flush(t, b->d_feaids, b->d_U, Nb, b->d_urow, b->d_need, b->d_rank, b->d_total);
       if (rc) return rc;
@@ -2507,8 +2540,7 @@ int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n,
   DFH_HIP(hipMemsetAsync(d_o, 0, sizeof(double), s));
   if (pairs) {
     DFH_HIP(hipMemsetAsync(d_acc, 0, 8 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_auc_pairs, dim3((unsigned)((n + 255) / 256), (unsigned)((n + AUC_TILE - 1) / AUC_TILE)), dim3(256), 0, s, d_p,
-                       d_l, (uint32_t)n, d_acc, d_o);
+    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units((uint32_t)n)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, d_acc, d_o);
   } else {
     uint32_t* k0 = cv.take<uint32_t>(n);
     uint32_t* k1 = cv.take<uint32_t>(n);

@@ -1791,48 +1791,70 @@ __global__ void __launch_bounds__(1024) k_auc_area(const uint32_t* __restrict__ 
 // BinClassMetric::AUC without a sort, for minibatch-sized n: the reference's area is the number of
 // (positive j, negative i) pairs in which j comes before i in the sorted order (bin_class_metric.h:44-50),
 // and "before" can be decided pair by pair: pred_j < pred_i, ties by index (the order a stable sort gives;
-// std::sort leaves the order of ties unspecified).  n^2 comparisons, 1e8 for a 10 000-row minibatch: a few
-// microseconds of VALU work spread over the chip, no passes over memory, one launch.  Block (bx, by)
-// compares 256 rows i (registers) with AUC_TILE columns j (LDS broadcast reads); the count is an
-// integer, so the result does not depend on the order of the atomics.  The last block to finish
-// turns {area, positives} into AUC * n (:51-53), adds it to *out_slot and zeroes acc for the next call.
+// std::sort leaves the order of ties unspecified).  The count is an integer, so the result does not depend on
+// the order of the atomics.  Round 4: only positive columns are compared (a tile of AUC_TILE examples is
+// compacted to its positives in LDS, any order) and (image of pred, index) is ONE 64-bit key, so a pair costs a
+// broadcast LDS read, one v_cmp_lt_u64 and one add-with-carry: ~2e7 pairs of 2 VALU operations for a 10 000-row
+// minibatch with 25 % positives, where round 3 spent 1e8 pairs of 7.  auc_pairs_block is one unit of work:
+// 256 rows (this block's threads) against the column tiles ct, ct + nct, ...; units are independent and may
+// run as blocks of k_auc_pairs or as a role of k_update_fused (the update launch has idle VALUs: the metric
+// rides along for free).  The last unit to finish turns {area, positives} into AUC * n (:51-53), adds it to
+// *out_slot and zeroes acc for the next call.
 constexpr int AUC_TILE = 1024;
 constexpr uint32_t AUC_PAIRS_MAX_N = 32768;   // beyond: the radix-sort path (n^2 would pass the cost of sorting)
-__global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
-                                                   unsigned long long* __restrict__ acc /* area, positives, finished blocks */,
-                                                   double* __restrict__ out_slot) {
-  __shared__ uint2 col[AUC_TILE];  // {order-preserving image of pred_j, label_j > 0}
+constexpr uint32_t AUC_COL_SPLIT = 4;         // column tiles are dealt to this many units per row tile
+
+__device__ __forceinline__ uint32_t auc_key(float pred) {
+  const uint32_t bits = __float_as_uint(pred + 0.0f);  // -0 and +0 compare equal in the reference: one image
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__host__ __device__ inline uint32_t auc_units(uint32_t n) {  // units of work for n examples
+  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
+  return ((n + 255) / 256) * (ntile < AUC_COL_SPLIT ? ntile : AUC_COL_SPLIT);
+}
+
+// unit `unit` of auc_units(n): 256-thread blocks only
+__device__ __forceinline__ void auc_pairs_block(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n, uint32_t unit,
+                                                unsigned long long* __restrict__ acc /* area, positives, finished units */,
+                                                double* __restrict__ out_slot) {
+  __shared__ unsigned long long colp[AUC_TILE];  // positives of the current column tile: image of pred_j << 32 | j
+  __shared__ uint32_t npos_tile;
   __shared__ uint32_t red[4];
-  const uint32_t j0 = blockIdx.y * AUC_TILE;
-  const uint32_t lim = min((uint32_t)AUC_TILE, n - j0);
-  for (uint32_t t = threadIdx.x; t < lim; t += blockDim.x) {
-    const uint32_t bits = __float_as_uint(pred[j0 + t] + 0.0f);  // -0 and +0 compare equal in the reference: one image
-    col[t] = make_uint2((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u), label[j0 + t] > 0 ? 1u : 0u);
-  }
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t ki = 0;
+  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
+  const uint32_t nct = ntile < AUC_COL_SPLIT ? ntile : AUC_COL_SPLIT;
+  const uint32_t rt = unit / nct, ct = unit % nct;
+  const uint32_t i = rt * 256u + threadIdx.x;
+  unsigned long long ki = 0;
   bool neg = false, pos = false;
   if (i < n) {
-    const uint32_t bits = __float_as_uint(pred[i] + 0.0f);
-    ki = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    ki = ((unsigned long long)auc_key(pred[i]) << 32) | i;
     pos = label[i] > 0;
     neg = !pos;
   }
-  __syncthreads();
   uint32_t cnt = 0;
+  for (uint32_t tile = ct; tile < ntile; tile += nct) {
+    __syncthreads();  // the previous tile has been consumed
+    if (threadIdx.x == 0) npos_tile = 0;
+    __syncthreads();
+    const uint32_t j0 = tile * AUC_TILE;
+    const uint32_t lim = min((uint32_t)AUC_TILE, n - j0);
+    for (uint32_t t = threadIdx.x; t < lim; t += 256u) {
+      const uint32_t j = j0 + t;
+      if (label[j] > 0) colp[atomicAdd(&npos_tile, 1u)] = ((unsigned long long)auc_key(pred[j]) << 32) | j;
+    }
+    __syncthreads();
+    const uint32_t np = npos_tile;
 #pragma unroll 8
-  for (uint32_t t = 0; t < lim; ++t) {
-    const uint2 c = col[t];
-    const bool before = c.x < ki || (c.x == ki && j0 + t < i);
-    cnt += (c.y != 0u && before) ? 1u : 0u;
+    for (uint32_t t = 0; t < np; ++t) cnt += colp[t] < ki ? 1u : 0u;  // (pred_j, j) before (pred_i, i)
   }
   if (!neg) cnt = 0;
-  uint32_t npos = (blockIdx.y == 0 && pos) ? 1u : 0u;
+  uint32_t npos = (ct == 0 && pos) ? 1u : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     cnt += __shfl_xor(cnt, o, 64);
     npos += __shfl_xor(npos, o, 64);
   }
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1843,7 +1865,7 @@ __global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pre
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+    const unsigned long long total = auc_units(n);
     if (atomicAdd(&acc[2], 1ULL) + 1 == total) {
       const double area = (double)__hip_atomic_load(&acc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       const double tp = (double)__hip_atomic_load(&acc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1861,6 +1883,11 @@ __global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pre
       acc[2] = 0;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
+                                                   unsigned long long* __restrict__ acc, double* __restrict__ out_slot) {
+  auc_pairs_block(pred, label, n, blockIdx.x, acc, out_slot);
 }
 
 // table export: one thread per hash slot

@@ -32,6 +32,10 @@
 #ifndef DFH_SHARD_HIP_
 #define DFH_SHARD_HIP_
 #include <dlfcn.h>
+#include <link.h>
+
+#include <chrono>
+#include <thread>
 
 namespace dfh {
 
@@ -48,16 +52,39 @@ struct RcclApi {
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  std::string path;        // the file ncclSend was bound from (dladdr)
+  bool was_loaded = false; // the process already carried this library (e.g. the copy inside torch/lib)
 };
+
+// a library of the process whose file name contains "librccl": a host that already carries RCCL (PyTorch bundles
+// one) must share it — two RCCLs in one process would each run their own bootstrap and proxy threads
+inline int rccl_phdr_cb(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+    *static_cast<std::string*>(out) = info->dlpi_name;
+    return 1;
+  }
+  return 0;
+}
 
 inline RcclApi* rccl_api() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
+    // (1) whatever RCCL the process has already mapped, by its own path; (2) a loaded library under the usual
+    // sonames; (3) load one
+    std::string loaded;
+    dl_iterate_phdr(rccl_phdr_cb, &loaded);
+    if (!loaded.empty()) api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
-      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    }
+    api.was_loaded = api.lib != nullptr;
+    for (const char* n : names) {
+      if (api.lib) break;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!api.lib) return;
 #define DFH_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name))
@@ -69,7 +96,10 @@ inline RcclApi* rccl_api() {
     DFH_SYM(Recv, "ncclRecv");
     DFH_SYM(GroupStart, "ncclGroupStart");
     DFH_SYM(GroupEnd, "ncclGroupEnd");
+    DFH_SYM(GetVersion, "ncclGetVersion");
 #undef DFH_SYM
+    Dl_info di;
+    if (api.Send && dladdr(reinterpret_cast<void*>(api.Send), &di) && di.dli_fname) api.path = di.dli_fname;
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
       dlclose(api.lib);
       api.lib = nullptr;
@@ -110,6 +140,8 @@ struct dfh_comm {
   char* h_send = nullptr;               // pinned staging of the callback transport
   char* h_recv = nullptr;
   size_t h_cap = 0;
+  // payload this rank handed to / took from OTHER ranks since the last reset, and the message groups it took
+  uint64_t bytes_sent = 0, bytes_recv = 0, groups = 0;
 };
 
 struct dfh_shard {
@@ -184,6 +216,13 @@ struct XPart {
 int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = nullptr) {
   hipStream_t s = on ? on : c->ctx->stream;
   const int W = c->world;
+  for (int i = 0; i < nparts; ++i)
+    for (int p = 0; p < W; ++p)
+      if (p != c->rank) {
+        c->bytes_sent += parts[i].send_b[p];
+        c->bytes_recv += parts[i].recv_b[p];
+      }
+  ++c->groups;
   if (c->rccl) {
     RcclApi* a = rccl_api();
     bool any = false;
@@ -358,6 +397,75 @@ int dfh_comm_allreduce_sum(dfh_comm* c, double* vals, int n) {
     double s = 0;
     for (int p = 0; p < W; ++p) s += h[(size_t)p * n + i];  // rank order: the same sum on every rank
     vals[i] = s;
+  }
+  return DFH_OK;
+}
+
+int dfh_comm_stats(dfh_comm* c, int reset, uint64_t* bytes_sent, uint64_t* bytes_recv, uint64_t* groups) {
+  DFH_ARG(c, "dfh_comm_stats: NULL communicator");
+  if (bytes_sent) *bytes_sent = c->bytes_sent;
+  if (bytes_recv) *bytes_recv = c->bytes_recv;
+  if (groups) *groups = c->groups;
+  if (reset) c->bytes_sent = c->bytes_recv = c->groups = 0;
+  return DFH_OK;
+}
+
+int dfh_comm_info(dfh_comm* c, char* buf, size_t n) {
+  DFH_ARG(c && buf && n >= 1, "dfh_comm_info: bad argument");
+  std::string t;
+  if (c->rccl) {
+    RcclApi* a = rccl_api();
+    int v = 0;
+    if (a && a->GetVersion) a->GetVersion(&v);
+    t = "rccl " + std::to_string(v) + " from " + (a ? a->path : std::string("?")) +
+        (a && a->was_loaded ? " (already loaded by the host process)" : " (loaded by libdifacto_hip)");
+  } else {
+    t = "host callback transport";
+  }
+  snprintf(buf, n, "%s", t.c_str());
+  return DFH_OK;
+}
+
+// start-up self-check: every rank contributes rank + 1 to an all-to-all and must read world (world + 1) / 2 back.
+// The exchange is queued and then POLLED: a peer that never joined (bad rendezvous, wrong world size, a dead rank)
+// makes this return DFH_ERR_STATE after timeout_s seconds instead of hanging the job in its first step.
+int dfh_comm_selfcheck(dfh_comm* c, double timeout_s) {
+  DFH_ARG(c && timeout_s > 0, "dfh_comm_selfcheck: bad argument");
+  dfh_ctx* ctx = c->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int W = c->world;
+  int rc = ensure_scratch(ctx, 2 * (size_t)W * sizeof(double) + 512);
+  if (rc) return rc;
+  Carver cv(ctx->scratch);
+  double* d_s = cv.take<double>(W);
+  double* d_r = cv.take<double>(W);
+  std::vector<double> h(W, (double)(c->rank + 1));
+  DFH_HIP(hipMemcpyAsync(d_s, h.data(), W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  DFH_HIP(hipMemsetAsync(d_r, 0, W * sizeof(double), ctx->stream));
+  std::vector<size_t> cnt(W, sizeof(double));
+  rc = comm_alltoallv(c, d_s, cnt.data(), d_r, cnt.data());
+  if (rc) return rc;
+  DFH_HIP(hipMemcpyAsync(h.data(), d_r, W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) {
+      set_error(std::string("dfh_comm_selfcheck: ") + hipGetErrorString(q));
+      return DFH_ERR_HIP;
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      set_error("dfh_comm_selfcheck: the first exchange did not complete within " + std::to_string((int)timeout_s) +
+                " s — a rank is missing or the rendezvous is wrong (rank " + std::to_string(c->rank) + " of " + std::to_string(W) + ")");
+      return DFH_ERR_STATE;
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  }
+  double sum = 0;
+  for (int p = 0; p < W; ++p) sum += h[p];
+  if (sum != 0.5 * W * (W + 1)) {
+    set_error("dfh_comm_selfcheck: the ranks' ids do not add up (got " + std::to_string(sum) + "): duplicate or missing ranks");
+    return DFH_ERR_STATE;
   }
   return DFH_OK;
 }

@@ -83,6 +83,13 @@ struct UpdArgs {
   int k, kp;
   KeyRange rg;              // sharded store: only the keys this rank owns
   dfh_updater_param p;
+  // BinClassMetric::AUC of the minibatch's predictions as the first nb_auc blocks of the launch (auc_pairs_block:
+  // VALU work beside a memory-bound kernel), or nb_auc = 0
+  const float* auc_pred;
+  const float* auc_label;
+  unsigned long long* auc_acc;
+  double* auc_out;
+  uint32_t nb_auc;
 };
 
 // Model rows (V, accumulators) are loaded and stored with streaming (nt) hints.  Measured dead end, kept as
@@ -478,14 +485,18 @@ __device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
 
 template <int L, bool EXACT, bool HAS_VAL>
 __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
+  if (blockIdx.x < a.nb_auc) {  // uniform per block
+    auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_acc, a.auc_out);
+    return;
+  }
   float pen = 0.f;
   const uint32_t w = threadIdx.x >> 6;
   // block -> role.  The list roles (hot, mid, few) are chains of dependent round trips on few bytes, the singles
   // stream most of the launch's HBM traffic: dispatched in that order the former would hold every block slot of
   // the chip for the length of their chains before the first model row moves.  Interleaved 1 : (R - 1) both kinds
   // are resident from the start.
-  const uint32_t nb_list = a.nb_hot + a.nb_mid + a.nb_few, nb_single = gridDim.x - nb_list;
-  uint32_t bid = blockIdx.x;
+  const uint32_t nb_list = a.nb_hot + a.nb_mid + a.nb_few, nb_single = gridDim.x - a.nb_auc - nb_list;
+  uint32_t bid = blockIdx.x - a.nb_auc;
   bool list_role = bid < nb_list;
   if (a.ileave > 1u) {
     // groups of [one list block, R - 1 singles blocks] while both kinds last, then the rest: list blocks, singles blocks

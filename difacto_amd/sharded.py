@@ -52,7 +52,10 @@ def owner_of(keys, splits):
 
 
 # --------------------------------------------------------------------------- bench (N > 1), native transport
-def bench_main_native(args, rank, world, local_rank, hyper):
+XGMI_LINK_GBPS = 153.6   # per link, both directions together; 7 links per MI355X, one to every peer of the node
+
+
+def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None, pmc_traffic_fn=None):
     """bench.py --gpus N under torchrun, the exchange inside libdifacto_hip.so (dfh_shard_step over RCCL
     ncclSend / ncclRecv): weak scaling, every rank trains its own B-row minibatch per step against the
     key-range-sharded model, zero staleness.  torch.distributed (gloo) only carries the rendezvous id,
@@ -92,6 +95,9 @@ def bench_main_native(args, rank, world, local_rank, hyper):
         ids = [capi.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = capi.Comm.rccl(ctx, rank, world, ids[0])
+    # a bad rendezvous (a rank that never joins) fails here within a minute instead of hanging the first step
+    comm.selfcheck(float(os.environ.get("DFH_SELFCHECK_TIMEOUT", "60")))
+    comm_info = comm.info()
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
     splits = None
@@ -123,13 +129,19 @@ def bench_main_native(args, rank, world, local_rank, hyper):
     if args.exchange == "overlap":
         shard.set_exchange("overlap")
     gen.rng = np.random.default_rng(1000 + rank)   # every rank draws its own stream (different data parts, sgd_learner.cc:78-89)
-    nd = max(1, min(args.distinct, args.steps + args.warmup))
+    nd = max(1, args.distinct)
     dev = []
+    host_sample = []   # rank 0 keeps a few host batches for the CPU baseline
     for _ in range(nd):
         hb = gen.batch(B)
+        if rank == 0 and len(host_sample) < 8:
+            host_sample.append(hb)
         dev.append((capi.DeviceBuffer.from_numpy(ctx, hb["offset"].astype(np.uint32)), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
                     capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
     bts = [capi.Batch(ctx, B, B * S) for _ in range(3)]
+    if not getattr(args, "no_auc", False):
+        for b_ in bts:
+            b_.set_option("compute_auc", 1)   # BinClassMetric::AUC of every minibatch (sgd_learner.cc:153-155)
 
     def prep(i):
         o, x, l = dev[i % nd]
@@ -179,11 +191,14 @@ def bench_main_native(args, rank, world, local_rank, hyper):
 
     # the K-step region is repeated until min_time seconds are timed (every rank derives the same count from the
     # all-reduced time of the first region); the reported time is the median region
+    comm.stats(reset=True)
     reps = [region()]
     more = int(min(max(np.ceil(args.min_time / max(reps[0], 1e-9)) - 1, 0), args.max_reps - 1))
     for _ in range(more):
         reps.append(region())
     dt = float(sorted(reps)[len(reps) // 2])
+    x_sent, x_recv, x_groups = comm.stats(reset=True)
+    x_steps = len(reps) * args.steps
     fwd_t = ctx.get_timing(reset=True).get("forward", (0.0, 0)) if mask else (0.0, 0)
     table.check()
     # per-stage device time from a separate, instrumented pass (NOT part of the timed region): HIP events around the
@@ -204,7 +219,15 @@ def bench_main_native(args, rank, world, local_rank, hyper):
         stage_ms = {n: round(float(v), 5) for n, v in zip(names, per.tolist())}
     progs = [b.progress(reset=True) for b in bts]
     U_last = bts[(done - 1) % len(bts)].shape()[2]
-    tot = comm.allreduce_sum([sum(p.loss for p in progs), sum(p.nrows for p in progs), float(U_last)])
+    tot = comm.allreduce_sum([sum(p.loss for p in progs), sum(p.nrows for p in progs), float(U_last),
+                              float(x_sent), float(x_recv)])
+    cpu = None
+    if rank == 0 and cpu_baseline_fn is not None and args.cpu_batches != 0:
+        # the reference's CPU path on rank 0's host cores, on a bounded sample of rank 0's own stream (the other ranks
+        # wait at the barrier below); the same function as the N = 1 line
+        nb = args.cpu_batches if args.cpu_batches > 0 else max(2, min(len(host_sample), int((60000 if k <= 64 else 30000) / max(B, 1))))
+        base_hyper = dict(hyper, lr=hyper["lr"] * world, V_lr=hyper["V_lr"] * world)
+        cpu = cpu_baseline_fn(host_sample, k, min(nb, len(host_sample)), base_hyper)
     if rank == 0:
         ex_per_s = args.steps * B * world / dt
         r_g = S * (1 + k) * 4
@@ -212,9 +235,27 @@ def bench_main_native(args, rank, world, local_rank, hyper):
         if fwd_t[1] > 0:
             fwd_ms = fwd_t[0] / fwd_t[1]
             achieved = B * r_g / (fwd_ms * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel="k_forward (rows pulled into the exchange layout, rank 0)", achieved=achieved,
-                            peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=None,
+            tr, tr_src = pmc_traffic_fn(["k_forward<"], "sharded-w1") if pmc_traffic_fn else (None, None)
+            roofline = dict(bound="hbm", kernel="k_forward (own keys read in the table, the others in the pulled rows; rank 0)",
+                            achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=tr,
+                            traffic_source=tr_src, traffic_note="counters of a committed ONE-rank run of this code path "
+                            "(--force-sharded), not of this run" if tr else None,
                             algorithmic_bytes_per_launch=B * r_g, avg_launch_ms=fwd_ms, launches_timed=int(fwd_t[1]))
+        # the exchange against the links: payload this GPU sent + received per step (keys and epoch-0 counts out, rows back,
+        # gradient rows out; the same three for the keys it owns) over the device time of the K, RW and G stages
+        roofline_x = None
+        if True:   # one rank: zero bytes, zero time — the block is still there so that the line has one shape for every N
+            per_gpu_step = (tot[3] + tot[4]) / world / max(x_steps, 1)
+            x_ms = (stage_ms["K"] + stage_ms["RW"] + stage_ms["G"]) if stage_ms else None
+            peak = 7 * XGMI_LINK_GBPS
+            links = max(world - 1, 1)
+            ach = per_gpu_step / (x_ms * 1e-3) / 1e9 if x_ms else None
+            roofline_x = dict(bound="xgmi", stages="K + RW + G (device time of the three all-to-all-v stages, instrumented pass, max over ranks)",
+                              bytes_per_gpu_step=per_gpu_step, exchange_ms_per_step=x_ms, achieved=ach, peak=peak, unit="GB/s",
+                              frac=(ach / peak) if ach is not None else None, links_in_use=min(world - 1, 7),
+                              frac_of_links_in_use=(ach / (links * XGMI_LINK_GBPS)) if ach is not None else None,
+                              peak_note="7 xGMI links x 153.6 GB/s per GPU, both directions together; with N ranks N - 1 links carry traffic",
+                              message_groups_per_step=x_groups / max(x_steps, 1))
         out = {
             "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
             "value": ex_per_s, "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,11 +277,13 @@ def bench_main_native(args, rank, world, local_rank, hyper):
                        "lr_scaled_by_world": {"lr": hyper["lr"], "V_lr": hyper["V_lr"], "divided_by": world,
                                               "why": "a key present in every worker's minibatch receives `world` pushes per step"},
                        "transport": "host callback over gloo (dry run, ranks share devices)" if shared else "RCCL ncclSend/ncclRecv",
+                       "transport_bound": comm_info, "distinct_batches_per_rank": nd,
+                       "auc_every_minibatch": not getattr(args, "no_auc", False),
                        "owned_keys_rank0": int(owned)},
             "stage_ms_per_step": stage_ms,
             "stage_ms_per_step_note": "separate instrumented pass; max over ranks per stage; counts/K/G/RW run on the "
                                       "collectives' stream in overlap mode and overlap F/R/P on the main stream",
-            "roofline": roofline, "cpu_baseline": None,
+            "roofline": roofline, "roofline_exchange": roofline_x, "cpu_baseline": cpu,
             "train_logloss_per_example": tot[0] / max(tot[1], 1.0),
             "hbm_gbps_step_algorithmic": ex_per_s * r_g / 1e9,
             "prefill_seconds": t_prefill,

@@ -87,13 +87,16 @@ int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
  *   "fwd_blocks"        0 .. 16384      cap on the forward grid, 0 = one wave per example (default)
  *   "bwd_small_blocks"  1 .. 65536      cap on the short-segment blocks of the backward launch (default 2048)
  *   "prep_priority"     -1 | 0 | 1      stream priority of the preparation streams: lowest (default),
- *                                       normal, highest; before dfh_ctx_set_pipeline creates them */
+ *                                       normal, highest; before dfh_ctx_set_pipeline creates them
+ *   "upd_kernel", "upd_*_blocks", "upd_interleave", "event_flags": see csrc/dfh_api.hip (measurement switches)
+ *   "auc_in_update"     0 | 1           BinClassMetric::AUC of a training step (batch option "compute_auc") as the first
+ *                                       blocks of the update launch (default 1) or as a launch of its own */
 int dfh_ctx_set_option(dfh_ctx* ctx, const char* name, int value);
 
 /* optional per-kernel timing with HIP events recorded on the context's stream
  * (what bench.py's roofline block reads); ids index total_ms[]/calls[] */
 enum {
-  DFH_K_LOCALIZE = 0, DFH_K_LOOKUP, DFH_K_FORWARD, DFH_K_BACKWARD, DFH_K_PULL, DFH_K_PUSH, DFH_K_MISC, DFH_K_COUNT
+  DFH_K_LOCALIZE = 0, DFH_K_LOOKUP, DFH_K_FORWARD, DFH_K_BACKWARD, DFH_K_PULL, DFH_K_PUSH, DFH_K_MISC, DFH_K_AUC, DFH_K_COUNT
 };
 int dfh_ctx_set_timing(dfh_ctx* ctx, int enable);
 /* time only the kernels whose bit (1u << DFH_K_*) is set.  Single-launch kernels (forward,
@@ -342,6 +345,17 @@ int dfh_comm_world(dfh_comm* c);
 int dfh_comm_allreduce_sum(dfh_comm* c, double* vals, int n);
 /* every rank's `bytes` host bytes to every rank: recv holds world * bytes, in rank order.  COLLECTIVE. */
 int dfh_comm_allgather(dfh_comm* c, const void* send, size_t bytes, void* recv);
+/* payload bytes this rank has sent to / received from OTHER ranks and the number of message groups, since the last
+ * reset (what the N > 1 bench line prices against the xGMI links: `roofline_exchange`) */
+int dfh_comm_stats(dfh_comm* c, int reset, uint64_t* bytes_sent, uint64_t* bytes_recv, uint64_t* groups);
+/* which transport is bound: "rccl <version> from <file> (already loaded by the host process | loaded by libdifacto_hip)"
+ * or "host callback transport".  A host that already carries an RCCL (PyTorch bundles one) shares it. */
+int dfh_comm_info(dfh_comm* c, char* buf, size_t n);
+/* start-up self-check, collective: a first exchange of the ranks' ids, polled; DFH_ERR_STATE after timeout_s seconds
+ * if a peer never joins (bad rendezvous) or if the ids do not add up — fails loudly instead of hanging the first step.
+ * The reference's Store has no such call: its ps-lite van blocks in Postoffice::Barrier (include/difacto/store.h:53-93
+ * is the interface this transport serves). */
+int dfh_comm_selfcheck(dfh_comm* c, double timeout_s);
 /* Split keys that balance the shards on the DATA instead of on the key space: every rank hands in a sample of the
  * reversed keys it will see (n may differ per rank, 0 allowed); the samples are gathered and splits[world-1] receives
  * the (identical on every rank) quantiles of their union — the argument for dfh_shard_create.  With feature-group ids

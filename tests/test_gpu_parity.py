@@ -1006,23 +1006,41 @@ def test_auc_with_tied_predictions(capi, ctx, n):
     assert ctx.auc_times_n(lab, pred) == pytest.approx(exact, rel=1e-6)
 
 
-def test_fused_step_auc(capi, ctx, oracle):
-    rng = np.random.default_rng(4)
-    b = random_batch(rng, 300, 2000, 20, empty_rows=False)
+@pytest.mark.parametrize("auc_in_update", [1, 0])
+@pytest.mark.parametrize("nrows,V_dim", [(300, 4), (5000, 16), (10000, 0)])
+def test_fused_step_auc(capi, oracle, auc_in_update, nrows, V_dim):
+    """BinClassMetric::AUC of every minibatch inside dfh_sgd_step (sgd_learner.cc:153-155): as the first blocks of the
+    update launch (the default of a training step) and as a launch of its own (validation steps; auc_in_update = 0) —
+    both against the reference's value on the step's own predictions, several column tiles and row tiles, training
+    and validation steps mixed"""
+    rng = np.random.default_rng(4 + nrows)
+    b = random_batch(rng, nrows, 20 * nrows, 20, empty_rows=False)
     kw = dict(l1=0.01, l2=0.0, lr=0.2, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.3, seed=1)
-    tb = capi.Table(ctx, 1 << 14, V_dim=4, **kw)
-    bt = capi.Batch(ctx, 300, int(b["offset"][-1]))
+    ctx = capi.Context(0)
+    ctx.set_option("auc_in_update", auc_in_update)
+    tb = capi.Table(ctx, 1 << 19, V_dim=V_dim, **kw)
+    bt = capi.Batch(ctx, nrows, int(b["offset"][-1]))
     bt.set_option("compute_auc", 1)
-    for it in range(3):
+    checked = 0
+    for it in range(4):
         bt.load_host(b["offset"], b["index"], b["value"], b["label"])
         bt.localize()
-        bt.sgd_step(tb, is_train=True, push_cnt=(it == 0))
+        bt.sgd_step(tb, is_train=(it != 2), push_cnt=(it == 0))
         pred = bt.pred()
         prog = bt.progress(reset=True)
-        if len(np.unique(pred)) == len(pred):
-            assert prog.auc == pytest.approx(oracle.auc_times_n(b["label"], pred), rel=1e-6)
-    tb.close()
-    bt.close()
+        # the definition (bin_class_metric.h:35-56) in exact arithmetic; ties by index (what a stable sort gives: at it == 0
+        # every prediction is 0 — the reference's std::sort leaves the order of ties unspecified)
+        lab = (b["label"] > 0)[np.lexsort((np.arange(nrows), pred))]
+        area, tp = float(np.sum(np.cumsum(lab)[~lab])), float(lab.sum())
+        a = area / (tp * (nrows - tp))
+        assert prog.auc == pytest.approx((1 - a if a < 0.5 else a) * nrows, rel=3e-7)   # dfh_progress.auc is a float
+        if len(np.unique(pred)) == len(pred):   # and the restatement, within its fp32 accumulation (area, cum_tp are floats there)
+            assert prog.auc == pytest.approx(oracle.auc_times_n(b["label"], pred), rel=1e-5)
+            checked += 1
+    assert checked >= 2
+    for o in (bt, tb):
+        o.close()
+    ctx.close()
 
 
 def test_config_c2_rcv1_vdim8(capi, ctx, oracle, rcv1):

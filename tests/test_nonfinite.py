@@ -105,9 +105,9 @@ def test_restatement_matches_reference_on_nonfinite_values(oracle, ref, k):
     assert np.array_equal(go[f], gr[f])
 
 
-def test_zero_slope_is_skipped_like_the_reference(oracle, ref):
-    """V_dim = 0 (no clamp): logits of +-1000 make the slope exactly -+0 for examples on the right side of their label;
-    TransTimes skips them (spmv.h:155), so an Inf value in such a row does not reach the gradient"""
+def _zero_slope_scenario(oracle):
+    """V_dim = 0 (no clamp): a logit of +1000 on a positive example makes its slope exactly -0 (exp overflows); the row also
+    carries an Inf value on a key of zero weight"""
     rng = np.random.default_rng(5)
     b = _batch(rng, 0, nrows=80, nkeys=120, s=6)
     loc = oracle.localize(b["offset"], b["index"])
@@ -120,14 +120,20 @@ def test_zero_slope_is_skipped_like_the_reference(oracle, ref):
     val[off[0]] = 1.0
     b["label"][0] = 1.0            # y pred = +1000 -> exp = inf -> p = -0
     # poison another nonzero of row 0 whose key has zero weight
-    u2 = loc["index"][off[0] + 1]
-    if u2 == big:
-        u2 = loc["index"][off[0] + 2]
-        val[off[0] + 2] = np.inf
-    else:
-        val[off[0] + 1] = np.inf
+    j2 = off[0] + 1 if loc["index"][off[0] + 1] != big else off[0] + 2
+    u2 = loc["index"][j2]
+    val[j2] = np.inf
     W[u2] = 0.0
+    for j in range(off[0], off[1]):   # no other nonzero of row 0 may share the two special keys
+        if j not in (off[0], j2) and loc["index"][j] in (big, u2):
+            val[j] = 0.0
     b["value"] = val
+    return b, loc, W, u2
+
+
+def test_zero_slope_is_skipped_like_the_reference(oracle, ref):
+    """TransTimes skips a slope that is exactly 0 (spmv.h:155), so an Inf value in such a row does not reach the gradient"""
+    b, loc, W, u2 = _zero_slope_scenario(oracle)
     pr, gr = ref.fm_predict_calcgrad(0, loc["offset"], loc["index"], b["value"], b["label"], W)
     assert np.isfinite(pr[0]) and pr[0] > 500
     go = oracle.fm_calcgrad(0, loc["offset"], loc["index"], b["value"], b["label"], W, pr)
@@ -224,3 +230,46 @@ def test_hip_fused_step_on_nonfinite_values(capi, ctx, oracle, k):
     assert np.isfinite(vo).sum() > 0.3 * len(vo)
     tb.close()
     bt.close()
+
+
+@pytest.mark.gpu
+def test_hip_zero_slope_is_skipped(capi, ctx, oracle):
+    """k_backward_all (gradient rows) and the fused update, V_dim = 0: the example whose slope underflowed to 0 does not
+    hand its Inf value to the gradient of a zero-weight key"""
+    from oracle import bindings as ob, tolerance as T
+    b, loc, W, u2 = _zero_slope_scenario(oracle)
+    U = loc["U"]
+    stride = capi.row_stride(0)
+    rows = T.packed_rows(W, np.zeros(0, np.int32), 0, stride)
+    bt = capi.Batch(ctx, len(b["label"]), int(b["offset"][-1]))
+    bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+    bt.localize()
+    d_rows = capi.DeviceBuffer.from_numpy(ctx, rows)
+    d_grads = capi.DeviceBuffer(ctx, max(rows.nbytes, 16))
+    bt.forward(0, d_rows.ptr)
+    pg = bt.pred()
+    assert np.isfinite(pg[0]) and pg[0] > 500
+    go = oracle.fm_calcgrad(0, loc["offset"], loc["index"], b["value"], b["label"], W, pg)
+    bt.backward(0, d_rows.ptr, d_grads.ptr)
+    gg = d_grads.to_numpy(np.float32, rows.size).reshape(U, stride)
+    assert np.isfinite(gg[u2, 0])
+    _mask_check(gg[:, 0], go, "grad_w with a zero slope", rtol=1e-4)
+    # the fused step on the same model
+    kw = dict(l1=0.0, l2=0.0, lr=0.05, V_threshold=1000, seed=1)
+    so = oracle.store_create(init_mode=ob.INIT_HASH, V_dim=0, **kw)
+    tb = capi.Table(ctx, 1 << 10, V_dim=0, init_mode=capi.INIT_HASH, **kw)
+    scal = np.stack([np.ones(U), W, np.full(U, 0.5), np.zeros(U)], 1).astype(np.float32)
+    for i in range(U):
+        so.poke(int(loc["feaids"][i]), *scal[i], None)
+    tb.import_(loc["feaids"], scal, np.zeros(U, np.int32), None)
+    bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+    bt.localize()
+    bt.sgd_step(tb, is_train=True, push_cnt=False)
+    g2 = oracle.fm_calcgrad(0, loc["offset"], loc["index"], b["value"], b["label"], W, bt.pred())
+    so.push(loc["feaids"], ob.GRADIENT, g2)
+    vg, _ = tb.pull(loc["feaids"])
+    vo, _ = so.pull(loc["feaids"])
+    assert np.isfinite(vo[u2])
+    _mask_check(vg, vo, "model after the step with a zero slope", rtol=2e-4, atol=1e-6)
+    for o in (bt, d_rows, d_grads, tb):
+        o.close()
