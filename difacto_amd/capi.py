@@ -30,7 +30,7 @@ SYMBOLS = [
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
-    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck",
+    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity",
 ]
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
 K_COUNT = 8
@@ -102,6 +102,7 @@ def lib():
     L.dfh_table_destroy.argtypes = [vp]
     L.dfh_table_size.argtypes = [vp, PP(u64)]
     L.dfh_table_param.argtypes = [vp, PP(UpdaterParam)]
+    L.dfh_table_capacity.argtypes = [vp, PP(u64), PP(u64)]
     L.dfh_table_bytes.restype = u64
     L.dfh_table_bytes.argtypes = [vp]
     L.dfh_pull.argtypes = [vp, vp, sz, vp, PP(sz), vp, PP(sz)]
@@ -335,6 +336,12 @@ class Table:
         n = C.c_uint64(0)
         _ck(lib().dfh_table_size(self.h, C.byref(n)))
         return n.value
+
+    def capacity(self):
+        """(rows the arrays hold now, number of growths) — a table created with capacity 0 grows"""
+        c, g = C.c_uint64(0), C.c_uint64(0)
+        _ck(lib().dfh_table_capacity(self.h, C.byref(c), C.byref(g)))
+        return c.value, g.value
 
     def bytes(self):
         return int(lib().dfh_table_bytes(self.h))

@@ -27,6 +27,7 @@ struct dfh_ctx {
   // preparation streams (copies, Localizer, key lookup): with pipelining on, the batches being
   // prepared take them round-robin while an earlier batch trains on `stream`
   std::vector<hipStream_t> preps;
+  std::vector<hipStream_t> extra;  // other streams that carry work on this context's tables (a shard's collectives stream): drained by sync_all
   unsigned nprep = 0;       // streams in use (0: pipelining off, everything on `stream`)
   unsigned next_prep = 0;
   bool pipeline = false;
@@ -47,6 +48,7 @@ struct dfh_ctx {
   int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
   int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
   int auc_in_update = 1;       // a training step's AUC as the first blocks of k_update_fused (1) or a launch of its own (0)
+  int grow_initial_rows = 1 << 20;  // first allocation of a growing table (dfh_table_create with capacity_rows = 0)
   // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
   // consumer of these events is a stream of this device
   int event_flags = 1;
@@ -98,6 +100,12 @@ struct dfh_table {
   uint64_t hslots = 0;
   uint64_t bytes = 0;
   bool has_aux = true;  // SGDUpdater::has_aux_ (sgd_updater.h:80): false after loading a model saved without optimiser state
+  // capacity_rows = 0 at creation: the table GROWS like the reference's unordered_map (sgd_updater.h:78).  rows_bound is a
+  // host-side upper bound of the rows allocated so far (every launch that may insert adds the keys it carries); when it
+  // reaches the capacity the true count is read back and, if the headroom is short, the arrays are re-allocated.
+  bool auto_grow = false;
+  uint64_t rows_bound = 0;
+  uint64_t grows = 0;
   // REFRAND scratch (need/rank/urow per pushed key) for the literal + shard calls
   uint32_t* d_need = nullptr;
   uint32_t* d_rank = nullptr;
@@ -220,6 +228,7 @@ int main_end(dfh_batch* b) {
 }
 int sync_all(dfh_ctx* c) {
   for (hipStream_t p : c->preps) DFH_HIP(hipStreamSynchronize(p));
+  for (hipStream_t p : c->extra) DFH_HIP(hipStreamSynchronize(p));
   DFH_HIP(hipStreamSynchronize(c->stream));
   return DFH_OK;
 }
@@ -330,6 +339,105 @@ int require_aux(const dfh_table* t, const char* who) {
   set_error(std::string(who) + ": no aux data — the model was loaded without optimiser state (reference CHECK(has_aux_), "
                                "sgd_updater.cc:75)");
   return DFH_ERR_STATE;
+}
+
+// the largest pow2 index with load factor <= 0.5
+inline uint64_t hslots_for(uint64_t capacity_rows) {
+  uint64_t H = 1024;
+  while (H < 2 * capacity_rows) H <<= 1;
+  return H;
+}
+
+// re-allocate an auto-growing table at new_cap rows: row ids are stable (rows are handed out by a counter and never move
+// inside hdr / va), so the two row arrays are copied as they are and only the key index is rebuilt.  Every stream of the
+// context is drained first: no launch holds the old pointers.
+int table_grow(dfh_table* t, uint64_t new_cap) {
+  dfh_ctx* c = t->ctx;
+  TableView& v = t->v;
+  int rc = sync_all(c);
+  if (rc) return rc;
+  uint32_t nrows = 0;
+  DFH_HIP(hipMemcpy(&nrows, v.nrows, sizeof(nrows), hipMemcpyDeviceToHost));
+  nrows = std::min<uint32_t>(nrows, v.capacity);
+  const uint64_t H = hslots_for(new_cap);
+  const size_t ht_b = H * sizeof(HEntry), hdr_b = new_cap * sizeof(RowHdr);
+  const size_t row_b = (size_t)(2 * v.kp) * sizeof(float);
+  const size_t va_b = std::max<size_t>(new_cap * row_b, 256);
+  HEntry* ht2 = nullptr;
+  RowHdr* hdr2 = nullptr;
+  float* va2 = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&ht2, ht_b)) != hipSuccess || (e = hipMalloc(&hdr2, hdr_b)) != hipSuccess || (e = hipMalloc(&va2, va_b)) != hipSuccess) {
+    if (ht2) (void)hipFree(ht2);
+    if (hdr2) (void)hipFree(hdr2);
+    if (va2) (void)hipFree(va2);
+    (void)hipGetLastError();
+    set_error("model table: cannot grow to " + std::to_string(new_cap) + " rows (" + hipGetErrorString(e) +
+              "); set table capacity explicitly to what fits the HBM");
+    return DFH_ERR_CAPACITY;
+  }
+  hipStream_t s = c->stream;
+  DFH_HIP(hipMemsetAsync(ht2, 0xFF, ht_b, s));
+  DFH_HIP(hipMemcpyAsync(hdr2, v.hdr, (size_t)nrows * sizeof(RowHdr), hipMemcpyDeviceToDevice, s));
+  DFH_HIP(hipMemsetAsync(hdr2 + nrows, 0, hdr_b - (size_t)nrows * sizeof(RowHdr), s));
+  if (row_b) {
+    DFH_HIP(hipMemcpyAsync(va2, v.va, (size_t)nrows * row_b, hipMemcpyDeviceToDevice, s));
+    DFH_HIP(hipMemsetAsync(reinterpret_cast<char*>(va2) + (size_t)nrows * row_b, 0, va_b - (size_t)nrows * row_b, s));
+  } else {
+    DFH_HIP(hipMemsetAsync(va2, 0, va_b, s));
+  }
+  hipLaunchKernelGGL(k_rehash, dim3(grid_for_threads(t->hslots, c)), dim3(256), 0, s, v.ht, t->hslots, ht2, H - 1);
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipStreamSynchronize(s));
+  DFH_HIP(hipFree(v.ht));
+  DFH_HIP(hipFree(v.hdr));
+  DFH_HIP(hipFree(v.va));
+  v.ht = ht2;
+  v.hdr = hdr2;
+  v.va = va2;
+  v.hmask = H - 1;
+  v.capacity = (uint32_t)new_cap;
+  t->hslots = H;
+  t->bytes = ht_b + hdr_b + va_b;
+  ++t->grows;
+  return DFH_OK;
+}
+
+// before a launch that may insert up to n new keys into the index.  Tables of a fixed capacity: nothing (an overflow is
+// flagged by the device and reported as DFH_ERR_CAPACITY).  Growing tables: keep rows_bound + n inside the capacity.
+int table_reserve(dfh_table* t, uint64_t n) {
+  if (!t->auto_grow) return DFH_OK;
+  TableView& v = t->v;
+  if (t->rows_bound + n <= v.capacity) {
+    t->rows_bound += n;
+    return DFH_OK;
+  }
+  // the bound is spent: read the true row count (one drain of the context's streams; rare, see the headroom below)
+  int rc = sync_all(t->ctx);
+  if (rc) return rc;
+  uint32_t nrows = 0;
+  DFH_HIP(hipMemcpy(&nrows, v.nrows, sizeof(nrows), hipMemcpyDeviceToHost));
+  t->rows_bound = nrows;
+  // grow when fewer than 32 launches of this size fit (at most 2^24 rows of slack for a bulk load): the drain above then
+  // recurs every 32 launches at worst
+  const uint64_t want = t->rows_bound + n + std::min<uint64_t>(31 * n, 1ull << 24);
+  uint64_t cap = v.capacity;
+  while (cap < (uint64_t)kRowMask && want > cap) cap = std::min<uint64_t>(2 * cap, (uint64_t)kRowMask);
+  if (cap != v.capacity) {
+    rc = table_grow(t, cap);
+    if (rc == DFH_ERR_CAPACITY && t->rows_bound + n <= v.capacity) rc = DFH_OK;  // no room to grow yet, but this launch still fits
+    if (rc == DFH_ERR_CAPACITY) {  // try the smallest capacity that holds this launch
+      const uint64_t least = std::min<uint64_t>((uint64_t)kRowMask, t->rows_bound + 2 * n);
+      if (least > v.capacity && least >= t->rows_bound + n) rc = table_grow(t, least);
+    }
+    if (rc) return rc;
+  }
+  if (t->rows_bound + n > v.capacity) {
+    set_error("model table is full: " + std::to_string(t->rows_bound) + " rows + " + std::to_string(n) + " keys exceed 2^29 - 1 rows");
+    return DFH_ERR_CAPACITY;
+  }
+  t->rows_bound += n;
+  return DFH_OK;
 }
 
 RowSrc table_src(const dfh_table* t, const uint32_t* urow) {
@@ -748,6 +856,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
     DFH_ARG(value >= 1 && value <= 65536, "upd_*_blocks must be in [1, 65536]");
     (n == "upd_hot_blocks" ? c->upd_hot_blocks : n == "upd_mid_blocks" ? c->upd_mid_blocks : n == "upd_few_blocks" ? c->upd_few_blocks
                                                                                                         : c->upd_single_blocks) = value;
+  } else if (n == "grow_initial_rows") {
+    DFH_ARG(value >= 16 && value <= (1 << 28), "grow_initial_rows must be in [16, 2^28]");
+    c->grow_initial_rows = value;
   } else if (n == "auc_in_update") {
     DFH_ARG(value == 0 || value == 1, "auc_in_update must be 0 (k_auc_pairs as its own launch) or 1 (a role of k_update_fused)");
     c->auc_in_update = value;
@@ -843,20 +954,22 @@ int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_r
   DFH_ARG(c && p && out, "dfh_table_create: NULL argument");
   DFH_ARG(p->V_dim >= 0 && p->V_dim <= 10000, "V_dim out of range [0, 10000] (FMLossParam, fm_loss.h:25)");
   // the three top bits of a row word carry flags (kRemoteRow, kSingleRow, kCountLater); 2^29 rows of V_dim 64 would be 300 GB
-  DFH_ARG(capacity_rows >= 1 && capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^29)");
+  DFH_ARG(capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^29), or 0: a table that grows");
+  const bool auto_grow = capacity_rows == 0;
+  if (auto_grow) capacity_rows = (uint64_t)c->grow_initial_rows;  // the first allocation (2^20 rows: 0.6 GB at V_dim 64); doubled as the model grows
   DFH_ARG(p->lr > 0, "lr must be > 0");
   DFH_ARG(p->init_mode == DFH_INIT_HASH || p->init_mode == DFH_INIT_REFRAND, "bad init_mode");
   DFH_HIP(hipSetDevice(c->device));
   dfh_table* t = new (std::nothrow) dfh_table();
   DFH_ARG(t != nullptr, "out of host memory");
   t->ctx = c;
+  t->auto_grow = auto_grow;
   TableView& v = t->v;
   v.p = *p;
   v.k = p->V_dim;
   v.kp = (p->V_dim + 3) / 4 * 4;
   v.capacity = (uint32_t)capacity_rows;
-  uint64_t H = 1024;
-  while (H < 2 * capacity_rows) H <<= 1;
+  const uint64_t H = hslots_for(capacity_rows);
   t->hslots = H;
   v.hmask = H - 1;
   size_t ht_b = H * sizeof(HEntry);
@@ -924,6 +1037,13 @@ int dfh_table_param(dfh_table* t, dfh_updater_param* out) {
 }
 uint64_t dfh_table_bytes(dfh_table* t) { return t ? t->bytes : 0; }
 
+int dfh_table_capacity(dfh_table* t, uint64_t* capacity_rows, uint64_t* grows) {
+  DFH_ARG(t, "NULL table");
+  if (capacity_rows) *capacity_rows = t->v.capacity;
+  if (grows) *grows = t->grows;
+  return DFH_OK;
+}
+
 int dfh_table_set_has_aux(dfh_table* t, int has_aux) {
   DFH_ARG(t, "NULL table");
   t->has_aux = has_aux != 0;
@@ -934,6 +1054,7 @@ int dfh_table_has_aux(dfh_table* t) { return (t && t->has_aux) ? 1 : 0; }
 int dfh_table_warm_start(dfh_table* t, const uint64_t* d_keys, size_t n, float w0, float cnt0) {
   DFH_ARG(t && (n == 0 || d_keys), "dfh_table_warm_start: NULL argument");
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;
   hipLaunchKernelGGL(k_warm_start, dim3(grid_for_waves(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (uint64_t)n, w0, cnt0);
   DFH_HIP(hipGetLastError());
@@ -944,6 +1065,7 @@ int dfh_table_warm_start(dfh_table* t, const uint64_t* d_keys, size_t n, float w
 int dfh_shard_pull(dfh_table* t, const uint64_t* d_keys, size_t n, float* d_rows) {
   DFH_ARG(t && (n == 0 || (d_keys && d_rows)), "dfh_shard_pull: NULL argument");
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;  // Get inserts an entry for every id ever pulled (sgd_updater.cc:44)
   TimeScope ts(t->ctx, DFH_K_PULL);
   hipLaunchKernelGGL(k_pull_rows, dim3(grid_for_waves(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (uint32_t)n, d_rows, dfh_row_stride(t->v.k));
@@ -954,6 +1076,7 @@ int dfh_shard_pull(dfh_table* t, const uint64_t* d_keys, size_t n, float* d_rows
 int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const float* d_cnt) {
   DFH_ARG(t && (n == 0 || (d_keys && d_cnt)), "dfh_shard_push_count: NULL argument");
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;
   bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && t->v.k > 0;
   if (refrand) {
     int rc = ensure_table_aux(t, n);
@@ -971,6 +1094,7 @@ int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const fl
   DFH_ARG(t && (n == 0 || (d_keys && d_grads)), "dfh_shard_push_grad: NULL argument");
   if (int rca = require_aux(t, "dfh_shard_push_grad")) return rca;
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;
   bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && t->v.k > 0;
   if (refrand) {
     int rc = ensure_table_aux(t, n);
@@ -990,6 +1114,7 @@ int dfh_shard_push_grad(dfh_table* t, const uint64_t* d_keys, size_t n, const fl
 int dfh_shard_resolve(dfh_table* t, const uint64_t* d_keys, size_t n, uint32_t* d_rowid) {
   DFH_ARG(t && (n == 0 || (d_keys && d_rowid)), "dfh_shard_resolve: NULL argument");
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;
   TimeScope ts(t->ctx, DFH_K_LOOKUP);
   hipLaunchKernelGGL(k_resolve, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys, (uint32_t)n,
                      d_rowid);
@@ -1074,6 +1199,7 @@ int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* 
   const size_t n = g.off[nsrc];
   DFH_ARG(n == 0 || (d_keys && d_rowid), "dfh_shard_resolve_multi: NULL argument");
   if (n == 0) return DFH_OK;
+  if (int rcr = table_reserve(t, n)) return rcr;
   TimeScope ts(t->ctx, DFH_K_LOOKUP);
   hipLaunchKernelGGL(k_resolve_multi, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys, g, d_rowid);
   DFH_HIP(hipGetLastError());
@@ -1306,6 +1432,7 @@ int dfh_table_import(dfh_table* t, uint64_t n, const uint64_t* keys, const float
   DFH_HIP(hipSetDevice(c->device));
   const int k = t->v.k;
   DFH_ARG(k == 0 || V, "V is NULL");
+  if (int rcr = table_reserve(t, n)) return rcr;
   size_t vfl = (size_t)n * 2 * (size_t)std::max(k, 1);
   int rc = ensure_scratch(c, padded<uint64_t>(n) + padded<float>(n * 4) + padded<int>(n) + padded<float>(vfl));
   if (rc) return rc;
@@ -1860,9 +1987,13 @@ struct dfh_rowbuf {
   float* d_val = nullptr;      // [max_nnz]
   bool has_value = false;
   hipStream_t up = nullptr;    // uploads: the feed thread's own stream
-  hipEvent_t ev_loaded = nullptr, ev_used = nullptr;
-  std::mutex mu;               // used_pending is set by the thread that gathers, read by the thread that uploads
-  bool used_pending = false;
+  hipEvent_t ev_loaded = nullptr;
+  // one "gathered" event per stream that has gathered out of this buffer (the two batch objects of a worker loop gather on
+  // different preparation streams: one shared event would only remember the LAST gather); `pending` marks the ones
+  // recorded since the last upload.  Set by the thread that gathers, read by the thread that uploads.
+  struct Used { hipStream_t stream; hipEvent_t ev; bool pending; };
+  std::mutex mu;
+  std::vector<Used> used;
   std::vector<uint32_t> off32;
 };
 
@@ -1902,8 +2033,7 @@ int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** 
       (e = hipMalloc(reinterpret_cast<void**>(&rb->d_idx), max_nnz * sizeof(uint64_t))) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&rb->d_val), max_nnz * sizeof(float))) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&rb->up, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&rb->ev_loaded, hipEventDisableTiming)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&rb->ev_used, hipEventDisableTiming)) != hipSuccess) {
+      (e = hipEventCreateWithFlags(&rb->ev_loaded, hipEventDisableTiming)) != hipSuccess) {
     set_error(std::string("dfh_rowbuf_create: ") + hipGetErrorString(e));
     dfh_rowbuf_destroy(rb);
     return DFH_ERR_HIP;
@@ -1915,13 +2045,17 @@ int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** 
 int dfh_rowbuf_destroy(dfh_rowbuf* rb) {
   if (!rb) return DFH_OK;
   hipSetDevice(rb->ctx->device);
-  sync_all(rb->ctx);
+  // the gathers out of this buffer, wherever they were queued (NOT sync_all: this may run beside the thread that drives
+  // the context, and only this buffer's own consumers matter)
+  for (auto& u : rb->used) {
+    if (u.pending) hipEventSynchronize(u.ev);
+    hipEventDestroy(u.ev);
+  }
   if (rb->up) {
     hipStreamSynchronize(rb->up);
     hipStreamDestroy(rb->up);
   }
   if (rb->ev_loaded) hipEventDestroy(rb->ev_loaded);
-  if (rb->ev_used) hipEventDestroy(rb->ev_used);
   for (void* p : {(void*)rb->d_off, (void*)rb->d_idx, (void*)rb->d_val})
     if (p) hipFree(p);
   delete rb;
@@ -1934,13 +2068,15 @@ int dfh_rowbuf_load_host(dfh_rowbuf* rb, size_t nrows, const size_t* offset, con
   DFH_ARG(nnz <= rb->max_nnz, "dfh_rowbuf_load_host: more nonzeros than the buffer holds");
   DFH_ARG(nnz == 0 || index, "dfh_rowbuf_load_host: index is NULL");
   DFH_HIP(hipSetDevice(rb->ctx->device));
-  bool wait_used;
   {
+    // every gather out of the previous contents, on whichever stream it was queued, precedes the copies below
     std::lock_guard<std::mutex> lk(rb->mu);
-    wait_used = rb->used_pending;
-    rb->used_pending = false;
+    for (auto& u : rb->used) {
+      if (!u.pending) continue;
+      DFH_HIP(hipStreamWaitEvent(rb->up, u.ev, 0));
+      u.pending = false;
+    }
   }
-  if (wait_used) DFH_HIP(hipEventSynchronize(rb->ev_used));  // the gathers out of the previous contents have run
   rb->off32.resize(nrows + 1);
   for (size_t i = 0; i <= nrows; ++i) {
     DFH_ARG(offset[i] >= base && (i == 0 || offset[i] >= offset[i - 1]), "dfh_rowbuf_load_host: offsets must not decrease");
@@ -2016,10 +2152,19 @@ int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, cons
     const unsigned blocks = (unsigned)std::min<size_t>((seg_rows[g] + 3) / 4, 4096);
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, s, rb->d_off, rb->d_idx, rb->has_value ? rb->d_val : (const float*)nullptr,
                        d_rows + at, (uint32_t)seg_rows[g], b->d_offset + at, b->d_raw, any_value ? b->d_value : (float*)nullptr);
-    DFH_HIP(hipEventRecord(rb->ev_used, s));
     {
       std::lock_guard<std::mutex> lk(rb->mu);
-      rb->used_pending = true;
+      dfh_rowbuf::Used* u = nullptr;
+      for (auto& x : rb->used)
+        if (x.stream == s) u = &x;
+      if (!u) {
+        hipEvent_t ev = nullptr;
+        DFH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        rb->used.push_back({s, ev, false});
+        u = &rb->used.back();
+      }
+      DFH_HIP(hipEventRecord(u->ev, s));
+      u->pending = true;
     }
     at += seg_rows[g];
   }
@@ -2040,6 +2185,9 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   dfh_ctx* c = b->ctx;
   DFH_HIP(hipSetDevice(c->device));
   const uint32_t N = (uint32_t)b->nnz;
+  if (probe && N) {
+    if (int rcr = table_reserve(probe, N)) return rcr;  // before anything of this phase is queued: growth drains the streams
+  }
   {
     int rc = prep_begin(b);
     if (rc) return rc;
@@ -2203,7 +2351,9 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   dfh_ctx* c = b->ctx;
   if (b->nnz == 0) return DFH_OK;
   DFH_HIP(hipSetDevice(c->device));
-  int rc = prep_begin(b);
+  int rc = table_reserve(t, b->nnz);  // U <= nnz keys may be new
+  if (rc) return rc;
+  rc = prep_begin(b);
   if (rc) return rc;
   {
     hipStream_t ps = prep_of(b);
@@ -2402,6 +2552,10 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   }
   const bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && k > 0;
   const uint32_t Nb = (uint32_t)b->nnz;  // upper bound of U for grids
+  if (b->looked_up != t) {  // the step's own lookup probes the index: up to U <= nnz new keys
+    rc = table_reserve(t, Nb);
+    if (rc) return rc;
+  }
   rc = main_begin(b);
   if (rc) return rc;
   // Pull: key -> row (+ epoch-0 Push(kFeaCount), sgd_learner.cc:214-217).  When dfh_batch_lookup

@@ -126,6 +126,25 @@ __device__ __forceinline__ uint32_t find_or_insert(const TableView& t, uint64_t 
   }
 }
 
+// growth of a table (dfh_api.hip table_grow): every {key, row} of the old index into the new, larger one.  Runs alone on
+// the table (every stream drained); distinct keys only race for slots.
+__global__ void k_rehash(const HEntry* __restrict__ old_ht, uint64_t old_slots, HEntry* __restrict__ ht, uint64_t hmask) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < old_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = old_ht[i].key;
+    if (key == kEmptyKey) continue;
+    uint64_t h = splitmix64(key) & hmask;
+    for (;;) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&ht[h].key), (unsigned long long)kEmptyKey,
+                                               (unsigned long long)key);
+      if (old == kEmptyKey) {
+        ht[h].row = old_ht[i].row;
+        break;
+      }
+      h = (h + 1) & hmask;
+    }
+  }
+}
+
 // read-only probe (export / tests)
 __device__ __forceinline__ uint32_t find_only(const TableView& t, uint64_t key) {
   uint64_t h = splitmix64(key) & t.hmask;
@@ -1802,7 +1821,7 @@ __global__ void __launch_bounds__(1024) k_auc_area(const uint32_t* __restrict__ 
 // *out_slot and zeroes acc for the next call.
 constexpr int AUC_TILE = 1024;
 constexpr uint32_t AUC_PAIRS_MAX_N = 32768;   // beyond: the radix-sort path (n^2 would pass the cost of sorting)
-constexpr uint32_t AUC_COL_SPLIT = 4;         // column tiles are dealt to this many units per row tile
+constexpr uint32_t AUC_COL_SPLIT = 16;        // column tiles are dealt to this many units per row tile (10 000 rows: one tile per unit)
 
 __device__ __forceinline__ uint32_t auc_key(float pred) {
   const uint32_t bits = __float_as_uint(pred + 0.0f);  // -0 and +0 compare equal in the reference: one image
@@ -1832,15 +1851,30 @@ __device__ __forceinline__ void auc_pairs_block(const float* __restrict__ pred, 
     neg = !pos;
   }
   uint32_t cnt = 0;
+  const int lane = threadIdx.x & 63;
   for (uint32_t tile = ct; tile < ntile; tile += nct) {
     __syncthreads();  // the previous tile has been consumed
     if (threadIdx.x == 0) npos_tile = 0;
-    __syncthreads();
     const uint32_t j0 = tile * AUC_TILE;
-    const uint32_t lim = min((uint32_t)AUC_TILE, n - j0);
-    for (uint32_t t = threadIdx.x; t < lim; t += 256u) {
-      const uint32_t j = j0 + t;
-      if (label[j] > 0) colp[atomicAdd(&npos_tile, 1u)] = ((unsigned long long)auc_key(pred[j]) << 32) | j;
+    // all of the tile's loads first (one round trip), then the compaction: a ballot per wave and ONE LDS atomic per wave
+    // and quarter (same-address atomics serialise: one per positive cost 5-10 us per tile)
+    float pj[AUC_TILE / 256], lj[AUC_TILE / 256];
+#pragma unroll
+    for (int r = 0; r < AUC_TILE / 256; ++r) {
+      const uint32_t j = min(j0 + r * 256u + threadIdx.x, n - 1);
+      pj[r] = pred[j];
+      lj[r] = label[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < AUC_TILE / 256; ++r) {
+      const uint32_t j = j0 + r * 256u + threadIdx.x;
+      const bool pj_pos = j < n && lj[r] > 0;
+      const unsigned long long m = __ballot(pj_pos);
+      uint32_t base = 0;
+      if (lane == 0 && m) base = atomicAdd(&npos_tile, (uint32_t)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (pj_pos) colp[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)auc_key(pj[r]) << 32) | j;
     }
     __syncthreads();
     const uint32_t np = npos_tile;

@@ -177,6 +177,10 @@ struct dfh_shard {
   hipStream_t cs = nullptr;           // the collectives' own stream (the sync step exchanges on the context's stream)
   hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr}, ev_rw[2] = {nullptr, nullptr};
   hipEvent_t ev_f = nullptr, ev_g = nullptr;
+  // P (or the release) of the minibatch that last used exchange slot q has been queued and recorded: the next K into
+  // r_keys[q] / r_cnt[q] waits for it (P reads r_keys / r_rowid / r_rows on the main stream; K writes on the collectives')
+  hipEvent_t ev_p[2] = {nullptr, nullptr};
+  bool p_pending[2] = {false, false};
   struct Flight {                     // one minibatch on its way through the stages
     dfh_batch* b = nullptr;           // NULL: this rank has no minibatch in that step (it still serves its shard)
     bool described = false;           // the counts exchange is through: the sizes below are valid
@@ -564,14 +568,18 @@ int dfh_shard_destroy(dfh_shard* s) {
     if (p) hipFree(p);
   if (s->h_cnt) hipHostFree(s->h_cnt);
   if (s->cnt_ev) hipEventDestroy(s->cnt_ev);
-  for (hipEvent_t e : {s->ev_k[0], s->ev_k[1], s->ev_r[0], s->ev_r[1], s->ev_rw[0], s->ev_rw[1], s->ev_f, s->ev_g})
+  for (hipEvent_t e : {s->ev_k[0], s->ev_k[1], s->ev_r[0], s->ev_r[1], s->ev_rw[0], s->ev_rw[1], s->ev_f, s->ev_g, s->ev_p[0], s->ev_p[1]})
     if (e) hipEventDestroy(e);
   for (auto& sp : s->spans) {
     hipEventDestroy(sp.a);
     hipEventDestroy(sp.b);
   }
   for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
-  if (s->cs) hipStreamDestroy(s->cs);
+  if (s->cs) {
+    auto& ex = s->c->ctx->extra;
+    ex.erase(std::remove(ex.begin(), ex.end(), s->cs), ex.end());
+    hipStreamDestroy(s->cs);
+  }
   delete s;
   return DFH_OK;
 }
@@ -718,6 +726,10 @@ int flight_K(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
   dfh_batch* b = f.b;
   StageScope ts(s, DFH_SHARD_STAGE_K, s->cs);
   if (b && b->ready_pending) DFH_HIP(hipStreamWaitEvent(s->cs, b->ev_ready, 0));  // its Localizer (preparation stream)
+  if (s->p_pending[f.slot]) {  // the previous user of this slot's receive buffers has applied (or released) what it received
+    DFH_HIP(hipStreamWaitEvent(s->cs, s->ev_p[f.slot], 0));
+    s->p_pending[f.slot] = false;
+  }
   std::vector<size_t> sb, rb, so;
   flight_bytes(f, W, sizeof(uint64_t), sb, rb, so);
   XPart xk{f.have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys[f.slot], rb.data(), nullptr};
@@ -804,13 +816,16 @@ int dfh_shard_set_exchange(dfh_shard* s, int mode) {
   if (rc) return rc;
   if (mode == 1 && !s->cs) {
     DFH_HIP(hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking));
+    s->c->ctx->extra.push_back(s->cs);  // a growing table drains it before it re-allocates (table_grow)
     // these events order two streams of ONE device: no system-scope fence at the record
     const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
-    for (hipEvent_t* e : {&s->ev_k[0], &s->ev_k[1], &s->ev_r[0], &s->ev_r[1], &s->ev_rw[0], &s->ev_rw[1], &s->ev_f, &s->ev_g})
+    for (hipEvent_t* e : {&s->ev_k[0], &s->ev_k[1], &s->ev_r[0], &s->ev_r[1], &s->ev_rw[0], &s->ev_rw[1], &s->ev_f, &s->ev_g,
+                          &s->ev_p[0], &s->ev_p[1]})
       DFH_HIP(hipEventCreateWithFlags(e, evf));
   }
   if (s->cs) DFH_HIP(hipStreamSynchronize(s->cs));
   s->exchange = mode;
+  s->p_pending[0] = s->p_pending[1] = false;  // everything was drained above
   s->fl[0] = dfh_shard::Flight();
   s->fl[1] = dfh_shard::Flight();
   s->cur = 0;
@@ -945,6 +960,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   const uint32_t n_own = own_hi - own_lo;  // meaningless for W == 1 (the kernels clamp to *d_U)
   // ---- L: this rank's own keys: rows + Push(kFeaCount) on its own table, {row, w} per key for the forward
   if (any_own) {
+    if (int rcr = table_reserve(t, W == 1 ? b->nnz : n_own)) return rcr;
     StageScope ts(s, DFH_SHARD_STAGE_L, st);
     const bool counts = push_cnt != 0;
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
@@ -1126,6 +1142,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
   // after everything the previous step applied: own keys are read with zero staleness.
   const uint32_t n_own = cur.own_hi - cur.own_lo;
   if (cur.any_own) {
+    if (int rcr = table_reserve(t, n_own)) return rcr;
     StageScope ts(s, DFH_SHARD_STAGE_L, st);
     const bool counts = push_cnt != 0;
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
@@ -1239,6 +1256,10 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
   } else if (cur.nrecv) {
     rc = dfh_shard_release(t, s->r_rowid[q], cur.nrecv, q);
     if (rc) return rc;
+  }
+  if (cur.nrecv) {  // r_keys[q] / r_rowid[q] / r_rows[q] are free again once this point of the main stream is reached
+    DFH_HIP(hipEventRecord(s->ev_p[q], st));
+    s->p_pending[q] = true;
   }
   cur = dfh_shard::Flight();
   if (look) s->cur ^= 1;  // the announced minibatch (described, maybe pulled) is the next call's

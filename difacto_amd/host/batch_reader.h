@@ -870,7 +870,6 @@ class BatchReader : public BatchSource {
     // on the 256-thread host of the GPU box, 640 minibatches of 10 000 rows: 0.25-0.31 s with 1 thread, 0.24-0.29 s with
     // 4, 0.17-0.24 s with 8 — the rows come out of a buffer another thread assembled (another CCD's cache), not out of
     // this core's, and more cores do not change where the lines are.
-    feaid_t mx = batch_.max_index;
     constexpr size_t kAhead = 32;  // tools/gather_host_bench.cc on the GPU box's CPU: 12 rows ahead 0.300 ms, 32 rows 0.274 ms per minibatch
     const int nth = nsel >= 2048 ? GatherThreads() : 1;
 #pragma omp parallel for num_threads(nth) schedule(static) if (nth > 1)
@@ -887,10 +886,9 @@ class BatchReader : public BatchSource {
       memcpy(&batch_.index[dst], in_blk_.index + b, n * sizeof(feaid_t));
       if (in_blk_.value) memcpy(&batch_.value[dst], in_blk_.value + b, n * sizeof(real_t));
     }
-    // RowBlockContainer keeps the largest index it holds: one pass over what was appended (a max inside the copy loop kept
-    // the copy from being a memcpy: tools/gather_host_bench.cc)
-    for (size_t x = nnz_before; x < nnz_before + add; ++x) mx = std::max(mx, batch_.index[x]);
-    batch_.max_index = mx;
+    // RowBlockContainer::max_index goes stale (GetMaxIndex() rescans on demand): nothing on this path reads it, and both a
+    // max inside the copy loop and a pass of its own cost the gather measurably (tools/gather_host_bench.cc)
+    batch_.max_index_stale = batch_.max_index_stale || add > 0;
   }
   static int GatherThreads() {
     static const int n = [] {

@@ -46,8 +46,7 @@ long ingest_read(const char* uri, const char* format, unsigned part, unsigned np
       dmlc::RowBlock<feaid_t> slice = blk;
       slice.index = blk.index + blk.offset[0];
       slice.value = blk.value ? blk.value + blk.offset[0] : nullptr;
-      c.Push(slice);
-      if (serial > 4) buffers.erase(serial - 4);   // a minibatch spans at most two buffers; the reader runs a few ahead
+      c.Push(slice);   // kept until the consumer has gathered the last minibatch that names it (released below)
     });
   std::unique_ptr<BatchSource> src(br.release());
   if (pf && atoi(pf) > 0) src.reset(new PrefetchSource(src.release(), atoi(pf)));
@@ -80,6 +79,11 @@ long ingest_read(const char* uri, const char* format, unsigned part, unsigned np
         }
       }
       if (q != d.size) return -4;
+      // minibatches take their rows from the buffers in order (with down-sampling one minibatch may span many of them):
+      // everything before the last buffer this one names is exhausted
+      uint64_t last = 0;
+      for (const RowSeg& seg : reader.Aux()) last = std::max<uint64_t>(last, seg.buf);
+      while (!buffers.empty() && buffers.begin()->first < last) buffers.erase(buffers.begin());
       bool binary = true;   // the copying reader drops an all-ones value array per minibatch (batch_reader.cc:71-73)
       for (auto f : rebuilt.value)
         if (f != 1) { binary = false; break; }

@@ -2,6 +2,7 @@
  * sgd_learner.cc — see sgd_learner.h.  Reference: src/sgd/sgd_learner.cc.
  */
 #include "./sgd_learner.h"
+#include <map>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -204,30 +205,59 @@ void SGDLearner::IterateData(const sgd::Job& job, sgd::Progress* prog) {
 
 namespace {
 // Device feed: the reader's shuffle buffers in HBM.  The reader thread uploads every buffer once, when it becomes current
-// (BatchReader::Describe), into a ring of device row buffers; the worker loop then sends 4 B per row of a minibatch and the
-// rows are gathered on the device (dfh_batch_gather_rows) instead of being copied twice on the host (into the minibatch,
-// into the pinned staging area).  A slot is reused kRing buffers later: every minibatch that names it has been gathered by
-// then (the reader runs at most three minibatches ahead of the loop), and the upload waits for those gathers on the device.
+// (BatchReader::Describe), into a device row buffer; the worker loop then sends 4 B per row of a minibatch and the rows are
+// gathered on the device (dfh_batch_gather_rows) instead of being copied twice on the host (into the minibatch, into the
+// pinned staging area).  Buffers are named by their serial: `live` holds every uploaded buffer that a minibatch may still
+// name; the worker loop hands a buffer back (Release) once the gather of the last minibatch that names it has been queued —
+// with down-sampling (neg_sampling < 1) one minibatch may span any number of buffers, so there is no fixed ring.  A buffer
+// that is handed back is reused by a later upload, which waits ON THE DEVICE for the gathers queued on it
+// (dfh_rowbuf_load_host); buffers are freed on the loop's thread, at the end of the job.
 struct DeviceFeed {
-  static constexpr int kRing = 6;
   dfh_ctx* ctx = nullptr;
-  dfh_rowbuf* ring[kRing] = {};
-  size_t cap_rows[kRing] = {}, cap_nnz[kRing] = {};
+  std::mutex mu;
+  std::map<uint64_t, dfh_rowbuf*> live;        // serial -> uploaded buffer
+  std::vector<dfh_rowbuf*> spare, all;         // handed back / every buffer ever created
+  std::map<dfh_rowbuf*, std::pair<size_t, size_t>> cap;
   void Upload(const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) {   // on the reader's thread
-    const int s = static_cast<int>(serial % kRing);
     const size_t nnz = blk.offset[blk.size] - blk.offset[0];
-    if (!ring[s] || blk.size > cap_rows[s] || nnz > cap_nnz[s]) {
-      if (ring[s]) DFH_CALL(dfh_rowbuf_destroy(ring[s]));
-      cap_rows[s] = std::max(cap_rows[s], blk.size);
-      cap_nnz[s] = std::max<size_t>(std::max(cap_nnz[s], nnz + nnz / 4), 1);
-      DFH_CALL(dfh_rowbuf_create(ctx, cap_rows[s], cap_nnz[s], &ring[s]));
+    dfh_rowbuf* rb = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < spare.size() && !rb; ++i) {
+        const auto& c = cap[spare[i]];
+        if (c.first >= blk.size && c.second >= nnz) {
+          rb = spare[i];
+          spare.erase(spare.begin() + i);
+        }
+      }
     }
-    DFH_CALL(dfh_rowbuf_load_host(ring[s], blk.size, blk.offset, blk.index, blk.value));
+    if (!rb) {   // none fits: a new one (too small ones stay spare and are freed with the feed)
+      const size_t rows = std::max<size_t>(blk.size, 1), nz = std::max<size_t>(nnz + nnz / 4, 1);
+      DFH_CALL(dfh_rowbuf_create(ctx, rows, nz, &rb));
+      std::lock_guard<std::mutex> lk(mu);
+      all.push_back(rb);
+      cap[rb] = {rows, nz};
+    }
+    DFH_CALL(dfh_rowbuf_load_host(rb, blk.size, blk.offset, blk.index, blk.value));
+    std::lock_guard<std::mutex> lk(mu);
+    CHECK(live.emplace(serial, rb).second) << "shuffle buffer " << serial << " uploaded twice";
   }
-  dfh_rowbuf* Of(uint64_t serial) const { return ring[serial % kRing]; }
+  dfh_rowbuf* Of(uint64_t serial) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(serial);
+    CHECK(it != live.end()) << "minibatch names shuffle buffer " << serial << ", which is not (or no longer) on the device";
+    return it->second;
+  }
+  // the gathers of every minibatch that names a buffer below `serial` have been queued
+  void Release(uint64_t serial) {
+    std::lock_guard<std::mutex> lk(mu);
+    while (!live.empty() && live.begin()->first < serial) {
+      spare.push_back(live.begin()->second);
+      live.erase(live.begin());
+    }
+  }
   ~DeviceFeed() {
-    for (auto* rb : ring)
-      if (rb) dfh_rowbuf_destroy(rb);
+    for (auto* rb : all) dfh_rowbuf_destroy(rb);
   }
 };
 }  // namespace
@@ -306,6 +336,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       }
       DFH_CALL(dfh_batch_gather_rows(b, blk.size, blk.offset, blk.label, static_cast<int>(segs.size()), bufs.data(), rows.data(),
                                      cnts.data()));
+      // minibatches take their rows from the buffers in order: the buffers before this one's last are exhausted
+      uint64_t last = 0;
+      for (const auto& g : segs) last = std::max<uint64_t>(last, g.buf);
+      feed.Release(last);
     } else {
       DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
     }
@@ -546,11 +580,27 @@ void SGDLearner::IterateDataLiteral(const sgd::Job& job, sgd::Progress* progress
 void SGDLearner::SaveModel() {
   auto* ss = dynamic_cast<ShardedDeviceStore*>(store_);
   const std::string path = ss ? param_.model_out + ".part-" + std::to_string(store_->Rank()) : param_.model_out;
+  // written under a temporary name and renamed when complete: a reader never sees half a file, and a rank that dies
+  // mid-save leaves the previous part in place
+  const std::string tmp = path + ".tmp";
   {
-    std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(path.c_str(), "w"));
+    std::unique_ptr<dmlc::Stream> fo(dmlc::Stream::Create(tmp.c_str(), "w"));
     GetUpdater()->Save(true, fo.get());
   }
+  if (ss) {
+    // the manifest is the commit point of a sharded save: it may only name parts that are complete.  Every rank has closed
+    // its part when this all-reduce returns (a rank that failed never arrives: no new manifest); the parts are then
+    // renamed into place and rank 0 writes the manifest after a second round.
+    double ok[1] = {1.0};
+    DFH_CALL(dfh_comm_allreduce_sum(ss->comm(), ok, 1));
+    CHECK_EQ(static_cast<int>(ok[0]), store_->NumWorkers()) << "a rank did not finish its model part";
+  }
+  CHECK_EQ(rename(tmp.c_str(), path.c_str()), 0) << "cannot move " << tmp << " to " << path;
   LOG(INFO) << "model saved to " << path;
+  if (ss) {
+    double done[1] = {1.0};
+    DFH_CALL(dfh_comm_allreduce_sum(ss->comm(), done, 1));   // every part is in place
+  }
   if (ss && store_->Rank() == 0) {
     const int world = store_->NumWorkers();
     for (int n = world;; ++n) {  // parts of an earlier save with more ranks

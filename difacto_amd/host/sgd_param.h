@@ -76,7 +76,8 @@ struct SGDUpdaterParam : public dmlc::Parameter<SGDUpdaterParam> {
 
 /*! \brief keys that exist only in the device build (all optional) */
 struct DeviceParam : public dmlc::Parameter<DeviceParam> {
-  /*! \brief rows of the model table in HBM (the reference's hash map grows without bound) */
+  /*! \brief rows of the model table in HBM; 0 (default): the table grows as the reference's hash map does
+   *  (sgd_updater.h:78), > 0: a fixed capacity, overflow is an error */
   unsigned long long table_capacity;
   /*! \brief "hash": order-independent V init; "refrand": the reference's rand_r chain, bit for bit */
   std::string V_init;
@@ -91,7 +92,7 @@ struct DeviceParam : public dmlc::Parameter<DeviceParam> {
   DMLC_DECLARE_PARAMETER(DeviceParam) {
     DMLC_DECLARE_FIELD(shard_ranges).set_default("balanced");
     DMLC_DECLARE_FIELD(shard_exchange).set_default("overlap");
-    DMLC_DECLARE_FIELD(table_capacity).set_default(1ULL << 22);
+    DMLC_DECLARE_FIELD(table_capacity).set_default(0);
     DMLC_DECLARE_FIELD(V_init).set_default("refrand");
     DMLC_DECLARE_FIELD(device_path).set_default("fused");
   }

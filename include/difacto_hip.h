@@ -89,6 +89,7 @@ int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
  *   "prep_priority"     -1 | 0 | 1      stream priority of the preparation streams: lowest (default),
  *                                       normal, highest; before dfh_ctx_set_pipeline creates them
  *   "upd_kernel", "upd_*_blocks", "upd_interleave", "event_flags": see csrc/dfh_api.hip (measurement switches)
+ *   "grow_initial_rows" 16 .. 2^28      first allocation of a growing table (dfh_table_create, capacity_rows = 0; default 2^20)
  *   "auc_in_update"     0 | 1           BinClassMetric::AUC of a training step (batch option "compute_auc") as the first
  *                                       blocks of the update launch (default 1) or as a launch of its own */
 int dfh_ctx_set_option(dfh_ctx* ctx, const char* name, int value);
@@ -117,8 +118,14 @@ uint64_t dfh_encode_fea_grp_id(uint64_t x, int gid, int nbits);
 /* Replaces SGDUpdater's unordered_map<feaid_t,SGDEntry> (src/sgd/sgd_updater.h:78)
  * with a row store in HBM: capacity_rows fixed-stride rows + an open-addressing
  * key index.  Unseen keys are inserted as zero rows on first touch, exactly as
- * SGDUpdater::Get/Update do through model_[id] (sgd_updater.cc:44,66,87). */
+ * SGDUpdater::Get/Update do through model_[id] (sgd_updater.cc:44,66,87).
+ * capacity_rows = 0: the table GROWS like the reference's map (it starts at 2^20 rows and is re-allocated at twice
+ * the size whenever fewer than 32 launches' worth of new keys would still fit; row ids are stable, only the key index
+ * is rebuilt; needs old + new arrays side by side, so a model beyond a third of the HBM wants an explicit capacity).
+ * capacity_rows > 0: fixed; inserting beyond it is reported as DFH_ERR_CAPACITY, never silent.  At most 2^29 - 1 rows. */
 int dfh_table_create(dfh_ctx* ctx, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out);
+/* rows the arrays hold now, and how often the table has grown (0 for a fixed capacity) */
+int dfh_table_capacity(dfh_table* t, uint64_t* capacity_rows, uint64_t* grows);
 int dfh_table_destroy(dfh_table* t);
 int dfh_table_size(dfh_table* t, uint64_t* nkeys); /* synchronises */
 int dfh_table_param(dfh_table* t, dfh_updater_param* out);

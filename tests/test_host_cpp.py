@@ -177,6 +177,57 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_reference_criteo_conf_unchanged_on_a_model_that_outgrows_the_first_allocation(built, tmp_path):
+    """the reference's own example/criteo_sgd.conf, key for key (only the two file names differ): no table_capacity,
+    no device-only key.  The data brings ~3 M distinct ids (every categorical token random): the model table starts at
+    2^20 rows and must grow — the reference's unordered_map is unbounded (sgd_updater.h:78) — where round 3's fixed
+    default of 2^22 rows... and any fixed default... would end a bigger file in DFH_ERR_CAPACITY."""
+    import numpy as np
+    from oracle import ingest as oi
+    rng = np.random.default_rng(5)
+    nrows, blk = 110000, 10000
+    lab = (rng.random(nrows) < 0.25).astype(np.float32)
+    # 13 small-vocabulary slots + 26 slots of random 52-bit tokens, slot id in the low 12 bits (EncodeFeaGrpID, base.h:60-63)
+    tok = rng.integers(0, 1 << 52, size=(nrows, 39), dtype=np.uint64)
+    tok[:, :13] = rng.integers(0, 5000, size=(nrows, 13), dtype=np.uint64)
+    idx = ((tok << np.uint64(12)) | np.arange(39, dtype=np.uint64)[None, :]).reshape(-1)
+    recs = []
+    for a in range(0, nrows, blk):
+        n = min(blk, nrows - a)
+        o = (np.arange(n + 1) * 39).astype(np.uint64)
+        recs.append(oi.write_crb_record(o, lab[a:a + n], idx[a * 39:(a + n) * 39]))
+    rec = os.path.join(tmp_path, "criteo_train.rec")
+    open(rec, "wb").write(oi.write_recordio(recs))
+    ref_conf = """# data
+data_in = %s
+data_val = %s
+data_format = rec
+
+# learner
+task = train
+learner = sgd
+max_num_epochs = 10
+batch_size = 10000
+
+# linear term
+l1 = 10
+l2 = 10
+
+# embedding term
+V_dim = 10
+V_threshold = 10
+V_l2 = 10
+""" % (rec, rec)
+    conf = os.path.join(tmp_path, "criteo_sgd.conf")
+    open(conf, "w").write(ref_conf)
+    r = subprocess.run([os.path.join(built, "difacto"), "argfile=" + conf], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stderr[-2500:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Start epoch 0" in r.stderr and "Validation: loss = " in r.stderr
+    assert "model table is full" not in r.stderr and "Unrecognized keyword" not in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_runs_are_reproducible(built, tmp_path):
     """two runs of one command give the same trajectory, shuffle buffer included: the permutation comes from the reader's
     own restatement of the reference's rand() stream (RefRand, batch_reader.h), not from the process-wide rand(), which
@@ -205,11 +256,22 @@ def test_cli_device_feed_matches_host_feed(built, tmp_path):
     rng = np.random.default_rng(33)
     txt = os.path.join(tmp_path, "train.criteo")
     open(txt, "wb").write(_criteo_text(rng, 4000))
+    sparse = os.path.join(tmp_path, "sparse.criteo")
+    lines = []
+    for _ in range(12000):
+        f = [str(int(rng.random() < 0.03))] + [str(int(rng.integers(0, 50))) for _ in range(13)] + ["%08x" % int(rng.integers(0, 1 << 20)) for _ in range(26)]
+        lines.append("\t".join(f))
+    open(sparse, "w").write("\n".join(lines) + "\n")
     runs = {}
     cases = [("criteo", ["data_in=" + txt, "data_format=criteo", "batch_size=300", "shuffle=2", "neg_sampling=0.7", "V_dim=4", "V_threshold=0",
                          "l1=.01", "lr=.1", "V_lr=.05", "V_init=hash", "table_capacity=262144", "max_num_epochs=3", "stop_rel_objv=0",
                          "num_jobs_per_epoch=2"]),
-             ("rcv1", ["argfile=" + _hash_conf(tmp_path, 3, 25), "shuffle=2"])]
+             ("rcv1", ["argfile=" + _hash_conf(tmp_path, 3, 25), "shuffle=2"]),
+             # one shuffle buffer per minibatch and 97 % of the negatives dropped on data with 3 % positives: a
+             # minibatch draws its rows from ~17 buffers, far more than the six-slot ring of round 3 held
+             ("sparse", ["data_in=" + sparse, "data_format=criteo", "batch_size=200", "shuffle=1", "neg_sampling=0.97", "V_dim=4",
+                         "V_threshold=0", "l1=.01", "lr=.1", "V_lr=.05", "V_init=hash", "max_num_epochs=2", "stop_rel_objv=0",
+                         "num_jobs_per_epoch=1"])]
     for name, args in cases:
         for feed in ("device", "host"):
             env = dict(os.environ)
@@ -218,7 +280,7 @@ def test_cli_device_feed_matches_host_feed(built, tmp_path):
             r = subprocess.run([exe, "task=train", "learner=sgd"] + args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
             assert r.returncode == 0, r.stderr[-2000:]
             runs[name, feed] = [l.split("] ")[-1] for l in r.stderr.splitlines() if "loss = " in l]
-        assert len(runs[name, "device"]) >= 3 and runs[name, "device"] == runs[name, "host"], (name, runs[name, "device"], runs[name, "host"])
+        assert len(runs[name, "device"]) >= 2 and runs[name, "device"] == runs[name, "host"], (name, runs[name, "device"], runs[name, "host"])
 
 
 @pytest.mark.gpu

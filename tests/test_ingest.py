@@ -278,6 +278,39 @@ def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch,
                 assert np.array_equal(got[k], want[k]), (fmt, kw, k)
 
 
+@pytest.mark.parametrize("depth", [0, 2])
+def test_described_minibatches_spanning_many_buffers(ing, tmp_path, monkeypatch, depth):
+    """with strong down-sampling (the reference DROPS a negative with probability neg_sampling,
+    batch_reader.cc:57-63, so values near 1 on data with few positives) ONE minibatch draws its rows
+    from dozens of shuffle buffers, and the reader runs further ahead in buffers than any fixed ring holds.  The
+    description's consumer keeps every announced buffer until the last minibatch that names it has been gathered
+    (ingest_capi.cc here, DeviceFeed in the worker loop): still exactly the copying reader's minibatches"""
+    rng = np.random.default_rng(41 + depth)
+    lines = []
+    for i in range(6000):   # 3 % positives
+        n = int(rng.integers(1, 7))
+        ids = rng.integers(1, 10 ** 9, size=n)
+        lines.append(" ".join(["1" if rng.random() < 0.03 else "-1"] + ["%d:%g" % (a, b) for a, b in zip(ids, np.round(rng.normal(size=n), 2))]))
+    svm = tmp_path / "sparse_pos.libsvm"
+    svm.write_text("\n".join(lines) + "\n")
+    monkeypatch.setenv("DIFACTO_CHUNK_BYTES", "9000")
+    for kw in (dict(batch=100, shuffle=100, neg=0.98), dict(batch=150, shuffle=300, neg=0.95), dict(batch=64, shuffle=64, neg=0.99)):
+        monkeypatch.delenv("DIFACTO_INGEST_DESCRIBE", raising=False)
+        monkeypatch.delenv("DIFACTO_INGEST_PREFETCH", raising=False)
+        ing.ingest_reset_shuffle_stream()
+        want = read_all(ing, svm, "libsvm", **kw)
+        kept = len(want["label"])
+        assert kept < 0.12 * 6000 and want["nbatches"] >= 2   # most negatives dropped: a minibatch spans >= 8 buffers on average
+        monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", "1")
+        if depth:
+            monkeypatch.setenv("DIFACTO_INGEST_PREFETCH", str(depth))
+        ing.ingest_reset_shuffle_stream()
+        got = read_all(ing, svm, "libsvm", **kw)
+        assert got["nbatches"] == want["nbatches"], kw
+        for k in ("offset", "label", "index", "value"):
+            assert np.array_equal(got[k], want[k]), (kw, k)
+
+
 def test_reader_threads_under_tsan(tmp_path):
     """the reader's threads (parser pool, shuffle-buffer thread, minibatch thread) under ThreadSanitizer: no report"""
     import shutil

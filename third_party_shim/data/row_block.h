@@ -33,9 +33,24 @@ struct RowBlockContainer {
   std::vector<real_t> weight;
   std::vector<IndexType, DefaultInitAllocator<IndexType>> index;
   std::vector<real_t, DefaultInitAllocator<real_t>> value;
+  /*! \brief the largest index stored — exact after Push(Row) and after an assignment (Localizer::RemapIndex sets it,
+   *  src/data/localizer.cc:102); Push(RowBlock) and bulk appenders only mark it stale (the scan was a second pass over
+   *  every byte the shuffle buffer's assembly copies): read it through GetMaxIndex(), which rescans when needed */
   IndexType max_index;
+  bool max_index_stale;
 
   RowBlockContainer() { Clear(); }
+
+  /*! \brief max_index, recomputed first if bulk appends have left it stale */
+  inline IndexType GetMaxIndex() {
+    if (max_index_stale) {
+      IndexType m = 0;
+      for (const IndexType& id : index) m = std::max(m, id);
+      max_index = m;
+      max_index_stale = false;
+    }
+    return max_index;
+  }
 
   inline void Clear() {
     offset.assign(1, 0);
@@ -44,6 +59,7 @@ struct RowBlockContainer {
     index.clear();
     value.clear();
     max_index = 0;
+    max_index_stale = false;
   }
   inline size_t Size() const { return offset.size() - 1; }
   inline size_t MemCostBytes() const {
@@ -78,10 +94,10 @@ struct RowBlockContainer {
     size_t nnz = blk.offset[blk.size] - blk.offset[0];
     if (blk.label != nullptr) label.insert(label.end(), blk.label, blk.label + blk.size);
     if (blk.weight != nullptr) weight.insert(weight.end(), blk.weight, blk.weight + blk.size);
-    // one pass (converts when I != IndexType), no zero fill.  max_index is NOT maintained for appended blocks: nothing on
-    // this path reads it (the Localizer is given its modulus explicitly, src/sgd/sgd_learner.cc:203) and the scan was a
-    // second pass over every byte the shuffle buffer's assembly copies
+    // one pass (converts when I != IndexType), no zero fill.  max_index goes stale instead of being rescanned here:
+    // nothing on the worker path reads it (the Localizer is given its modulus explicitly, src/sgd/sgd_learner.cc:203)
     index.insert(index.end(), blk.index, blk.index + nnz);
+    max_index_stale = max_index_stale || nnz > 0;
     if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
     size_t shift = offset.back();
     for (size_t i = 0; i < blk.size; ++i) {
