@@ -156,7 +156,7 @@ struct dfh_batch {
   // step workspace
   // long-segment key lists for the backward pass (SegLists): list buckets = sort buckets
   uint2 *d_mid = nullptr, *d_hot = nullptr, *d_few = nullptr;  // [list buckets] {cnt, off}
-  uint32_t *d_mid_ent = nullptr, *d_hot_ent = nullptr, *d_few_ent = nullptr;
+  SegEnt *d_mid_ent = nullptr, *d_hot_ent = nullptr, *d_few_ent = nullptr;
   uint32_t seg_nb = 0;                              // list buckets of the current localized view
   uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
@@ -170,7 +170,8 @@ struct dfh_batch {
   hipStream_t prep = nullptr;      // stream of the current preparation phase (load .. localize .. lookup)
   bool compute_auc = false;        // dfh_sgd_step also accumulates BinClassMetric::AUC per batch
   uint32_t *d_auc_keys = nullptr, *d_auc_skeys = nullptr, *d_auc_lab = nullptr, *d_auc_slab = nullptr;
-  unsigned long long* d_auc_acc = nullptr;  // k_auc_pairs: {area, positives, finished blocks}, zero between launches
+  uint32_t* d_auc_part = nullptr;  // auc_pairs_block: one count per unit + the positives per row tile
+  uint32_t auc_pending_n = 0;      // examples of the AUC whose units have been queued but not finalised (0: none)
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
   bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
@@ -566,14 +567,26 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* 
   return DFH_OK;
 }
 
+// an AUC whose units have run (inside an update launch) but whose slots have not been added up yet
+AucFin auc_pending(dfh_batch* b) { return AucFin{b->d_auc_part, b->auc_pending_n, b->d_prog + PROG_AUC * PROG_SLOTS}; }
+int auc_flush_pending(dfh_batch* b) {
+  if (!b->auc_pending_n) return DFH_OK;
+  hipLaunchKernelGGL(k_auc_finalize, dim3(1), dim3(256), 0, b->ctx->stream, auc_pending(b));
+  b->auc_pending_n = 0;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
 // BinClassMetric::AUC of the batch's predictions, accumulated into the progress block
 int launch_auc(dfh_batch* b) {
   hipStream_t s = b->ctx->stream;
   const uint32_t n = (uint32_t)b->nrows;
   if (n <= AUC_PAIRS_MAX_N) {
-    // minibatch-sized: pair counting, one hand-written launch (k_auc_pairs)
-    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units(n)), dim3(256), 0, s, b->d_pred, b->d_label, n, b->d_auc_acc,
-                       b->d_prog + PROG_AUC * PROG_SLOTS);
+    // minibatch-sized: pair counting (auc_pairs_block units), then one block adds the units' slots up
+    int rc = auc_flush_pending(b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units(n)), dim3(256), 0, s, b->d_pred, b->d_label, n, b->d_auc_part);
+    hipLaunchKernelGGL(k_auc_finalize, dim3(1), dim3(256), 0, s, AucFin{b->d_auc_part, n, b->d_prog + PROG_AUC * PROG_SLOTS});
     DFH_HIP(hipGetLastError());
     return DFH_OK;
   }
@@ -623,8 +636,7 @@ UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* nee
   a.nb_hot = a.nb_mid = a.nb_few = 0;
   a.auc_pred = nullptr;
   a.auc_label = nullptr;
-  a.auc_acc = nullptr;
-  a.auc_out = nullptr;
+  a.auc_part = nullptr;
   a.nb_auc = 0;
   return a;
 }
@@ -640,9 +652,11 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   if (with_auc) {  // the minibatch's AUC rides in this launch (dfh_sgd_step, compute_auc)
     a.auc_pred = b->d_pred;
     a.auc_label = b->d_label;
-    a.auc_acc = b->d_auc_acc;
-    a.auc_out = b->d_prog + PROG_AUC * PROG_SLOTS;
-    a.nb_auc = auc_units((uint32_t)b->nrows);
+    int rcf = auc_flush_pending(b);  // the slots are about to be overwritten (normally closed by this step's k_lookup already)
+    if (rcf) return rcf;
+    a.auc_part = b->d_auc_part;
+    a.nb_auc = (auc_units((uint32_t)b->nrows) + 7u) & ~7u;  // a multiple of 8: the roles behind keep their XCDs
+    b->auc_pending_n = (uint32_t)b->nrows;  // finalised by the next launch that carries it (k_lookup of the next step, dfh_batch_progress)
   }
   // blocks per role (U and the list sizes live on the device; nnz bounds them): surplus blocks find their
   // list exhausted and leave at once
@@ -650,6 +664,10 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   a.nb_hot = (uint32_t)std::max<size_t>(1, std::min<size_t>(nnz / (BWD_MID + 1) + 1, (size_t)c->upd_hot_blocks));
   a.nb_mid = (uint32_t)std::max<size_t>(1, std::min<size_t>((nnz / (BWD_SMALL + 1)) / UPD_NW + 1, (size_t)c->upd_mid_blocks));
   a.nb_few = (uint32_t)std::max<size_t>(1, std::min<size_t>((nnz / 2) / (UPD_NW * G) + 1, (size_t)c->upd_few_blocks));
+  // singles block b on the XCD that ran the forward's block b (workgroups go round-robin over the 8 XCDs; the XV rows and
+  // slopes of a block's four examples sit in that XCD's L2): the blocks before it add up to a multiple of 8.  (Measured in
+  // round 4 by shifting the role 1 or 4 blocks: no difference, 86.0 against 85.9 M examples/sec — kept because it is free.)
+  a.nb_few += (8u - (a.nb_hot + a.nb_mid + a.nb_few) % 8u) % 8u;
   const size_t nb_single = std::max<size_t>(1, std::min<size_t>((b->nrows + UPD_NW - 1) / UPD_NW, (size_t)c->upd_single_blocks));
   hipEvent_t ea = nullptr, eb = nullptr;  // timing rides on the dispatch, like the forward's
   if ((c->timing >> DFH_K_BACKWARD) & 1u) {
@@ -1084,7 +1102,7 @@ int dfh_shard_push_count(dfh_table* t, const uint64_t* d_keys, size_t n, const f
   }
   hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (const uint32_t*)nullptr, (uint32_t)n, refrand ? t->d_urow : (uint32_t*)nullptr, d_cnt,
-                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr, 0, (uint2*)nullptr);
+                     (const uint32_t*)nullptr, 1, refrand ? t->d_need : (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
   DFH_HIP(hipGetLastError());
   if (refrand) return refrand_flush(t, d_keys, nullptr, (uint32_t)n, t->d_urow, t->d_need, t->d_rank, t->d_total);
   return DFH_OK;
@@ -1147,7 +1165,7 @@ int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const u
   if (n == 0) return DFH_OK;
   hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n, t->ctx)), dim3(256), 0, t->ctx->stream, t->v, d_keys,
                      (const uint32_t*)nullptr, (uint32_t)n, const_cast<uint32_t*>(d_rowid), d_cnt, (const uint32_t*)nullptr, 1,
-                     (uint32_t*)nullptr, 1, (uint2*)nullptr);
+                     (uint32_t*)nullptr, 1, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
@@ -1823,9 +1841,9 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_urow, N, uint32_t);
   DFH_ALLOC(b->d_uw, N, uint2);
   // bucket q of the sample sort may list n_q / 9 + 2 mid and n_q / 257 + 2 hot keys (k_loc_emit)
-  DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
-  DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
-  DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_MAX_BUCKETS + 16, uint32_t);
+  DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
+  DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
+  DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
   DFH_ALLOC(b->d_mid, LOC_MAX_BUCKETS, uint2);
   DFH_ALLOC(b->d_hot, LOC_MAX_BUCKETS, uint2);
   DFH_ALLOC(b->d_few, LOC_MAX_BUCKETS, uint2);
@@ -1838,7 +1856,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_skeys, B, uint32_t);
   DFH_ALLOC(b->d_auc_lab, B, uint32_t);
   DFH_ALLOC(b->d_auc_slab, B, uint32_t);
-  DFH_ALLOC(b->d_auc_acc, 8, unsigned long long);
+  DFH_ALLOC(b->d_auc_part, AUC_PART_WORDS, uint32_t);
 #undef DFH_ALLOC
   b->d_total = b->d_U + 1;
   // ev_ready / ev_free order streams of ONE device: no system-scope fence (cache write-back + invalidate) at the record
@@ -1848,7 +1866,6 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
-  DFH_HIP(hipMemsetAsync(b->d_auc_acc, 0, 8 * sizeof(unsigned long long), c->stream));
   // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
   // all-ones makes a stray use fault at once instead of reading some row
   DFH_HIP(hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream));
@@ -1872,7 +1889,7 @@ int dfh_batch_destroy(dfh_batch* b) {
                   b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
                   b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
                   b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw,
-                  b->d_auc_acc, b->d_few, b->d_few_ent};
+                  b->d_auc_part, b->d_few, b->d_few_ent};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete b;
@@ -2296,7 +2313,7 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     b->seg_nb = 1;
     if (probe)  // the library sort's path has no emit pass to carry the probe
       hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, s, probe->v, b->d_feaids, b->d_U, 0u, b->d_urow,
-                         (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr);
+                         (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
   }
   delete tsp;
   DFH_HIP(hipGetLastError());
@@ -2359,7 +2376,7 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
     hipStream_t ps = prep_of(b);
     TimeScope ts(c, DFH_K_LOOKUP, ps);
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, ps, t->v, b->d_feaids, b->d_U, 0u,
-                       b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr);
+                       b->d_urow, (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
   }
   DFH_HIP(hipGetLastError());
   b->looked_up = t;
@@ -2570,9 +2587,11 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   const bool defer_cnt = push_cnt && is_train && c->upd_kernel != 0;
   {
     TimeScope ts(c, DFH_K_LOOKUP);
+    // (the lookup's first block also adds up the AUC slots this batch object's previous step left behind)
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
-                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw);
+                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b));
+    b->auc_pending_n = 0;
   }
   DFH_HIP(hipGetLastError());
   if (push_cnt && refrand) {
@@ -2640,7 +2659,9 @@ int dfh_batch_progress(dfh_batch* b, dfh_progress* out, int reset) {
   std::vector<double> p(2 * PROG_SLOTS + 1);
   hipStream_t s = b->ctx->stream;
   {
-    int rc = sync_all(b->ctx);
+    int rc = auc_flush_pending(b);  // the last step's AUC slots, if no later step has added them up
+    if (rc) return rc;
+    rc = sync_all(b->ctx);
     if (rc) return rc;
   }
   DFH_HIP(hipMemcpyAsync(p.data(), b->d_prog, p.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2681,20 +2702,20 @@ int dfh_auc_times_n(dfh_ctx* c, const float* label, const float* pred, size_t n,
   if (!pairs)
     rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
                               c->stream);
-  int rc = ensure_scratch(c, 2 * padded<float>(n) + (pairs ? 0 : 4 * padded<uint32_t>(n)) + tb + 2048);
+  int rc = ensure_scratch(c, 2 * padded<float>(n) + (pairs ? 0 : 4 * padded<uint32_t>(n)) + tb + padded<uint32_t>(AUC_PART_WORDS) + 2048);
   if (rc) return rc;
   Carver cv(c->scratch);
   float* d_l = cv.take<float>(n);
   float* d_p = cv.take<float>(n);
   double* d_o = cv.take<double>(1);
-  unsigned long long* d_acc = cv.take<unsigned long long>(8);
+  uint32_t* d_part = cv.take<uint32_t>(AUC_PART_WORDS);
   hipStream_t s = c->stream;
   DFH_HIP(hipMemcpyAsync(d_l, label, n * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(d_p, pred, n * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemsetAsync(d_o, 0, sizeof(double), s));
   if (pairs) {
-    DFH_HIP(hipMemsetAsync(d_acc, 0, 8 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units((uint32_t)n)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, d_acc, d_o);
+    hipLaunchKernelGGL(k_auc_pairs, dim3(auc_units((uint32_t)n)), dim3(256), 0, s, d_p, d_l, (uint32_t)n, d_part);
+    hipLaunchKernelGGL(k_auc_finalize, dim3(1), dim3(256), 0, s, AucFin{d_part, (uint32_t)n, d_o});
   } else {
     uint32_t* k0 = cv.take<uint32_t>(n);
     uint32_t* k1 = cv.take<uint32_t>(n);

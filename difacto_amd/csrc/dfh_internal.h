@@ -64,13 +64,16 @@ struct TableView {
 // Localizer fills one list bucket per sort bucket (k_loc_emit: no inter-block compaction);
 // k_seg_lists fills a single one.  Order inside and across buckets is arbitrary.  The number of
 // list buckets is known to the host when it queues the Localizer and travels as a kernel argument.
+// an entry carries the key's rank AND its segment {u, beg, end, 0}: the role that walks a list has the occurrence
+// range with the entry's own 16 B load instead of a dependent col_ptr[u], col_ptr[u + 1] round trip (round 4)
+typedef uint4 SegEnt;
 struct SegLists {
   const uint2* mid;         // [nb] {cnt, off}
-  const uint32_t* mid_ent;
+  const SegEnt* mid_ent;
   const uint2* hot;         // [nb] {cnt, off}
-  const uint32_t* hot_ent;
+  const SegEnt* hot_ent;
   const uint2* few;         // [nb] {cnt, off}: keys with 2 .. BWD_SMALL occurrences (k_update_fused only)
-  const uint32_t* few_ent;
+  const SegEnt* few_ent;
 };
 
 // flag bits of the row word k_lookup / k_uw_remote leave per unique key in uw[]: a table holds fewer

@@ -66,9 +66,10 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
 // acc + a * b the way SpMV does it (src/common/spmv.h:125, :155): an operand `a` that is exactly zero is SKIPPED, not
 // multiplied.  Neutral for finite b; for b = Inf / NaN (a non-finite feature value) it is the difference between the
 // reference's result and NaN: a zero weight (pulled as 0: no entry yet, or clipped by l1) and a slope that underflowed to 0
-// do not see the value at all.  The forward applies the same test to the coordinates of V: a key WITHOUT V is skipped by
-// SpMM (V_pos = -1, spmm.h:108) and is an all-zero row here, so the skip reproduces it (the one case left apart: a V
-// coordinate that is exactly 0.0 in an allocated row times a non-finite value, NaN in the reference, skipped here).
+// do not see the value at all.  The forward treats V rows likewise, slice by slice: a key WITHOUT V is skipped by SpMM
+// (V_pos = -1, spmm.h:108) and is an all-zero row here; a lane whose 16 B slice of a row is all zero multiplies by x = 0
+// instead of the value (k_forward).  The one case left apart: an ALLOCATED row four consecutive coordinates of which
+// are exactly 0.0, times a non-finite value — NaN in the reference, neutral here.
 __device__ __forceinline__ float fma_skip0(float a, float b, float acc) { return a != 0.f ? __builtin_fmaf(a, b, acc) : acc; }
 
 // The sharding-independent V init: must match oracle/difacto_oracle.c:orc_hash_init_value
@@ -269,6 +270,148 @@ constexpr int BWD_THREADS = DFH_BWD_THREADS;    // threads per block of k_backwa
 __device__ unsigned long long g_bwd_trace[3 * 8192];
 #endif
 
+// BinClassMetric::AUC without a sort, for minibatch-sized n: the reference's area is the number of
+// (positive j, negative i) pairs in which j comes before i in the sorted order (bin_class_metric.h:44-50),
+// and "before" can be decided pair by pair: pred_j < pred_i, ties by index (the order a stable sort gives;
+// std::sort leaves the order of ties unspecified).  The count is an integer: exact, whatever the order.
+// Round 4: only positive columns are compared (a tile of AUC_TILE examples is compacted to its positives in LDS,
+// any order) and (image of pred, index) is ONE 64-bit key, so a pair costs a broadcast LDS read, one v_cmp_lt_u64
+// and one add-with-carry: ~2e7 pairs of 2 VALU operations for a 10 000-row minibatch with 25 % positives, where
+// round 3 spent 1e8 pairs of 7.  auc_pairs_block is one unit of work: 256 rows (this block's threads) against the
+// column tiles ct, ct + nct, ...; units are independent, write their count to a slot of their own — no atomics,
+// no fence, no ticket (round 3's three same-address atomics + a device-scope fence per block were most of the
+// kernel's 27 us) — and may run as blocks of k_auc_pairs or as a role of k_update_fused (the update launch has idle
+// VALUs).  auc_finalize_block (one block, any later launch on the stream) adds the slots up and turns
+// {area, positives} into AUC * n (:51-53).
+constexpr int AUC_TILE = 1024;
+constexpr uint32_t AUC_PAIRS_MAX_N = 32768;   // beyond: the radix-sort path (n^2 would pass the cost of sorting)
+constexpr uint32_t AUC_COL_SPLIT = 16;        // column tiles are dealt to this many units per row tile (10 000 rows: one tile per unit)
+constexpr uint32_t AUC_MAX_ROWTILES = AUC_PAIRS_MAX_N / 256;
+constexpr uint32_t AUC_PART_WORDS = AUC_MAX_ROWTILES * (AUC_COL_SPLIT + 1);  // [units] counts | [row tiles] positives
+
+__device__ __forceinline__ uint32_t auc_key(float pred) {
+  const uint32_t bits = __float_as_uint(pred + 0.0f);  // -0 and +0 compare equal in the reference: one image
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__host__ __device__ inline uint32_t auc_nct(uint32_t n) {  // units per row tile
+  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
+  return ntile < AUC_COL_SPLIT ? ntile : AUC_COL_SPLIT;
+}
+__host__ __device__ inline uint32_t auc_units(uint32_t n) { return ((n + 255) / 256) * auc_nct(n); }
+
+// a finished set of units waiting for its finalisation: part (device), n examples; n == 0: nothing pending
+struct AucFin {
+  const uint32_t* part;
+  uint32_t n;
+  double* out_slot;
+};
+
+// unit `unit` of auc_units(n): 256-thread blocks only.  part[unit] = pairs counted; part[auc_units(n) + rt] = positives of
+// row tile rt (written by the tile's first unit)
+__device__ __forceinline__ void auc_pairs_block(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n, uint32_t unit,
+                                                uint32_t* __restrict__ part) {
+  __shared__ unsigned long long colp[AUC_TILE];  // positives of the current column tile: image of pred_j << 32 | j
+  __shared__ uint32_t npos_tile;
+  __shared__ uint32_t red[8];
+  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
+  const uint32_t nct = auc_nct(n);
+  const uint32_t rt = unit / nct, ct = unit % nct;
+  const uint32_t i = rt * 256u + threadIdx.x;
+  unsigned long long ki = 0;
+  bool neg = false, pos = false;
+  if (i < n) {
+    ki = ((unsigned long long)auc_key(pred[i]) << 32) | i;
+    pos = label[i] > 0;
+    neg = !pos;
+  }
+  uint32_t cnt = 0;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t tile = ct; tile < ntile; tile += nct) {
+    __syncthreads();  // the previous tile has been consumed
+    if (threadIdx.x == 0) npos_tile = 0;
+    const uint32_t j0 = tile * AUC_TILE;
+    // all of the tile's loads first (one round trip), then the compaction: a ballot per wave and ONE LDS atomic per wave
+    // and quarter
+    float pj[AUC_TILE / 256], lj[AUC_TILE / 256];
+#pragma unroll
+    for (int r = 0; r < AUC_TILE / 256; ++r) {
+      const uint32_t j = min(j0 + r * 256u + threadIdx.x, n - 1);
+      pj[r] = pred[j];
+      lj[r] = label[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < AUC_TILE / 256; ++r) {
+      const uint32_t j = j0 + r * 256u + threadIdx.x;
+      const bool pj_pos = j < n && lj[r] > 0;
+      const unsigned long long m = __ballot(pj_pos);
+      uint32_t base = 0;
+      if (lane == 0 && m) base = atomicAdd(&npos_tile, (uint32_t)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (pj_pos) colp[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)auc_key(pj[r]) << 32) | j;
+    }
+    __syncthreads();
+    const uint32_t np = npos_tile;
+#pragma unroll 8
+    for (uint32_t t = 0; t < np; ++t) cnt += colp[t] < ki ? 1u : 0u;  // (pred_j, j) before (pred_i, i)
+  }
+  if (!neg) cnt = 0;
+  uint32_t npos = pos ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    npos += __shfl_xor(npos, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    red[threadIdx.x >> 6] = cnt;
+    red[4 + (threadIdx.x >> 6)] = npos;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[unit] = red[0] + red[1] + red[2] + red[3];
+    if (ct == 0) part[auc_units(n) + rt] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// one 256-thread block: the units' slots -> AUC * n, added to *out_slot
+__device__ __forceinline__ void auc_finalize_block(const AucFin f) {
+  __shared__ unsigned long long fsum[2][4];
+  const uint32_t nu = auc_units(f.n), nrt = (f.n + 255) / 256;
+  unsigned long long area = 0, tp = 0;
+  for (uint32_t q = threadIdx.x; q < nu; q += 256u) area += f.part[q];
+  for (uint32_t q = threadIdx.x; q < nrt; q += 256u) tp += f.part[nu + q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    area += __shfl_xor(area, o, 64);
+    tp += __shfl_xor(tp, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    fsum[0][threadIdx.x >> 6] = area;
+    fsum[1][threadIdx.x >> 6] = tp;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a_all = (double)(fsum[0][0] + fsum[0][1] + fsum[0][2] + fsum[0][3]);
+    const double tpd = (double)(fsum[1][0] + fsum[1][1] + fsum[1][2] + fsum[1][3]);
+    const double nn = (double)f.n;
+    double auc_n;
+    if (tpd == 0.0 || tpd == nn) {
+      auc_n = 1.0;  // :51 (the reference returns 1, not n)
+    } else {
+      const double a = a_all / (tpd * (nn - tpd));
+      auc_n = (a < 0.5 ? 1.0 - a : a) * nn;
+    }
+    *f.out_slot += auc_n;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
+                                                   uint32_t* __restrict__ part) {
+  auc_pairs_block(pred, label, n, blockIdx.x, part);
+}
+__global__ void __launch_bounds__(256) k_auc_finalize(AucFin f) { auc_finalize_block(f); }
+
 // ---------------------------------------------------------------------------
 // k_lookup: one thread per unique key.  urow[u] = row of feaids[u] (inserted as
 // a zero row if unseen: sgd_updater.cc:44).  With cnt != NULL it also applies
@@ -278,7 +421,9 @@ __device__ unsigned long long g_bwd_trace[3 * 8192];
 __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
-                         int rows_known, uint2* __restrict__ uw) {
+                         int rows_known, uint2* __restrict__ uw, AucFin fin) {
+  // a step's lookup also closes the AUC its batch object's previous step left pending (dfh_sgd_step; fin.n == 0: none)
+  if (fin.n && blockIdx.x == 0) auc_finalize_block(fin);
   uint32_t n = d_n ? *d_n : n_static;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
     uint64_t key = keys[u];
@@ -490,13 +635,16 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
           }
 #pragma unroll
           for (int q = 0; q < FWD_DEPTH; ++q) {
-            const float xx = xs[q];
-            // zero coordinates (every coordinate of a key without V) are skipped, see fma_skip0
-            xv.x = fma_skip0(v[q].x, xx, xv.x); xv.y = fma_skip0(v[q].y, xx, xv.y);
-            xv.z = fma_skip0(v[q].z, xx, xv.z); xv.w = fma_skip0(v[q].w, xx, xv.w);
+            // a key WITHOUT V is skipped by SpMM (V_pos = -1, spmm.h:108); here it is a row of zeros that was loaded
+            // speculatively: a slice that is all zero takes x = 0, so that an Inf / NaN feature value on such a key gives
+            // 0 * 0 and not NaN.  (One test per 16 B slice, not per coordinate: per-coordinate selects cost the forward
+            // 1.4 us of 20.)
+            const uint32_t any = (__float_as_uint(v[q].x) | __float_as_uint(v[q].y) | __float_as_uint(v[q].z) | __float_as_uint(v[q].w)) << 1;
+            const float xx = any ? xs[q] : 0.f;
+            xv.x += v[q].x * xx; xv.y += v[q].y * xx; xv.z += v[q].z * xx; xv.w += v[q].w * xx;
             const float x2 = xx * xx;
-            xxvv.x = fma_skip0(v[q].x * v[q].x, x2, xxvv.x); xxvv.y = fma_skip0(v[q].y * v[q].y, x2, xxvv.y);
-            xxvv.z = fma_skip0(v[q].z * v[q].z, x2, xxvv.z); xxvv.w = fma_skip0(v[q].w * v[q].w, x2, xxvv.w);
+            xxvv.x += (v[q].x * v[q].x) * x2; xxvv.y += (v[q].y * v[q].y) * x2;
+            xxvv.z += (v[q].z * v[q].z) * x2; xxvv.w += (v[q].w * v[q].w) * x2;
           }
         }
       }
@@ -761,11 +909,12 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
     const uint2 co = b.seg.mid[lb];
     const uint32_t nm = co.x;
     if (nm == 0) continue;
-    const uint32_t* __restrict__ ent = b.seg.mid_ent + co.y;
+    const SegEnt* __restrict__ ent = b.seg.mid_ent + co.y;
     for (uint32_t q = sub_w; q < nm; q += G) {
-      const uint32_t u = ent[q];
+      const SegEnt e = ent[q];
+      const uint32_t u = e.x;
       if (!key_in(rg, u)) continue;  // uniform per wave
-      const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+      const uint32_t beg = e.y, end = e.z;
       KeySums s = wave_segment_sums<L>(b, beg, end, 0, 1, k > 0, sub_ok, grp, sub, kp);
       // the key's row is fetched after the sums: one more round trip for a segment of 9+ occurrences,
       // 14 registers fewer alive through the loop (the kernel runs at 64 registers, 8 waves per SIMD)
@@ -797,11 +946,12 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
   const uint2 co = b.seg.hot[lb];
   const uint32_t nh = co.x;
   if (nh == 0) continue;
-  const uint32_t* __restrict__ ent = b.seg.hot_ent + co.y;
+  const SegEnt* __restrict__ ent = b.seg.hot_ent + co.y;
   for (uint32_t q = sub_b; q < nh; q += G) {
-    const uint32_t u = ent[q];
+    const SegEnt e = ent[q];
+    const uint32_t u = e.x;
     if (!key_in(rg, u)) continue;  // uniform per block
-    const uint32_t beg = b.col_ptr[u], end = b.col_ptr[u + 1];
+    const uint32_t beg = e.y, end = e.z;
     KeySums s = wave_segment_sums<L>(b, beg, end, (uint32_t)w, NW, k > 0, sub_ok, grp, sub, kp);
     __syncthreads();  // previous key's partials consumed
     if (grp == 0) {
@@ -1124,16 +1274,20 @@ __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(Bat
 // very large batches, batches localized on the host).
 __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ d_U,
                                                     uint2* __restrict__ mid0, uint2* __restrict__ hot0, uint2* __restrict__ few0,
-                                                    uint32_t* __restrict__ mid_ent, uint32_t* __restrict__ hot_ent,
-                                                    uint32_t* __restrict__ few_ent) {
+                                                    SegEnt* __restrict__ mid_ent, SegEnt* __restrict__ hot_ent,
+                                                    SegEnt* __restrict__ few_ent) {
   __shared__ uint32_t cnt[3], base[3];
   const uint32_t U = *d_U;
   for (uint32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += gridDim.x * blockDim.x) {
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t u = u0 + threadIdx.x;
-    uint32_t len = 0, slot = 0;
-    if (u < U) len = col_ptr[u + 1] - col_ptr[u];
+    uint32_t len = 0, slot = 0, cbeg = 0, cend = 0;
+    if (u < U) {
+      cbeg = col_ptr[u];
+      cend = col_ptr[u + 1];
+      len = cend - cbeg;
+    }
     const int which = len > BWD_MID ? 1 : (len > BWD_SMALL ? 0 : (len > 1 ? 2 : -1));
     if (which >= 0) slot = atomicAdd(&cnt[which], 1u);
     __syncthreads();
@@ -1141,9 +1295,10 @@ __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__
     if (threadIdx.x == 1 && cnt[1]) base[1] = atomicAdd(&hot0->x, cnt[1]);
     if (threadIdx.x == 2 && cnt[2]) base[2] = atomicAdd(&few0->x, cnt[2]);
     __syncthreads();
-    if (which == 0) mid_ent[base[0] + slot] = u;
-    if (which == 1) hot_ent[base[1] + slot] = u;
-    if (which == 2) few_ent[base[2] + slot] = u;
+    const SegEnt e = make_uint4(u, cbeg, cend, 0u);
+    if (which == 0) mid_ent[base[0] + slot] = e;
+    if (which == 1) hot_ent[base[1] + slot] = e;
+    if (which == 2) few_ent[base[2] + slot] = e;
     __syncthreads();
   }
 }
@@ -1805,123 +1960,6 @@ __global__ void __launch_bounds__(1024) k_auc_area(const uint32_t* __restrict__ 
     }
     *out_slot += auc_n;
   }
-}
-
-// BinClassMetric::AUC without a sort, for minibatch-sized n: the reference's area is the number of
-// (positive j, negative i) pairs in which j comes before i in the sorted order (bin_class_metric.h:44-50),
-// and "before" can be decided pair by pair: pred_j < pred_i, ties by index (the order a stable sort gives;
-// std::sort leaves the order of ties unspecified).  The count is an integer, so the result does not depend on
-// the order of the atomics.  Round 4: only positive columns are compared (a tile of AUC_TILE examples is
-// compacted to its positives in LDS, any order) and (image of pred, index) is ONE 64-bit key, so a pair costs a
-// broadcast LDS read, one v_cmp_lt_u64 and one add-with-carry: ~2e7 pairs of 2 VALU operations for a 10 000-row
-// minibatch with 25 % positives, where round 3 spent 1e8 pairs of 7.  auc_pairs_block is one unit of work:
-// 256 rows (this block's threads) against the column tiles ct, ct + nct, ...; units are independent and may
-// run as blocks of k_auc_pairs or as a role of k_update_fused (the update launch has idle VALUs: the metric
-// rides along for free).  The last unit to finish turns {area, positives} into AUC * n (:51-53), adds it to
-// *out_slot and zeroes acc for the next call.
-constexpr int AUC_TILE = 1024;
-constexpr uint32_t AUC_PAIRS_MAX_N = 32768;   // beyond: the radix-sort path (n^2 would pass the cost of sorting)
-constexpr uint32_t AUC_COL_SPLIT = 16;        // column tiles are dealt to this many units per row tile (10 000 rows: one tile per unit)
-
-__device__ __forceinline__ uint32_t auc_key(float pred) {
-  const uint32_t bits = __float_as_uint(pred + 0.0f);  // -0 and +0 compare equal in the reference: one image
-  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-}
-__host__ __device__ inline uint32_t auc_units(uint32_t n) {  // units of work for n examples
-  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
-  return ((n + 255) / 256) * (ntile < AUC_COL_SPLIT ? ntile : AUC_COL_SPLIT);
-}
-
-// unit `unit` of auc_units(n): 256-thread blocks only
-__device__ __forceinline__ void auc_pairs_block(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n, uint32_t unit,
-                                                unsigned long long* __restrict__ acc /* area, positives, finished units */,
-                                                double* __restrict__ out_slot) {
-  __shared__ unsigned long long colp[AUC_TILE];  // positives of the current column tile: image of pred_j << 32 | j
-  __shared__ uint32_t npos_tile;
-  __shared__ uint32_t red[4];
-  const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
-  const uint32_t nct = ntile < AUC_COL_SPLIT ? ntile : AUC_COL_SPLIT;
-  const uint32_t rt = unit / nct, ct = unit % nct;
-  const uint32_t i = rt * 256u + threadIdx.x;
-  unsigned long long ki = 0;
-  bool neg = false, pos = false;
-  if (i < n) {
-    ki = ((unsigned long long)auc_key(pred[i]) << 32) | i;
-    pos = label[i] > 0;
-    neg = !pos;
-  }
-  uint32_t cnt = 0;
-  const int lane = threadIdx.x & 63;
-  for (uint32_t tile = ct; tile < ntile; tile += nct) {
-    __syncthreads();  // the previous tile has been consumed
-    if (threadIdx.x == 0) npos_tile = 0;
-    const uint32_t j0 = tile * AUC_TILE;
-    // all of the tile's loads first (one round trip), then the compaction: a ballot per wave and ONE LDS atomic per wave
-    // and quarter (same-address atomics serialise: one per positive cost 5-10 us per tile)
-    float pj[AUC_TILE / 256], lj[AUC_TILE / 256];
-#pragma unroll
-    for (int r = 0; r < AUC_TILE / 256; ++r) {
-      const uint32_t j = min(j0 + r * 256u + threadIdx.x, n - 1);
-      pj[r] = pred[j];
-      lj[r] = label[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < AUC_TILE / 256; ++r) {
-      const uint32_t j = j0 + r * 256u + threadIdx.x;
-      const bool pj_pos = j < n && lj[r] > 0;
-      const unsigned long long m = __ballot(pj_pos);
-      uint32_t base = 0;
-      if (lane == 0 && m) base = atomicAdd(&npos_tile, (uint32_t)__popcll(m));
-      base = __shfl(base, 0, 64);
-      if (pj_pos) colp[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)auc_key(pj[r]) << 32) | j;
-    }
-    __syncthreads();
-    const uint32_t np = npos_tile;
-#pragma unroll 8
-    for (uint32_t t = 0; t < np; ++t) cnt += colp[t] < ki ? 1u : 0u;  // (pred_j, j) before (pred_i, i)
-  }
-  if (!neg) cnt = 0;
-  uint32_t npos = (ct == 0 && pos) ? 1u : 0u;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    cnt += __shfl_xor(cnt, o, 64);
-    npos += __shfl_xor(npos, o, 64);
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t c = red[0] + red[1] + red[2] + red[3];
-    if (c) atomicAdd(&acc[0], (unsigned long long)c);
-  }
-  if ((threadIdx.x & 63) == 0 && npos) atomicAdd(&acc[1], (unsigned long long)npos);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long total = auc_units(n);
-    if (atomicAdd(&acc[2], 1ULL) + 1 == total) {
-      const double area = (double)__hip_atomic_load(&acc[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      const double tp = (double)__hip_atomic_load(&acc[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      const double nn = (double)n;
-      double auc_n;
-      if (tp == 0.0 || tp == nn) {
-        auc_n = 1.0;  // :51 (the reference returns 1, not n)
-      } else {
-        const double a = area / (tp * (nn - tp));
-        auc_n = (a < 0.5 ? 1.0 - a : a) * nn;
-      }
-      *out_slot += auc_n;
-      acc[0] = 0;
-      acc[1] = 0;
-      acc[2] = 0;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
-                                                   unsigned long long* __restrict__ acc, double* __restrict__ out_slot) {
-  auc_pairs_block(pred, label, n, blockIdx.x, acc, out_slot);
 }
 
 // table export: one thread per hash slot

@@ -120,11 +120,11 @@ struct LocView {
 // long-segment lists for k_backward_all, one slot range per list bucket (dfh_internal.h: SegLists)
 struct SegListsOut {
   uint2* mid;  // [P] {cnt, off}
-  uint32_t* mid_ent;
+  SegEnt* mid_ent;
   uint2* hot;
-  uint32_t* hot_ent;
+  SegEnt* hot_ent;
   uint2* few;   // keys with 2 .. BWD_SMALL occurrences (k_update_fused)
-  uint32_t* few_ent;
+  SegEnt* few_ent;
 };
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
@@ -636,9 +636,10 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
         if (PROBE) urow[uid] = find_or_insert(tab, key);
         if (prev1) {  // closes segment uid - 1 = [prev1 - 1, i)
           const uint32_t len = i - (prev1 - 1);
-          if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid - 1;
-          else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid - 1;
-          else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = uid - 1;
+          const SegEnt e = make_uint4(uid - 1, prev1 - 1, i, 0u);
+          if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = e;
+          else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = e;
+          else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = e;
         }
       }
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
@@ -651,10 +652,11 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
       if (i == v.n - 1) {  // the end of the minibatch closes the last segment
         *d_U = uid + 1;
         col_ptr[uid + 1] = v.n;
-        const uint32_t len = v.n - (head ? i : prev1 - 1);
-        if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = uid;
-        else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = uid;
-        else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = uid;
+        const uint32_t lbeg = head ? i : prev1 - 1, len = v.n - lbeg;
+        const SegEnt e = make_uint4(uid, lbeg, v.n, 0u);
+        if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = e;
+        else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = e;
+        else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = e;
       }
       // the splitters of the next call: the exact P-quantiles of this sorted order
       if (P > 1) {

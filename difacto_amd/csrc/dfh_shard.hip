@@ -966,7 +966,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
                        W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo);
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo, AucFin{nullptr, 0u, nullptr});
     DFH_HIP(hipGetLastError());
   }
   // ---- K: the other keys (+ counts in epoch 0) to their owners.  Two message groups, one send and one receive
@@ -1148,7 +1148,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
                        (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr, b->d_col_ptr + cur.own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo);
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo, AucFin{nullptr, 0u, nullptr});
     DFH_HIP(hipGetLastError());
   }
   if (!cur.pulled) {  // pipeline fill: K, R, RW of this very minibatch, in the sync step's order (after L)

@@ -87,8 +87,7 @@ struct UpdArgs {
   // VALU work beside a memory-bound kernel), or nb_auc = 0
   const float* auc_pred;
   const float* auc_label;
-  unsigned long long* auc_acc;
-  double* auc_out;
+  uint32_t* auc_part;       // the units' slots (auc_pairs_block); finalised by a later launch (auc_finalize_block)
   uint32_t nb_auc;
 };
 
@@ -262,11 +261,12 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
   for (uint32_t lb = tm.first; lb < a.nlist; lb += tm.stride) {
     const uint2 co = a.seg.hot[lb];
     if (co.x == 0) continue;
-    const uint32_t* __restrict__ ent = a.seg.hot_ent + co.y;
+    const SegEnt* __restrict__ ent = a.seg.hot_ent + co.y;
     for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
-      const uint32_t u = ldu_s(ent + q);
+      const SegEnt e = ent[q];  // {u, beg, end}: the segment comes with the entry
+      const uint32_t u = e.x;
       if (!key_in(a.rg, u)) continue;  // uniform per block
-      const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
+      const uint32_t beg = e.y, end = e.z;
       const uint32_t rw = ld_rowword(a.uw + u);
       const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
@@ -312,11 +312,12 @@ __device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, ui
   for (uint32_t lb = tm.first; lb < a.nlist; lb += tm.stride) {
     const uint2 co = a.seg.mid[lb];
     if (co.x == 0) continue;
-    const uint32_t* __restrict__ ent = a.seg.mid_ent + co.y;
+    const SegEnt* __restrict__ ent = a.seg.mid_ent + co.y;
     for (uint32_t q = tm.sub; q < co.x; q += tm.size) {
-      const uint32_t u = ldu_s(ent + q);
+      const SegEnt e = ent[q];
+      const uint32_t u = e.x;
       if (!key_in(a.rg, u)) continue;  // uniform per wave
-      const uint32_t beg = ldu_s(a.col_ptr + u), end = ldu_s(a.col_ptr + u + 1);
+      const uint32_t beg = e.y, end = e.z;
       const uint32_t rw = ld_rowword(a.uw + u);
       const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, 0u, 1u, grp, sub, sub_ok, k, kp);
@@ -349,20 +350,22 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
     const uint2 co = a.seg.few[lb];
     const uint32_t n = co.x;
     if (n == 0) continue;
-    const uint32_t* __restrict__ ent = a.seg.few_ent + co.y;
+    const SegEnt* __restrict__ ent = a.seg.few_ent + co.y;
     for (uint32_t q0 = tm.sub * G; q0 < n; q0 += tm.size * G) {
-      // round trip 1: the key, its row word, its segment
+      // round trip 1: the entry {key rank, segment}
       const uint32_t q = q0 + grp;
-      const uint32_t u = ldu_s(ent + min(q, n - 1));
+      const SegEnt e = ent[min(q, n - 1)];
+      const uint32_t u = e.x;
       const bool act = q < n && key_in(a.rg, u);
-      const uint32_t rw = ld_rowword(a.uw + u);
-      const uint32_t beg = ldu_s(a.col_ptr + u);
-      const uint32_t len_all = ldu_s(a.col_ptr + u + 1) - beg;
+      const uint32_t beg = e.y;
+      const uint32_t len_all = e.z - beg;
       const uint32_t len = act ? len_all : 0u;
       const uint32_t last = beg + max(len_all, 1u) - 1u;
+      // round trip 2: the row word — and, with it, the first occurrences (the segment is known already)
+      const uint32_t rw = ld_rowword(a.uw + u);
       // a group without a key of its own (list exhausted, key of another rank) reads row 0 and drops it
       const uint32_t r = (act && (rw & kRemoteRow) == 0u) ? (rw & kRowMask) : 0u;
-      // round trip 2: the model row and the first occurrences, back to back
+      // round trip 3: the model row (beside the slopes and XV rows of the first occurrences)
       float4 h0, vv, ac;
       float fc;
       upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
@@ -485,8 +488,8 @@ __device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
 
 template <int L, bool EXACT, bool HAS_VAL>
 __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
-  if (blockIdx.x < a.nb_auc) {  // uniform per block
-    auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_acc, a.auc_out);
+  if (blockIdx.x < a.nb_auc) {  // uniform per block; nb_auc is auc_units(nrows) rounded up to 8 (see the XCD note below)
+    if (blockIdx.x < auc_units(a.nrows)) auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_part);
     return;
   }
   float pen = 0.f;
@@ -499,15 +502,20 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
   uint32_t bid = blockIdx.x - a.nb_auc;
   bool list_role = bid < nb_list;
   if (a.ileave > 1u) {
-    // groups of [one list block, R - 1 singles blocks] while both kinds last, then the rest: list blocks, singles blocks
-    const uint32_t R = a.ileave, P = min(nb_list, nb_single / (R - 1u));
-    if (bid < P * R) {
-      list_role = bid % R == 0u;
-      bid = list_role ? bid / R : bid - (bid / R + 1u);
+    // groups of [8 list blocks, 8 (R - 1) singles blocks] while both kinds last, then the rest: list blocks, singles blocks.
+    // In units of EIGHT because workgroups go round-robin over the 8 XCDs and the singles role wants its block b on the XCD
+    // that ran block b of the forward (the XV rows and slopes of examples 4b .. 4b + 3 are in THAT L2): singles block s
+    // must sit at a launch index congruent to s modulo 8 (round 3's interleave dealt single blocks and broke that).  Measured
+    // in round 4 with the alignment kept: 84.0 (R = 2) / 83.4 (R = 3) against 85.9 M examples/sec — list roles first stays.
+    const uint32_t R = a.ileave, G = 8u * R, P = min(nb_list / 8u, nb_single / (8u * (R - 1u)));
+    if (bid < P * G) {
+      const uint32_t g = bid / G, j = bid % G;
+      list_role = j < 8u;
+      bid = list_role ? g * 8u + j : g * 8u * (R - 1u) + (j - 8u);
     } else {
-      const uint32_t rem = bid - P * R;
-      list_role = rem < nb_list - P;
-      bid = list_role ? P + rem : P * (R - 1u) + (rem - (nb_list - P));
+      const uint32_t rem = bid - P * G, left = nb_list - P * 8u;
+      list_role = rem < left;
+      bid = list_role ? P * 8u + rem : P * 8u * (R - 1u) + (rem - left);
     }
   } else if (!list_role) {
     bid -= nb_list;

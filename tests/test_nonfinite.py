@@ -13,8 +13,9 @@ CPU: the C restatement against the reference itself (oracle/_ref) on such inputs
 (exchange layout) and the fused step (k_lookup + k_forward + k_update_fused on an imported model) against the
 restatement: the same finite / non-finite pattern, and rtol 1e-5 (+ floor) where finite.  The device does not
 distinguish +-Inf from NaN in a sum that is non-finite on both sides (padding lanes multiply by 0), and it has one
-documented deviation: a V coordinate that is exactly 0.0 inside an ALLOCATED row is skipped like the coordinates of a
-key without V (dfh_kernels.hip fma_skip0) — NaN in the reference, neutral here; not constructed below.
+documented deviation: four consecutive V coordinates (one lane's 16 B slice) that are all exactly 0.0 inside an
+ALLOCATED row are treated like a key without V (dfh_kernels.hip k_forward) — NaN in the reference,
+neutral here; not constructed below.
 """
 import numpy as np
 import pytest
