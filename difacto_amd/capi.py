@@ -30,7 +30,7 @@ SYMBOLS = [
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
-    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity",
+    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
 ]
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
 K_COUNT = 8
@@ -145,6 +145,7 @@ def lib():
     L.dfh_rowbuf_destroy.argtypes = [vp]
     L.dfh_rowbuf_load_host.argtypes = [vp, C.c_size_t, vp, vp, vp]
     L.dfh_batch_gather_rows.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.dfh_batch_prepare_rows.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.c_uint64]
     L.dfh_batch_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dfh_batch_key_ranges.argtypes = [vp, i32, vp]
     L.dfh_batch_key_ranges_device.argtypes = [vp, i32, vp, vp]
@@ -526,6 +527,17 @@ class Batch:
         ptrs = (C.c_void_p * n)(*[r.ctypes.data for r in rows])
         cnts = (C.c_size_t * n)(*[len(r) for r in rows])
         _ck(lib().dfh_batch_gather_rows(self.h, len(label), _p(offset), _p(label), n, bufs, ptrs, cnts))
+
+    def prepare_rows(self, table, offset, label, segments, max_index=2 ** 64 - 1):
+        """dfh_batch_prepare_rows: gather_rows + localize + lookup(table) as one preparation phase"""
+        offset = np.ascontiguousarray(offset, np.uint64)
+        label = np.ascontiguousarray(label, np.float32)
+        rows = [np.ascontiguousarray(r, np.uint32) for _, r in segments]
+        n = len(segments)
+        bufs = (C.c_void_p * n)(*[rb.h for rb, _ in segments])
+        ptrs = (C.c_void_p * n)(*[r.ctypes.data for r in rows])
+        cnts = (C.c_size_t * n)(*[len(r) for r in rows])
+        _ck(lib().dfh_batch_prepare_rows(table.h, self.h, len(label), _p(offset), _p(label), n, bufs, ptrs, cnts, max_index))
 
     def load_localized_host(self, offset, index, value, label, feaids, feacnt=None):
         offset = np.ascontiguousarray(offset, np.uint64)

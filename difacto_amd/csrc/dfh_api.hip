@@ -1,6 +1,7 @@
 // C ABI of libdifacto_hip (include/difacto_hip.h): handle management, host<->device
 // staging for the literal Store/Loss calls, and kernel orchestration.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -132,8 +133,12 @@ struct dfh_batch {
   float* o_label = nullptr;
   // pinned staging of dfh_batch_load_host (one block: offsets | labels | ids | values), allocated on first use
   char* h_stage = nullptr;
-  hipEvent_t ev_staged = nullptr;  // the copies out of h_stage have completed
+  hipEvent_t ev_staged = nullptr;  // the copies out of h_stage (or the kernels that read it in place) have completed
   bool staged_pending = false;
+  double t_prof[6] = {0, 0, 0, 0, 0, 0};  // DFH_PROFILE_PREP: host seconds inside dfh_batch_prepare_rows, by section
+  uint64_t n_prof = 0;
+  char* d_stage_view = nullptr;    // h_stage as the device sees it (dfh_batch_prepare_rows: the gather reads it in place)
+  bool defer_ready = false;        // inside a combined preparation call: the intermediate phases do not record ev_ready
   // localizer workspace
   uint64_t *d_keys = nullptr, *d_skeys = nullptr;   // bucket-major / sorted keys
   uint32_t *d_pos = nullptr, *d_spos = nullptr;     // row of every nnz position (d_pos) / sorted positions
@@ -205,7 +210,7 @@ int prep_begin(dfh_batch* b) {
 }
 int prep_end(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
-  if (c->pipeline) {
+  if (c->pipeline && !b->defer_ready) {
     DFH_HIP(hipEventRecord(b->ev_ready, prep_of(b)));
     b->ready_pending = true;
   }
@@ -1876,6 +1881,9 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
 }
 
 int dfh_batch_destroy(dfh_batch* b) {
+  if (b && b->n_prof)
+    fprintf(stderr, "dfh_batch_prepare_rows x %llu: begin %.4f s, wait staged %.4f, write description %.4f, gather %.4f, localize %.4f, lookup + ready %.4f\n",
+            (unsigned long long)b->n_prof, b->t_prof[0], b->t_prof[1], b->t_prof[2], b->t_prof[3], b->t_prof[4], b->t_prof[5]);
   if (!b) return DFH_OK;
   hipSetDevice(b->ctx->device);
   sync_all(b->ctx);
@@ -1923,7 +1931,8 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
     DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
   }
   if (b->staged_pending) {  // the previous minibatch staged here has long left; this wait is a formality
-    DFH_HIP(hipEventSynchronize(b->ev_staged));
+    // (a query first: hipEventSynchronize costs ~100 us of host time even on an event that completed long ago)
+    if (hipEventQuery(b->ev_staged) != hipSuccess) DFH_HIP(hipEventSynchronize(b->ev_staged));
     b->staged_pending = false;
   }
   memcpy(b->h_stage + o_off, off32.data(), (nrows + 1) * 4);
@@ -2011,6 +2020,9 @@ struct dfh_rowbuf {
   struct Used { hipStream_t stream; hipEvent_t ev; bool pending; };
   std::mutex mu;
   std::vector<Used> used;
+  std::vector<hipStream_t> seen_loaded;  // streams ordered behind the current upload already (one wait per stream and upload)
+  double t_prof[3] = {0, 0, 0};          // DFH_PROFILE_PREP: host seconds of dfh_rowbuf_load_host (offsets, queue, wait)
+  uint64_t n_prof = 0, bytes_prof = 0;
   std::vector<uint32_t> off32;
 };
 
@@ -2061,6 +2073,9 @@ int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** 
 
 int dfh_rowbuf_destroy(dfh_rowbuf* rb) {
   if (!rb) return DFH_OK;
+  if (rb->n_prof)
+    fprintf(stderr, "dfh_rowbuf_load_host x %llu (%.1f MB): offsets %.4f s, queue copies %.4f, wait %.4f\n", (unsigned long long)rb->n_prof,
+            rb->bytes_prof / 1e6, rb->t_prof[0], rb->t_prof[1], rb->t_prof[2]);
   hipSetDevice(rb->ctx->device);
   // the gathers out of this buffer, wherever they were queued (NOT sync_all: this may run beside the thread that drives
   // the context, and only this buffer's own consumers matter)
@@ -2093,20 +2108,95 @@ int dfh_rowbuf_load_host(dfh_rowbuf* rb, size_t nrows, const size_t* offset, con
       DFH_HIP(hipStreamWaitEvent(rb->up, u.ev, 0));
       u.pending = false;
     }
+    rb->seen_loaded.clear();
   }
+  static const bool prof = getenv("DFH_PROFILE_PREP") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp = prof ? now() : 0;
   rb->off32.resize(nrows + 1);
   for (size_t i = 0; i <= nrows; ++i) {
     DFH_ARG(offset[i] >= base && (i == 0 || offset[i] >= offset[i - 1]), "dfh_rowbuf_load_host: offsets must not decrease");
     rb->off32[i] = (uint32_t)(offset[i] - base);
   }
+  if (prof) { const double x = now(); rb->t_prof[0] += x - tp; tp = x; }
   DFH_HIP(hipMemcpyAsync(rb->d_off, rb->off32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, rb->up));
   if (nnz) DFH_HIP(hipMemcpyAsync(rb->d_idx, index + base, nnz * sizeof(uint64_t), hipMemcpyHostToDevice, rb->up));
   if (nnz && value) DFH_HIP(hipMemcpyAsync(rb->d_val, value + base, nnz * sizeof(float), hipMemcpyHostToDevice, rb->up));
   DFH_HIP(hipEventRecord(rb->ev_loaded, rb->up));
+  if (prof) { const double x = now(); rb->t_prof[1] += x - tp; tp = x; }
   DFH_HIP(hipStreamSynchronize(rb->up));   // the caller's arrays are free again
+  if (prof) { rb->t_prof[2] += now() - tp; ++rb->n_prof; rb->bytes_prof += nnz * (value ? 12 : 8) + nrows * 4; }
   rb->nrows = nrows;
   rb->nnz = nnz;
   rb->has_value = value != nullptr;
+  return DFH_OK;
+}
+
+namespace {
+__global__ void k_fill_f32(float* __restrict__ p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+}  // namespace
+
+// dfh_rowbuf_load_host for a buffer that was never assembled on the host: `offset` [nrows + 1] are the buffer's own
+// (cumulative) offsets, the ids / values arrive as `nslices` pieces that follow one another (slice g: nnz[g] ids at
+// index[g], values at value[g] or NULL = all ones).  One copy per piece, straight out of the caller's arrays.
+int dfh_rowbuf_load_host_slices(dfh_rowbuf* rb, size_t nrows, const size_t* offset, int nslices, const uint64_t* const* index,
+                                const float* const* value, const size_t* nnz_of) {
+  DFH_ARG(rb && offset && nrows >= 1 && nrows <= rb->max_rows, "dfh_rowbuf_load_host_slices: bad argument / more rows than the buffer holds");
+  DFH_ARG(nslices >= 0 && (nslices == 0 || (index && value && nnz_of)), "dfh_rowbuf_load_host_slices: NULL slice arrays");
+  const size_t base = offset[0], nnz = offset[nrows] - base;
+  DFH_ARG(nnz <= rb->max_nnz, "dfh_rowbuf_load_host_slices: more nonzeros than the buffer holds");
+  size_t total = 0;
+  bool any_value = false;
+  for (int g = 0; g < nslices; ++g) {
+    DFH_ARG(nnz_of[g] == 0 || index[g], "dfh_rowbuf_load_host_slices: a slice without ids");
+    total += nnz_of[g];
+    any_value = any_value || (nnz_of[g] && value[g]);
+  }
+  DFH_ARG(total == nnz, "dfh_rowbuf_load_host_slices: the slices must hold the buffer's nonzeros");
+  DFH_HIP(hipSetDevice(rb->ctx->device));
+  {
+    std::lock_guard<std::mutex> lk(rb->mu);
+    for (auto& u : rb->used) {
+      if (!u.pending) continue;
+      DFH_HIP(hipStreamWaitEvent(rb->up, u.ev, 0));
+      u.pending = false;
+    }
+    rb->seen_loaded.clear();
+  }
+  static const bool prof = getenv("DFH_PROFILE_PREP") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp = prof ? now() : 0;
+  rb->off32.resize(nrows + 1);
+  for (size_t i = 0; i <= nrows; ++i) {
+    DFH_ARG(offset[i] >= base && (i == 0 || offset[i] >= offset[i - 1]), "dfh_rowbuf_load_host_slices: offsets must not decrease");
+    rb->off32[i] = (uint32_t)(offset[i] - base);
+  }
+  if (prof) { const double x = now(); rb->t_prof[0] += x - tp; tp = x; }
+  DFH_HIP(hipMemcpyAsync(rb->d_off, rb->off32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, rb->up));
+  size_t at = 0;
+  for (int g = 0; g < nslices; ++g) {
+    const size_t n = nnz_of[g];
+    if (!n) continue;
+    DFH_HIP(hipMemcpyAsync(rb->d_idx + at, index[g], n * sizeof(uint64_t), hipMemcpyHostToDevice, rb->up));
+    if (any_value) {
+      if (value[g]) {
+        DFH_HIP(hipMemcpyAsync(rb->d_val + at, value[g], n * sizeof(float), hipMemcpyHostToDevice, rb->up));
+      } else {  // a block without a value array beside blocks with one: ones (compressed_row_block.h:36-44)
+        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, rb->up, rb->d_val + at, n, 1.0f);
+      }
+    }
+    at += n;
+  }
+  DFH_HIP(hipGetLastError());
+  DFH_HIP(hipEventRecord(rb->ev_loaded, rb->up));
+  if (prof) { const double x = now(); rb->t_prof[1] += x - tp; tp = x; }
+  DFH_HIP(hipStreamSynchronize(rb->up));   // the caller's arrays are free again
+  if (prof) { rb->t_prof[2] += now() - tp; ++rb->n_prof; rb->bytes_prof += nnz * (any_value ? 12 : 8) + nrows * 4; }
+  rb->nrows = nrows;
+  rb->nnz = nnz;
+  rb->has_value = any_value;
   return DFH_OK;
 }
 
@@ -2141,7 +2231,8 @@ int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, cons
     DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
   }
   if (b->staged_pending) {
-    DFH_HIP(hipEventSynchronize(b->ev_staged));
+    // (a query first: hipEventSynchronize costs ~100 us of host time even on an event that completed long ago)
+    if (hipEventQuery(b->ev_staged) != hipSuccess) DFH_HIP(hipEventSynchronize(b->ev_staged));
     b->staged_pending = false;
   }
   memcpy(b->h_stage + o_off, off32.data(), (nrows + 1) * 4);
@@ -2323,6 +2414,174 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   return prep_end(b);
 }
 }  // namespace
+
+namespace {
+// dfh_batch_prepare_rows: the description of the minibatch (row numbers, offsets, labels) is read where the host wrote it —
+// page-locked host memory mapped into the device's address space — 256 rows per block, coalesced, and passed on: the
+// minibatch's own offsets / labels land in HBM by the same kernel that gathers its rows, no copy is queued.
+__global__ void __launch_bounds__(256) k_gather_rows_staged(const uint32_t* __restrict__ src_off, const uint64_t* __restrict__ src_idx,
+                                                            const float* __restrict__ src_val, const uint32_t* __restrict__ h_rows,
+                                                            const uint32_t* __restrict__ h_off, const float* __restrict__ h_lab, uint32_t n,
+                                                            uint32_t* __restrict__ dst_off, float* __restrict__ dst_lab,
+                                                            uint64_t* __restrict__ dst_idx, float* __restrict__ dst_val, int write_end) {
+  // GR rows per block and pass: few enough that a minibatch spreads over the whole chip (10 000 rows = 313 blocks; 256
+  // rows per block left 216 of the 256 CUs idle and took 92 us), enough that the description is read in 128 B pieces
+  constexpr uint32_t GR = 32;
+  __shared__ uint32_t s_lo[GR], s_len[GR], s_d0[GR];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  for (uint32_t q0 = blockIdx.x * GR; q0 < n; q0 += gridDim.x * GR) {
+    const uint32_t m = min(GR, n - q0);
+    __syncthreads();
+    if (threadIdx.x < m) {
+      const uint32_t q = q0 + threadIdx.x;
+      const uint32_t r = h_rows[q], o = h_off[q];
+      const uint32_t lo = src_off[r];
+      s_lo[threadIdx.x] = lo;
+      s_len[threadIdx.x] = src_off[r + 1] - lo;
+      s_d0[threadIdx.x] = o;
+      dst_off[q] = o;
+      dst_lab[q] = h_lab[q];
+    }
+    if (threadIdx.x == 255 && write_end && q0 + m == n) dst_off[n] = h_off[n];
+    __syncthreads();
+    for (uint32_t t = w; t < m; t += 4u) {   // 8 rows per wave, independent addresses: the copies overlap
+      const uint32_t lo = s_lo[t], len = s_len[t], d0 = s_d0[t];
+      for (uint32_t j = lane; j < len; j += 64u) {
+        dst_idx[d0 + j] = src_idx[lo + j];
+        if (dst_val) dst_val[d0 + j] = src_val ? src_val[lo + j] : 1.0f;   // a buffer without values holds ones
+      }
+    }
+  }
+}
+}  // namespace
+
+int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg,
+                           dfh_rowbuf* const* bufs, const uint32_t* const* rows, const size_t* seg_rows, uint64_t max_index) {
+  DFH_ARG(t && b && t->ctx == b->ctx && offset && label && nseg >= 1 && bufs && rows && seg_rows, "dfh_batch_prepare_rows: NULL argument");
+  DFH_ARG(nrows >= 1 && nrows <= b->max_rows, "dfh_batch_prepare_rows: nrows out of range");
+  DFH_ARG(max_index != 0, "max_index must be nonzero");
+  const size_t base = offset[0], nnz = offset[nrows] - base;
+  DFH_ARG(nnz <= b->max_nnz && nnz < 0xFFFFFFFFULL, "dfh_batch_prepare_rows: nnz exceeds max_nnz");
+  size_t total = 0;
+  bool any_value = false;
+  for (int g = 0; g < nseg; ++g) {
+    DFH_ARG(bufs[g] && bufs[g]->ctx == b->ctx && (seg_rows[g] == 0 || rows[g]), "dfh_batch_prepare_rows: bad segment");
+    total += seg_rows[g];
+    any_value = any_value || bufs[g]->has_value;
+  }
+  DFH_ARG(total == nrows, "dfh_batch_prepare_rows: the segments must hold nrows rows");
+  dfh_ctx* c = b->ctx;
+  static const bool prof = getenv("DFH_PROFILE_PREP") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp = prof ? now() : 0;
+  auto lap = [&](int k) { if (prof) { const double x = now(); b->t_prof[k] += x - tp; tp = x; } };
+  DFH_HIP(hipSetDevice(c->device));
+  if (nnz) {
+    int rcr = table_reserve(t, nnz);  // U <= nnz keys may be new; before anything of this phase is queued
+    if (rcr) return rcr;
+  }
+  phase_begin(b);
+  int rc = prep_begin(b);
+  if (rc) return rc;
+  hipStream_t s = prep_of(b);
+  b->d_raw = b->o_raw; b->d_offset = b->o_offset; b->d_value = b->o_value; b->d_label = b->o_label;
+  // the same page-locked block as dfh_batch_load_host / dfh_batch_gather_rows: offsets | labels | (ids ->) row numbers
+  const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
+               o_val = o_idx + b->max_nnz * 8, stage_total = o_val + b->max_nnz * 4;
+  if (!b->h_stage) {
+    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), stage_total, hipHostMallocDefault));
+    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
+  }
+  if (!b->d_stage_view) DFH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_stage_view), b->h_stage, 0));
+  lap(0);  // set-up, prep_begin (wait for the batch object's previous step)
+  if (b->staged_pending) {
+    // (a query first: hipEventSynchronize costs ~100 us of host time even on an event that completed long ago)
+    if (hipEventQuery(b->ev_staged) != hipSuccess) DFH_HIP(hipEventSynchronize(b->ev_staged));
+    b->staged_pending = false;
+  }
+  lap(1);  // the previous description has been read
+  uint32_t* h_off = reinterpret_cast<uint32_t*>(b->h_stage + o_off);
+  for (size_t i = 0; i <= nrows; ++i) {
+    DFH_ARG(offset[i] >= base && (i == 0 || offset[i] >= offset[i - 1]), "dfh_batch_prepare_rows: offsets must not decrease");
+    h_off[i] = (uint32_t)(offset[i] - base);
+  }
+  memcpy(b->h_stage + o_lab, label, nrows * 4);
+  uint32_t* h_rows = reinterpret_cast<uint32_t*>(b->h_stage + o_idx);
+  size_t at = 0;
+  for (int g = 0; g < nseg; ++g) {
+    const uint32_t lim = (uint32_t)bufs[g]->nrows;
+    const uint32_t* src = rows[g];
+    uint32_t worst = 0;
+    for (size_t i = 0; i < seg_rows[g]; ++i) {
+      h_rows[at + i] = src[i];
+      worst = std::max(worst, src[i]);
+    }
+    DFH_ARG(seg_rows[g] == 0 || worst < lim, "dfh_batch_prepare_rows: row number beyond the buffer");
+    at += seg_rows[g];
+  }
+  lap(2);  // description written
+  const uint32_t* v_off = reinterpret_cast<const uint32_t*>(b->d_stage_view + o_off);
+  const float* v_lab = reinterpret_cast<const float*>(b->d_stage_view + o_lab);
+  const uint32_t* v_rows = reinterpret_cast<const uint32_t*>(b->d_stage_view + o_idx);
+  at = 0;
+  for (int g = 0; g < nseg; ++g) {
+    dfh_rowbuf* rb = bufs[g];
+    if (seg_rows[g] == 0) continue;
+    bool waited;
+    {
+      std::lock_guard<std::mutex> lk(rb->mu);
+      waited = std::find(rb->seen_loaded.begin(), rb->seen_loaded.end(), s) != rb->seen_loaded.end();
+      if (!waited) rb->seen_loaded.push_back(s);
+    }
+    if (!waited) DFH_HIP(hipStreamWaitEvent(s, rb->ev_loaded, 0));
+    const unsigned blocks = (unsigned)std::min<size_t>((seg_rows[g] + 31) / 32, 2048);
+    hipLaunchKernelGGL(k_gather_rows_staged, dim3(blocks), dim3(256), 0, s, rb->d_off, rb->d_idx,
+                       rb->has_value ? rb->d_val : (const float*)nullptr, v_rows + at, v_off + at, v_lab + at, (uint32_t)seg_rows[g],
+                       b->d_offset + at, b->d_label + at, b->d_raw, any_value ? b->d_value : (float*)nullptr,
+                       at + seg_rows[g] == nrows ? 1 : 0);
+    {
+      std::lock_guard<std::mutex> lk(rb->mu);
+      dfh_rowbuf::Used* u = nullptr;
+      for (auto& x : rb->used)
+        if (x.stream == s) u = &x;
+      if (!u) {
+        hipEvent_t ev = nullptr;
+        DFH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        rb->used.push_back({s, ev, false});
+        u = &rb->used.back();
+      }
+      DFH_HIP(hipEventRecord(u->ev, s));
+      u->pending = true;
+    }
+    at += seg_rows[g];
+  }
+  DFH_HIP(hipEventRecord(b->ev_staged, s));   // the page-locked block may be rewritten once the gathers have read it
+  b->staged_pending = true;
+  DFH_HIP(hipGetLastError());
+  b->nrows = nrows;
+  b->nnz = nnz;
+  b->has_value = any_value;
+  b->has_cnt = false;
+  b->localized = false;
+  b->looked_up = nullptr;
+  lap(3);  // gather queued
+  // Localizer::Compact + the key-index probe, same phase: ONE ev_ready at the end
+  b->defer_ready = true;
+  rc = localize_impl(b, max_index, nullptr);
+  lap(4);  // Localizer queued
+  if (!rc && nnz) {
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+                       (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
+    if (hipGetLastError() != hipSuccess) rc = DFH_ERR_HIP;
+    b->looked_up = t;
+  }
+  b->defer_ready = false;
+  if (rc) return rc;
+  rc = prep_end(b);
+  lap(5);  // lookup queued, ev_ready recorded
+  ++b->n_prof;
+  return rc;
+}
 
 int dfh_localize(dfh_batch* b, uint64_t max_index) {
   DFH_ARG(b && b->nrows > 0, "dfh_localize: no batch loaded");

@@ -402,7 +402,9 @@ class Reader {
     }
     if (nthreads <= 0) {
       // DIFACTO_PARSER_THREADS, else an eighth of the hardware threads (several readers may be alive: one per
-      // rank of a node, a training and a validation reader), at least 1, at most 16
+      // rank of a node, a training and a validation reader), at least 1, at most 16 (round 4, 256-thread host:
+      // 32 / 48 threads parse SLOWER — 9 / 16 s of summed parsing time against 6.4 s for the same criteo text — and the
+      // end-to-end rate drops with them)
       const char* e = getenv("DIFACTO_PARSER_THREADS");
       nthreads = e ? atoi(e) : static_cast<int>(std::thread::hardware_concurrency() / 8);
       nthreads = std::max(1, std::min(nthreads, 16));
@@ -443,8 +445,39 @@ class Reader {
     }
   }
   const dmlc::RowBlock<feaid_t>& Value() const { return blk_; }
+  /*! \brief Next(), but the chunk is handed over for keeps (slices of it may outlive the next call) */
+  bool NextShared(std::shared_ptr<RowChunk>* out) {
+    if (!Next()) return false;
+    // the container comes out of a pool and goes back to it when the last slice lets go: the parser threads keep
+    // writing into the same few dozen allocations (warm pages, which also is what the runtime's pageable uploads like:
+    // out of freshly allocated chunks they ran ten times slower)
+    std::shared_ptr<ChunkPool> pool = pool_;
+    RowChunk* raw = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(pool->mu);
+      if (!pool->spare.empty()) {
+        raw = pool->spare.back().release();
+        pool->spare.pop_back();
+      }
+    }
+    if (!raw) raw = new RowChunk();
+    raw->Clear();
+    std::shared_ptr<RowChunk> c(raw, [pool](RowChunk* p) {
+      std::lock_guard<std::mutex> lk(pool->mu);
+      pool->spare.emplace_back(p);
+    });
+    std::swap(*c, cur_);   // cur_ (and through it a parser's slot) gets the recycled storage
+    blk_ = c->GetBlock();
+    *out = std::move(c);
+    return true;
+  }
 
  private:
+  struct ChunkPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<RowChunk>> spare;
+  };
+  std::shared_ptr<ChunkPool> pool_ = std::make_shared<ChunkPool>();
   enum State { kFree, kBusy, kParsed };
   struct Slot {
     State state = kFree;
@@ -502,6 +535,17 @@ struct RowSeg {
   std::vector<unsigned> rows;
 };
 
+/*! \brief rows [row0, row0 + nrows) of a parsed chunk that stays alive as long as somebody names it: how a shuffle buffer is
+ * handed to the device feed WITHOUT being assembled on the host (round 4: the 31 MB copy per buffer was what the worker
+ * loop waited for) — the buffer's offsets and labels are assembled, its ids / values are uploaded slice by slice */
+struct BufSlice {
+  std::shared_ptr<RowChunk> chunk;
+  size_t row0, nrows;
+  const feaid_t* index() const { return chunk->index.data() + chunk->offset[row0]; }
+  const real_t* value() const { return chunk->value.empty() ? nullptr : chunk->value.data() + chunk->offset[row0]; }
+  size_t nnz() const { return chunk->offset[row0 + nrows] - chunk->offset[row0]; }
+};
+
 /*! \brief view of a row container; a described minibatch has offsets and labels but no index / value arrays */
 inline dmlc::RowBlock<feaid_t> ViewOf(const RowChunk& c) {
   if (!c.index.empty() || c.offset.back() == 0) return c.GetBlock();
@@ -525,6 +569,12 @@ class BatchSource {
     return none;
   }
   virtual void MoveAux(std::vector<RowSeg>* dst) { dst->clear(); }
+  /*! \brief the slices Value() is made of when the source keeps its blocks as slices of parsed chunks (else empty) */
+  virtual const std::vector<BufSlice>& Slices() const {
+    static const std::vector<BufSlice> none;
+    return none;
+  }
+  virtual void MoveSlices(std::vector<BufSlice>* dst) { dst->clear(); }
   /*! \brief next block; false when exhausted.  Value() stays valid until the next call */
   virtual bool Next() = 0;
   virtual const dmlc::RowBlock<feaid_t>& Value() const = 0;
@@ -563,12 +613,14 @@ class PrefetchSource : public BatchSource {
     if (!s.full) return false;
     blk_ = ViewOf(s.rows);
     aux_ = &s.aux;
+    slices_ = &s.slices;
     ++tail_;
     held_ = true;
     return blk_.size > 0;
   }
   const dmlc::RowBlock<feaid_t>& Value() const override { return blk_; }
   const std::vector<RowSeg>& Aux() const override { return aux_ ? *aux_ : BatchSource::Aux(); }
+  const std::vector<BufSlice>& Slices() const override { return slices_ ? *slices_ : BatchSource::Slices(); }
   void MoveAux(std::vector<RowSeg>* dst) override {
     std::lock_guard<std::mutex> lk(mu_);
     CHECK(held_);
@@ -586,6 +638,7 @@ class PrefetchSource : public BatchSource {
     bool full = false;
     RowChunk rows;
     std::vector<RowSeg> aux;
+    std::vector<BufSlice> slices;
   };
   void Work() {
     for (;;) {
@@ -599,6 +652,7 @@ class PrefetchSource : public BatchSource {
       const bool ok = inner_->Next();  // outside the lock: this is the work being overlapped
       if (ok) {
         inner_->MoveAux(&s->aux);   // before MoveOut: a source may reset its description there
+        inner_->MoveSlices(&s->slices);
         inner_->MoveOut(&s->rows);
       }
       {
@@ -623,6 +677,7 @@ class PrefetchSource : public BatchSource {
   bool held_ = false, done_ = false, stop_ = false;
   dmlc::RowBlock<feaid_t> blk_;
   const std::vector<RowSeg>* aux_ = nullptr;
+  const std::vector<BufSlice>* slices_ = nullptr;
 };
 
 /**
@@ -683,15 +738,30 @@ class RefRand {
 
 class BatchReader : public BatchSource {
  public:
+  /*! \brief slice_buffers (readers with a shuffle buffer whose minibatches will be DESCRIBED, see DescribeSlices): the
+   *  buffers are not assembled on the host — offsets and labels only, the ids / values stay in the parsed chunks */
+  typedef std::function<void(const dmlc::RowBlock<feaid_t>& buffer, const std::vector<BufSlice>& slices, uint64_t serial)> SliceFn;
+  /*! \brief slice_buffers (readers with a shuffle buffer whose minibatches will be DESCRIBED): the buffers are not
+   *  assembled on the host — offsets and labels only, the ids / values stay in the parsed chunks.  `on_built`, if given, is
+   *  called for every buffer (serial 1, 2, ..) on the thread that builds the buffers, as soon as the buffer exists — one
+   *  buffer AHEAD of the one being cut into minibatches: where the device feed starts its upload, so that the copy
+   *  is over when the first minibatch of the buffer wants its rows */
   BatchReader(const std::string& uri, const std::string& format, unsigned part_index, unsigned num_parts, unsigned batch_size,
-              unsigned shuffle_buf_size = 0, float neg_sampling = 1.0f)
+              unsigned shuffle_buf_size = 0, float neg_sampling = 1.0f, bool slice_buffers = false, SliceFn on_built = nullptr)
       : batch_size_(batch_size), shuf_buf_(shuffle_buf_size), neg_sampling_(neg_sampling) {
     CHECK_GT(batch_size, 0u);
     if (shuf_buf_) {
       CHECK_GE(shuf_buf_, batch_size_);
       // the next shuffle buffer is assembled (on its own thread) while this one is being cut into minibatches
-      buf_reader_.reset(new PrefetchSource(new BatchReader(uri, format, part_index, num_parts, shuf_buf_), 1));
+      BatchReader* inner = new BatchReader(uri, format, part_index, num_parts, shuf_buf_);
+      inner->keep_slices_ = slice_buffers;
+      inner->on_built_ = on_built;
+      sliced_ = slice_buffers;
+      uploaded_early_ = on_built != nullptr;
+      // (sliced buffers are offsets + labels only: two ahead, so that their uploads have a lead)
+      buf_reader_.reset(new PrefetchSource(inner, slice_buffers ? 2 : 1));
     } else {
+      CHECK(!slice_buffers) << "slice_buffers needs a shuffle buffer";
       reader_.reset(new Reader(uri, format, part_index, num_parts, 1 << 24));
     }
   }
@@ -703,10 +773,30 @@ class BatchReader : public BatchSource {
    * gathered wherever the buffers were put (the device: sgd_learner.cc's device feed).
    */
   typedef std::function<void(const dmlc::RowBlock<feaid_t>& buffer, uint64_t serial)> BufferFn;
-  void Describe(BufferFn on_buffer) {
+  /*! \brief `before_release` (optional) is called before the storage of the buffer last handed to on_buffer is given up
+   *  (the next buffer is about to be fetched, or the reader ends): an on_buffer that keeps reading the arrays after it
+   *  returns — an upload running beside the description of the buffer's minibatches — finishes there */
+  void Describe(BufferFn on_buffer, std::function<void()> before_release = nullptr) {
     CHECK(shuf_buf_) << "only a reader with a shuffle buffer can describe its minibatches";
+    CHECK(!sliced_) << "a reader built with slice_buffers hands its buffers out through DescribeSlices";
     describe_ = true;
     on_buffer_ = on_buffer;
+    before_release_ = before_release;
+  }
+  /*! \brief Describe for a reader built with slice_buffers: `buffer` carries size / offset / label (index and value are
+   *  NULL), `slices` the parsed chunks its rows live in, in order.  on_buffer may be empty when the reader was built with
+   *  on_built (the buffers were handed out as they were built) */
+  void DescribeSlices(SliceFn on_buffer, std::function<void()> before_release = nullptr) {
+    CHECK(shuf_buf_ && sliced_) << "DescribeSlices needs a reader built with a shuffle buffer and slice_buffers";
+    CHECK(on_buffer || uploaded_early_) << "nobody takes the buffers";
+    describe_ = true;
+    on_slices_ = on_buffer;
+    before_release_ = before_release;
+  }
+  const std::vector<BufSlice>& Slices() const override { return slices_; }
+  void MoveSlices(std::vector<BufSlice>* dst) override {
+    std::swap(slices_, *dst);
+    slices_.clear();
   }
   const std::vector<RowSeg>& Aux() const override { return segs_; }
   void MoveAux(std::vector<RowSeg>* dst) override {
@@ -716,6 +806,7 @@ class BatchReader : public BatchSource {
 
   /*! \brief next minibatch; false when the part is exhausted (batch_reader.cc:32-77) */
   ~BatchReader() override {
+    if (before_release_) before_release_();
     if (getenv("DIFACTO_PROFILE") && (t_fill_ + t_shuf_ + t_sel_ + t_app_) > 0)
       LOG(INFO) << "batch reader (" << batch_size_ << " rows, shuffle buffer " << shuf_buf_ << "): next chunk / buffer " << t_fill_
                 << " s, permutation " << t_shuf_ << " s, row selection " << t_sel_ << " s, row gather " << t_app_ << " s";
@@ -723,11 +814,12 @@ class BatchReader : public BatchSource {
   bool Next() override {
     batch_.Clear();
     segs_.clear();
+    slices_.clear();
     view_ = false;
     // a whole minibatch inside the current chunk, rows taken as they come: hand out a view of the chunk's
     // arrays instead of copying 39 ids per row (dmlc's RowBlock convention: offset holds absolute positions
     // into index / value).  Valid until the next call, like the copy.
-    if (shuf_buf_ == 0 && neg_sampling_ == 1.0f && end_ - start_ >= batch_size_) {
+    if (shuf_buf_ == 0 && neg_sampling_ == 1.0f && !keep_slices_ && end_ - start_ >= batch_size_) {
       out_blk_.size = batch_size_;
       out_blk_.offset = in_blk_.offset + start_;
       out_blk_.label = in_blk_.label + start_;
@@ -748,14 +840,23 @@ class BatchReader : public BatchSource {
       if (start_ == end_) {
         const double f0 = Now();
         if (shuf_buf_ == 0) {
-          if (!reader_->Next()) break;
+          if (keep_slices_) {
+            if (!reader_->NextShared(&cur_chunk_)) break;
+          } else if (!reader_->Next()) {
+            break;
+          }
           in_blk_ = reader_->Value();
           t_fill_ += Now() - f0;
         } else {
+          if (before_release_) before_release_();
           if (!buf_reader_->Next()) break;
           in_blk_ = buf_reader_->Value();
           ++buf_serial_;
-          if (describe_) on_buffer_(in_blk_, buf_serial_);
+          if (describe_ && sliced_) {
+            if (on_slices_) on_slices_(in_blk_, buf_reader_->Slices(), buf_serial_);
+          } else if (describe_) {
+            on_buffer_(in_blk_, buf_serial_);
+          }
           const double f1 = Now();
           t_fill_ += f1 - f0;
           if (rdp_.size() != in_blk_.size) {
@@ -797,6 +898,7 @@ class BatchReader : public BatchSource {
       if (f != 1) { binary = false; break; }
     if (binary) batch_.value.clear();
     out_blk_ = ViewOf(batch_);
+    if (on_built_ && out_blk_.size > 0) on_built_(out_blk_, slices_, ++built_serial_);
     return out_blk_.size > 0;
   }
   const dmlc::RowBlock<feaid_t>& Value() const override { return out_blk_; }
@@ -817,6 +919,15 @@ class BatchReader : public BatchSource {
   void Push(size_t pos, size_t len) {  // batch_reader.cc:80-96
     if (!len) return;
     CHECK_LE(pos + len, in_blk_.size);
+    if (keep_slices_) {  // offsets and labels only; the ids / values stay where the parser put them
+      const size_t r0 = batch_.label.size();
+      batch_.label.insert(batch_.label.end(), in_blk_.label + pos, in_blk_.label + pos + len);
+      batch_.offset.resize(r0 + 1 + len);
+      const size_t shift = batch_.offset[r0], o0 = in_blk_.offset[pos];
+      for (size_t i = 0; i < len; ++i) batch_.offset[r0 + 1 + i] = shift + (in_blk_.offset[pos + 1 + i] - o0);
+      slices_.push_back(BufSlice{cur_chunk_, pos, len});
+      return;
+    }
     dmlc::RowBlock<feaid_t> slice;
     slice.weight = nullptr;
     slice.size = len;
@@ -913,6 +1024,15 @@ class BatchReader : public BatchSource {
   bool view_ = false;  // Value() points into the current chunk, not into batch_
   bool describe_ = false;
   BufferFn on_buffer_;
+  SliceFn on_slices_;
+  std::function<void()> before_release_;
+  SliceFn on_built_;           // (buffer-building reader) called for every block it builds
+  uint64_t built_serial_ = 0;
+  bool uploaded_early_ = false;
+  bool keep_slices_ = false;   // this reader (the one that builds shuffle buffers) keeps its blocks as slices of chunks
+  bool sliced_ = false;        // this reader's shuffle buffers arrive as slices
+  std::shared_ptr<RowChunk> cur_chunk_;
+  std::vector<BufSlice> slices_;
   uint64_t buf_serial_ = 0;
   std::vector<RowSeg> segs_;
   size_t start_ = 0, end_ = 0;

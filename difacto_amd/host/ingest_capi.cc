@@ -34,11 +34,35 @@ long ingest_read(const char* uri, const char* format, unsigned part, unsigned np
   const char* pf = getenv("DIFACTO_INGEST_PREFETCH");
   // DIFACTO_INGEST_DESCRIBE = 1 (with a shuffle buffer): the reader describes its minibatches (BatchReader::Describe) and the
   // rows are gathered here from copies of the buffers it announced — what the device feed does in HBM
-  const bool describe = getenv("DIFACTO_INGEST_DESCRIBE") && atoi(getenv("DIFACTO_INGEST_DESCRIBE")) > 0 && shuffle > 0;
+  const int describe_mode = getenv("DIFACTO_INGEST_DESCRIBE") && shuffle > 0 ? atoi(getenv("DIFACTO_INGEST_DESCRIBE")) : 0;
+  const bool describe = describe_mode > 0;
+  const bool sliced = describe_mode == 2;   // 2: the buffers arrive as slices of the parsed chunks (never assembled on the host)
   std::mutex bmu;
   std::map<uint64_t, RowChunk> buffers;
-  std::unique_ptr<BatchReader> br(new BatchReader(uri, format, part, nparts, batch_size, shuffle, neg_sampling));
-  if (describe)
+  std::unique_ptr<BatchReader> br(new BatchReader(uri, format, part, nparts, batch_size, shuffle, neg_sampling, sliced));
+  if (describe && sliced)
+    br->DescribeSlices([&](const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {
+      std::lock_guard<std::mutex> lk(bmu);
+      RowChunk& c = buffers[serial];
+      c.Clear();
+      // what the device feed does with one copy per slice: the buffer's own offsets / labels + the slices' ids / values in order
+      c.offset.assign(blk.offset, blk.offset + blk.size + 1);
+      for (auto& o : c.offset) o -= blk.offset[0];
+      c.label.assign(blk.label, blk.label + blk.size);
+      bool any_value = false;
+      for (const BufSlice& sl : slices) any_value = any_value || sl.value() != nullptr;
+      size_t rows = 0;
+      for (const BufSlice& sl : slices) {
+        c.index.insert(c.index.end(), sl.index(), sl.index() + sl.nnz());
+        if (any_value) {
+          if (sl.value()) c.value.insert(c.value.end(), sl.value(), sl.value() + sl.nnz());
+          else c.value.resize(c.index.size(), 1.0f);
+        }
+        rows += sl.nrows;
+      }
+      if (rows != blk.size || c.index.size() != c.offset.back()) c.Clear();   // caught below as a mismatch
+    });
+  else if (describe)
     br->Describe([&](const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) {
       std::lock_guard<std::mutex> lk(bmu);
       RowChunk& c = buffers[serial];

@@ -2,7 +2,10 @@
  * sgd_learner.cc — see sgd_learner.h.  Reference: src/sgd/sgd_learner.cc.
  */
 #include "./sgd_learner.h"
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -215,35 +218,92 @@ namespace {
 struct DeviceFeed {
   dfh_ctx* ctx = nullptr;
   std::mutex mu;
+  std::condition_variable cv;
   std::map<uint64_t, dfh_rowbuf*> live;        // serial -> uploaded buffer
   std::vector<dfh_rowbuf*> spare, all;         // handed back / every buffer ever created
   std::map<dfh_rowbuf*, std::pair<size_t, size_t>> cap;
-  void Upload(const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) {   // on the reader's thread
-    const size_t nnz = blk.offset[blk.size] - blk.offset[0];
+  // A buffer's upload is queued by the thread that builds it, as soon as it exists — one buffer ahead of the one being cut
+  // into minibatches (BatchReader's on_built) — and carried out by a few upload threads, each on the stream of the row
+  // buffer it fills (one pageable copy per slice: ~1.4 ms per 31 MB buffer on one thread, more than the device needs for
+  // the buffer's ten minibatches)
+  struct Job {
+    std::vector<size_t> offset;     // the buffer's own offsets (copied: the builder's container moves on)
+    std::vector<BufSlice> slices;   // shared ownership of the parsed chunks
+    uint64_t serial;
+  };
+  std::deque<Job> jobs;
+  std::vector<std::thread> workers;
+  bool stop = false;
+  void Start() {
+    const char* e = getenv("DIFACTO_UPLOAD_THREADS");
+    const int n = std::max(1, std::min(e ? atoi(e) : 2, 8));
+    for (int t = 0; t < n; ++t) workers.emplace_back([this] { Work(); });
+  }
+  void Upload(const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {   // builder's thread
+    Job j;
+    j.offset.assign(blk.offset, blk.offset + blk.size + 1);
+    j.slices = slices;
+    j.serial = serial;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      jobs.push_back(std::move(j));
+    }
+    cv.notify_all();
+  }
+  void Work() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !jobs.empty(); });
+        if (jobs.empty()) return;
+        j = std::move(jobs.front());
+        jobs.pop_front();
+      }
+      DoUpload(j);
+    }
+  }
+  void DoUpload(const Job& j) {
+    const std::vector<BufSlice>& slices = j.slices;
+    const uint64_t serial = j.serial;
+    const size_t nrows = j.offset.size() - 1;
+    const size_t nnz = j.offset[nrows] - j.offset[0];
     dfh_rowbuf* rb = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu);
       for (size_t i = 0; i < spare.size() && !rb; ++i) {
         const auto& c = cap[spare[i]];
-        if (c.first >= blk.size && c.second >= nnz) {
+        if (c.first >= nrows && c.second >= nnz) {
           rb = spare[i];
           spare.erase(spare.begin() + i);
         }
       }
     }
     if (!rb) {   // none fits: a new one (too small ones stay spare and are freed with the feed)
-      const size_t rows = std::max<size_t>(blk.size, 1), nz = std::max<size_t>(nnz + nnz / 4, 1);
+      const size_t rows = std::max<size_t>(nrows, 1), nz = std::max<size_t>(nnz + nnz / 4, 1);
       DFH_CALL(dfh_rowbuf_create(ctx, rows, nz, &rb));
       std::lock_guard<std::mutex> lk(mu);
       all.push_back(rb);
       cap[rb] = {rows, nz};
     }
-    DFH_CALL(dfh_rowbuf_load_host(rb, blk.size, blk.offset, blk.index, blk.value));
-    std::lock_guard<std::mutex> lk(mu);
-    CHECK(live.emplace(serial, rb).second) << "shuffle buffer " << serial << " uploaded twice";
+    std::vector<const uint64_t*> idx(slices.size());
+    std::vector<const float*> val(slices.size());
+    std::vector<size_t> cnt(slices.size());
+    for (size_t g = 0; g < slices.size(); ++g) {
+      idx[g] = slices[g].index();
+      val[g] = slices[g].value();
+      cnt[g] = slices[g].nnz();
+    }
+    DFH_CALL(dfh_rowbuf_load_host_slices(rb, nrows, j.offset.data(), static_cast<int>(slices.size()), idx.data(), val.data(), cnt.data()));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      CHECK(live.emplace(serial, rb).second) << "shuffle buffer " << serial << " uploaded twice";
+    }
+    cv.notify_all();
   }
-  dfh_rowbuf* Of(uint64_t serial) {
-    std::lock_guard<std::mutex> lk(mu);
+  dfh_rowbuf* Of(uint64_t serial) {   // on the worker loop's thread: waits for an upload still under way
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return live.count(serial) != 0; });
     auto it = live.find(serial);
     CHECK(it != live.end()) << "minibatch names shuffle buffer " << serial << ", which is not (or no longer) on the device";
     return it->second;
@@ -257,6 +317,13 @@ struct DeviceFeed {
     }
   }
   ~DeviceFeed() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& w : workers)
+      if (w.joinable()) w.join();
     for (auto* rb : all) dfh_rowbuf_destroy(rb);
   }
 };
@@ -276,13 +343,26 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   DeviceFeed feed;   // outlives the reader, whose thread uploads into it
   feed.ctx = ctx;
   const bool device_feed = train && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
-  BatchReader* batch_reader = new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
-                                              train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f);
+  BatchReader::SliceFn upload;
+  if (device_feed) feed.Start();
   if (device_feed)
-    batch_reader->Describe([&feed](const dmlc::RowBlock<feaid_t>& blk, uint64_t serial) { feed.Upload(blk, serial); });
-  PrefetchSource reader(batch_reader, 2);
+    upload = [&feed](const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {
+      feed.Upload(blk, slices, serial);
+    };
+  // device feed: buffers as slices of the parsed chunks (no host assembly), uploaded by the thread that builds them
+  BatchReader* batch_reader = new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
+                                              train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f,
+                                              device_feed, upload);
+  if (device_feed) batch_reader->DescribeSlices(nullptr);
+  // described minibatches are ~120 KB each: a deeper queue lets the loop ride out the reader's pause at a buffer boundary
+  PrefetchSource reader(batch_reader, device_feed ? kFusedBatches : 2);
+  auto all_there = [&] {
+    for (auto* b : batch_)
+      if (!b) return false;
+    return true;
+  };
   auto ensure = [&](size_t rows, size_t nnz) {
-    if (batch_[0] && batch_[1] && rows <= batch_rows_ && nnz <= batch_nnz_) return;
+    if (all_there() && rows <= batch_rows_ && nnz <= batch_nnz_) return;
     for (auto& b : batch_) {
       if (b) {
         dfh_progress p;
@@ -298,12 +378,16 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       DFH_CALL(dfh_batch_set_option(b, "compute_auc", 1));  // sgd_learner.cc:153-155
     }
   };
+  const bool split_prep = getenv("DIFACTO_SPLIT_PREP") != nullptr;
+  std::vector<dfh_rowbuf*> bufs;
+  std::vector<const uint32_t*> rows;
+  std::vector<size_t> cnts;
   // prepare batch t+1 (H2D copy, Localizer, key lookup) while batch t trains
   auto prepare = [&](int slot) {
     const auto& blk = reader.Value();
     // a growing batch needs new buffers while the other slot may be in flight: drain first (the
     // main loop has already trained the pending batch)
-    if (!batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
+    if (!all_there() || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_) {
       DFH_CALL(dfh_ctx_sync(ctx));
       sgd::Progress keep;
       for (auto& b : batch_) {
@@ -326,20 +410,28 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     }
     const std::vector<RowSeg>& segs = reader.Aux();
     if (!segs.empty()) {   // a described minibatch: its rows are gathered out of the device-resident buffers
-      std::vector<dfh_rowbuf*> bufs(segs.size());
-      std::vector<const uint32_t*> rows(segs.size());
-      std::vector<size_t> cnts(segs.size());
+      bufs.resize(segs.size());
+      rows.resize(segs.size());
+      cnts.resize(segs.size());
       for (size_t g = 0; g < segs.size(); ++g) {
         bufs[g] = CHECK_NOTNULL(feed.Of(segs[g].buf));
         rows[g] = segs[g].rows.data();
         cnts[g] = segs[g].rows.size();
       }
-      DFH_CALL(dfh_batch_gather_rows(b, blk.size, blk.offset, blk.label, static_cast<int>(segs.size()), bufs.data(), rows.data(),
-                                     cnts.data()));
+      // gather + Localizer (Localizer lc(-1, ...), sgd_learner.cc:203) + key lookup as one preparation phase
+      // (DIFACTO_SPLIT_PREP=1: the three calls of round 3, for A/B)
+      if (split_prep) {
+        DFH_CALL(dfh_batch_gather_rows(b, blk.size, blk.offset, blk.label, static_cast<int>(segs.size()), bufs.data(), rows.data(),
+                                       cnts.data()));
+      } else {
+        DFH_CALL(dfh_batch_prepare_rows(table, b, blk.size, blk.offset, blk.label, static_cast<int>(segs.size()), bufs.data(),
+                                        rows.data(), cnts.data(), ~0ULL));
+      }
       // minibatches take their rows from the buffers in order: the buffers before this one's last are exhausted
       uint64_t last = 0;
       for (const auto& g : segs) last = std::max<uint64_t>(last, g.buf);
       feed.Release(last);
+      if (!split_prep) return;
     } else {
       DFH_CALL(dfh_batch_load_host(b, blk.size, blk.offset, blk.index, blk.value, blk.label));
     }
@@ -347,7 +439,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     DFH_CALL(dfh_batch_lookup(table, b));  // (dfh_localize_lookup does both in one pass; measured 0.4 % slower per step)
   };
   auto needs_growth = [&](const dmlc::RowBlock<feaid_t>& blk) {
-    return !batch_[0] || !batch_[1] || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
+    return !all_there() || blk.size > batch_rows_ || blk.offset[blk.size] - blk.offset[0] > batch_nnz_;
   };
   // DIFACTO_PROFILE=1: where the host thread of this loop spends its time (reader wait + batch assembly,
   // staging + Localizer / lookup queueing, step queueing), printed at the end of the job
@@ -361,18 +453,18 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   if (have) prepare(0);
   if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
   while (have) {
-    const int cur = i & 1;
+    const int cur = i % kFusedBatches, nxt = (i + 1) % kFusedBatches;
     const bool have_next = reader.Next();
     if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
     bool stepped = false;
     if (have_next && needs_growth(reader.Value())) {
-      // growing re-creates BOTH batch objects: the prepared, not yet trained batch goes first
+      // growing re-creates ALL batch objects: the prepared, not yet trained batch goes first
       DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
       if (predict) WritePredictions(batch_[cur]);
       stepped = true;
     }
     if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
-    if (have_next) prepare(cur ^ 1);
+    if (have_next) prepare(nxt);
     if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
     if (!stepped) {
       DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
@@ -421,6 +513,12 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
     q.loss = p.loss; q.penalty = p.penalty; q.auc = p.auc; q.nrows = p.nrows;
     progress->Merge(q);
   };
+  for (int q = 2; q < kFusedBatches; ++q) {  // the fused loop's further objects: this loop rotates two
+    if (!batch_[q]) continue;
+    drain(batch_[q]);
+    dfh_batch_destroy(batch_[q]);
+    batch_[q] = nullptr;
+  }
   size_t cap_rows[2] = {0, 0}, cap_nnz[2] = {0, 0};
   for (int q = 0; q < 2; ++q) {  // objects left by an earlier job keep their size
     if (batch_[q]) {

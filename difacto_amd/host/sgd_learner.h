@@ -75,7 +75,12 @@ class SGDLearner : public Learner {
   int blk_nthreads_ = DEFAULT_NTHREADS;
   std::vector<std::function<void(int, const sgd::Progress&, const sgd::Progress&)>> epoch_end_callback_;
   // device batches of the fused path (double-buffered)
-  dfh_batch* batch_[2] = {nullptr, nullptr};
+  // minibatch objects in rotation.  The fused loop uses kFusedBatches of them: the reader delivers minibatches in bursts
+  // (ten at a time, when a shuffle buffer becomes current) and the loop queues a whole burst on the device without
+  // waiting for any step — with two or three objects the device idled while the loop waited for the reader and the
+  // loop waited while the device caught up.  The sharded loop uses the first two.
+  static constexpr int kFusedBatches = 12;
+  dfh_batch* batch_[kFusedBatches] = {};
   size_t batch_rows_ = 0, batch_nnz_ = 0;
   FILE* pred_file_ = nullptr;       // open while a prediction job runs
   std::vector<float> pred_buf_;

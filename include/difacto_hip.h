@@ -245,8 +245,19 @@ typedef struct dfh_rowbuf dfh_rowbuf;
 int dfh_rowbuf_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_rowbuf** out);
 int dfh_rowbuf_destroy(dfh_rowbuf* rb);
 int dfh_rowbuf_load_host(dfh_rowbuf* rb, size_t nrows, const size_t* offset, const uint64_t* index, const float* value);
+/* the same for a buffer whose ids / values were never assembled on the host: `offset` [nrows + 1] are the buffer's own,
+ * slice g brings nnz[g] ids (and values, or NULL = all ones) that follow those of slice g - 1 — one copy per slice, straight
+ * out of the parser's chunks (round 4: assembling 31 MB per buffer on one host thread was what the worker loop waited for) */
+int dfh_rowbuf_load_host_slices(dfh_rowbuf* rb, size_t nrows, const size_t* offset, int nslices, const uint64_t* const* index,
+                                const float* const* value, const size_t* nnz);
 int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg, dfh_rowbuf* const* bufs,
                           const uint32_t* const* rows, const size_t* seg_rows);
+/* dfh_batch_gather_rows + dfh_localize + dfh_batch_lookup as ONE preparation phase — what a worker loop queues per
+ * minibatch (src/sgd/sgd_learner.cc:196-224: read, localize, pull): the minibatch's description is read by the gather
+ * kernel where the host wrote it (page-locked, mapped: no copy is queued), the phase records one cross-stream event.
+ * Same results as the three calls; about half their host time per minibatch. */
+int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg,
+                           dfh_rowbuf* const* bufs, const uint32_t* const* rows, const size_t* seg_rows, uint64_t max_index);
 
 /* already-localized batch from the host (what SGDLearner hands its batch thread,
  * src/sgd/sgd_learner.cc:203-212): feaids sorted unique, compact u32 index */

@@ -754,7 +754,8 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
 
 @pytest.mark.parametrize("streams", [0, 1])
 def test_device_row_gather_matches_host_load(capi, oracle, streams):
-    """the device feed (dfh_rowbuf_load_host + dfh_batch_gather_rows): minibatches gathered on the device out of shuffle
+    """the device feed (dfh_rowbuf_load_host + dfh_batch_gather_rows, or dfh_batch_prepare_rows = gather + Localizer + lookup
+    in one call): minibatches gathered on the device out of shuffle
     buffers held in HBM — one buffer, two buffers, a buffer without values beside one with, empty rows, repeated rows —
     must localize and step exactly like the same minibatch copied on the host and sent with dfh_batch_load_host"""
     rng = np.random.default_rng(41)
@@ -787,17 +788,20 @@ def test_device_row_gather_matches_host_load(capi, oracle, streams):
              [(1, rng.permutation(500)[:150])], [(1, rng.permutation(500)[:60]), (0, np.array([5, 5, 7, 5]))],
              [(2, np.arange(300))]]
     results = []
-    for device in (False, True):
+    for device in (False, True, "one_call"):
         tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_HASH, **kw)
         bt = capi.Batch(ctx, 400, 400 * 40)
         out = []
         for step, segments in enumerate(plans * 2):
             mb = host_minibatch(segments)
-            if device:
+            if device == "one_call":   # dfh_batch_prepare_rows: gather (description read in place) + Localizer + key lookup
+                bt.prepare_rows(tb, mb["offset"], mb["label"], [(rbs[g], rows) for g, rows in segments])
+            elif device:
                 bt.gather_rows(mb["offset"], mb["label"], [(rbs[g], rows) for g, rows in segments])
             else:
                 bt.load_host(mb["offset"], mb["index"], mb["value"], mb["label"])
-            bt.localize()
+            if device != "one_call":
+                bt.localize()
             got = bt.get_localized()
             want = oracle.localize(mb["offset"], mb["index"])
             assert np.array_equal(got["feaids"], want["feaids"]) and np.array_equal(got["index"], want["index"]), (device, step)
@@ -807,10 +811,11 @@ def test_device_row_gather_matches_host_load(capi, oracle, streams):
         results.append((out, tb.pull(oracle.reverse_bytes(keys))))
         bt.close()
         tb.close()
-    (p0, (v0, l0)), (p1, (v1, l1)) = results
-    for a, b in zip(p0, p1):
-        assert np.array_equal(a, b)
-    assert np.array_equal(l0, l1) and np.array_equal(v0, v1)
+    (p0, (v0, l0)) = results[0]
+    for (p1, (v1, l1)) in results[1:]:
+        for a, b in zip(p0, p1):
+            assert np.array_equal(a, b)
+        assert np.array_equal(l0, l1) and np.array_equal(v0, v1)
     for rb in rbs:
         rb.close()
     ctx.close()

@@ -240,8 +240,9 @@ def test_reader_threads_hand_out_the_same_minibatches(ing, tmp_path, monkeypatch
         assert not np.array_equal(plain["index"], shuf["index"]) and sorted(plain["index"].tolist()) == sorted(shuf["index"].tolist())
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])   # 1: assembled buffers; 2: buffers as slices of the parsed chunks (round 4)
 @pytest.mark.parametrize("depth", [0, 2])
-def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch, depth):
+def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch, depth, mode):
     """BatchReader::Describe (what the device feed reads): the shuffle buffers are announced once each and a minibatch is
     its offsets, labels and (buffer, rows) list; gathering those rows from copies of the buffers must give the copying
     reader's minibatches exactly — same permutation, same sampling draws, same boundaries, minibatches that straddle two
@@ -268,7 +269,7 @@ def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch,
             monkeypatch.delenv("DIFACTO_INGEST_PREFETCH", raising=False)
             ing.ingest_reset_shuffle_stream()
             want = read_all(ing, path, fmt, **kw)
-            monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", "1")
+            monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", mode)
             if depth:
                 monkeypatch.setenv("DIFACTO_INGEST_PREFETCH", str(depth))
             ing.ingest_reset_shuffle_stream()
@@ -278,8 +279,9 @@ def test_described_minibatches_equal_the_copied_ones(ing, tmp_path, monkeypatch,
                 assert np.array_equal(got[k], want[k]), (fmt, kw, k)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("depth", [0, 2])
-def test_described_minibatches_spanning_many_buffers(ing, tmp_path, monkeypatch, depth):
+def test_described_minibatches_spanning_many_buffers(ing, tmp_path, monkeypatch, depth, mode):
     """with strong down-sampling (the reference DROPS a negative with probability neg_sampling,
     batch_reader.cc:57-63, so values near 1 on data with few positives) ONE minibatch draws its rows
     from dozens of shuffle buffers, and the reader runs further ahead in buffers than any fixed ring holds.  The
@@ -301,7 +303,7 @@ def test_described_minibatches_spanning_many_buffers(ing, tmp_path, monkeypatch,
         want = read_all(ing, svm, "libsvm", **kw)
         kept = len(want["label"])
         assert kept < 0.12 * 6000 and want["nbatches"] >= 2   # most negatives dropped: a minibatch spans >= 8 buffers on average
-        monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", "1")
+        monkeypatch.setenv("DIFACTO_INGEST_DESCRIBE", mode)
         if depth:
             monkeypatch.setenv("DIFACTO_INGEST_PREFETCH", str(depth))
         ing.ingest_reset_shuffle_stream()

@@ -9,6 +9,9 @@
 #include <memory>
 #include <new>
 #include <utility>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include <vector>
 #include "dmlc/data.h"
 
@@ -96,13 +99,37 @@ struct RowBlockContainer {
     if (blk.weight != nullptr) weight.insert(weight.end(), blk.weight, blk.weight + blk.size);
     // one pass (converts when I != IndexType), no zero fill.  max_index goes stale instead of being rescanned here:
     // nothing on the worker path reads it (the Localizer is given its modulus explicitly, src/sgd/sgd_learner.cc:203)
-    index.insert(index.end(), blk.index, blk.index + nnz);
     max_index_stale = max_index_stale || nnz > 0;
-    if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
+    if (std::is_same<I, IndexType>::value && nnz >= (size_t(1) << 18) && BulkCopyThreads() > 1) {
+      // a shuffle buffer is assembled out of slices of several MB each: the copy is split over a few threads (one core
+      // copies ~15 GB/s; the assembly of the 31 MB buffers was what the worker loop waited for)
+      const size_t at = index.size();
+      index.resize(at + nnz);
+      if (blk.value != nullptr) value.resize(at + nnz);
+      const int nt = BulkCopyThreads();
+#pragma omp parallel for num_threads(nt) schedule(static)
+      for (int t = 0; t < nt; ++t) {
+        const size_t lo = nnz * t / nt, hi = nnz * (t + 1) / nt;
+        memcpy(static_cast<void*>(&index[at + lo]), static_cast<const void*>(blk.index + lo), (hi - lo) * sizeof(IndexType));
+        if (blk.value != nullptr) memcpy(&value[at + lo], blk.value + lo, (hi - lo) * sizeof(real_t));
+      }
+    } else {
+      index.insert(index.end(), blk.index, blk.index + nnz);
+      if (blk.value != nullptr) value.insert(value.end(), blk.value, blk.value + nnz);
+    }
     size_t shift = offset.back();
     for (size_t i = 0; i < blk.size; ++i) {
       offset.push_back(shift + blk.offset[i + 1] - blk.offset[0]);
     }
+  }
+
+  /*! \brief threads of a bulk append (DIFACTO_ASSEMBLY_THREADS, default 4, 1 .. 16) */
+  static int BulkCopyThreads() {
+    static const int n = [] {
+      const char* e = getenv("DIFACTO_ASSEMBLY_THREADS");
+      return std::max(1, std::min(e ? atoi(e) : 4, 16));
+    }();
+    return n;
   }
 
   /*! \brief view of the stored rows */

@@ -36,16 +36,24 @@ sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
 common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
           "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
 EXES = os.environ.get("E2E_EXES", "difacto").split(",")   # A/B: several binaries under build/ on the same files
+# A/B of environment switches on the same files: E2E_VARIANTS="name:KEY=VAL+KEY=VAL,name2:" (an entry of EXES may be
+# "binary@name" to run that binary under the named variant's environment)
+VARIANTS = {}
+for item in filter(None, os.environ.get("E2E_VARIANTS", "").split(",")):
+    name, _, kv = item.partition(":")
+    VARIANTS[name] = dict(x.split("=", 1) for x in kv.split("+") if x)
 exe = EXES[0]
 def run(path, fmt):
     t0 = time.time()
-    r = subprocess.run([os.path.join(R, "build", exe), "data_in=" + path, "data_format=" + fmt] + common,
-                       capture_output=True, text=True, timeout=900)
+    binary, _, var = exe.partition("@")
+    env = dict(os.environ, **VARIANTS.get(var, {}))
+    r = subprocess.run([os.path.join(R, "build", binary), "data_in=" + path, "data_format=" + fmt] + common,
+                       capture_output=True, text=True, timeout=900, env=env)
     dt = time.time() - t0
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
     for l in r.stderr.splitlines():
         if "host loop over" in l or "reader: " in l or "batch reader" in l:   # DIFACTO_PROFILE=1
-            sys.stderr.write(fmt + ": " + l.split("INFO")[-1].strip() + "\n")
+            sys.stderr.write(fmt + " " + exe + ": " + l.split("INFO")[-1].strip() + "\n")
     return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])
 
 
