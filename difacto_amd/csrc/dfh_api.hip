@@ -1823,19 +1823,19 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_uid, N, uint32_t);
   DFH_ALLOC(b->d_temp, b->temp_bytes, char);
   b->max_tiles = (N + LOC_TILE - 1) / LOC_TILE;
-  DFH_ALLOC(b->d_spl_key, LOC_MAX_BUCKETS, uint64_t);
-  DFH_ALLOC(b->d_spl_pos, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_smp_key, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint64_t);
-  DFH_ALLOC(b->d_smp_pos, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint32_t);
-  DFH_ALLOC(b->d_smp_rank, LOC_MAX_BUCKETS * LOC_OVERSAMPLE, uint32_t);
-  DFH_ALLOC(b->d_first_key, LOC_MAX_BUCKETS, uint64_t);
-  DFH_ALLOC(b->d_last_key, LOC_MAX_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_spl_key, LOC_BIG_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_spl_pos, LOC_BIG_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_smp_key, LOC_BIG_BUCKETS * LOC_OVERSAMPLE, uint64_t);
+  DFH_ALLOC(b->d_smp_pos, LOC_BIG_BUCKETS * LOC_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_smp_rank, LOC_BIG_BUCKETS * LOC_OVERSAMPLE, uint32_t);
+  DFH_ALLOC(b->d_first_key, LOC_BIG_BUCKETS, uint64_t);
+  DFH_ALLOC(b->d_last_key, LOC_BIG_BUCKETS, uint64_t);
   DFH_ALLOC(b->d_packed, N, uint32_t);
-  DFH_ALLOC(b->d_run_off, b->max_tiles * LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_bstart, LOC_MAX_BUCKETS + 1, uint32_t);
-  DFH_ALLOC(b->d_btotal, LOC_XCDS * LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_nheads, LOC_MAX_BUCKETS, uint32_t);
-  DFH_ALLOC(b->d_lh, LOC_MAX_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_run_off, b->max_tiles * LOC_BIG_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_bstart, LOC_BIG_BUCKETS + 1, uint32_t);
+  DFH_ALLOC(b->d_btotal, LOC_XCDS * LOC_BIG_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_nheads, LOC_BIG_BUCKETS, uint32_t);
+  DFH_ALLOC(b->d_lh, LOC_BIG_BUCKETS, uint32_t);
   DFH_ALLOC(b->d_feaids, N, uint64_t);
   DFH_ALLOC(b->d_feacnt, N, float);
   DFH_ALLOC(b->d_col_ptr, N + 1, uint32_t);
@@ -1846,12 +1846,12 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_urow, N, uint32_t);
   DFH_ALLOC(b->d_uw, N, uint2);
   // bucket q of the sample sort may list n_q / 9 + 2 mid and n_q / 257 + 2 hot keys (k_loc_emit)
-  DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
-  DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
-  DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_MAX_BUCKETS + 16, SegEnt);
-  DFH_ALLOC(b->d_mid, LOC_MAX_BUCKETS, uint2);
-  DFH_ALLOC(b->d_hot, LOC_MAX_BUCKETS, uint2);
-  DFH_ALLOC(b->d_few, LOC_MAX_BUCKETS, uint2);
+  DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
+  DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
+  DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
+  DFH_ALLOC(b->d_mid, LOC_BIG_BUCKETS, uint2);
+  DFH_ALLOC(b->d_hot, LOC_BIG_BUCKETS, uint2);
+  DFH_ALLOC(b->d_few, LOC_BIG_BUCKETS, uint2);
   DFH_ALLOC(b->d_need, N, uint32_t);
   DFH_ALLOC(b->d_rank, N, uint32_t);
   DFH_ALLOC(b->d_pred, B, float);
@@ -1870,7 +1870,7 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_HIP(hipEventCreateWithFlags(&b->ev_free, evf));
   DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_MAX_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
+  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_BIG_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
   // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
   // all-ones makes a stray use fault at once instead of reading some row
   DFH_HIP(hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream));
@@ -2321,9 +2321,13 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     P = b->spl_P;
     cold = false;
   } else {
+    // the small size class (<= 1024 buckets, up to 700 pairs each) as long as it holds the minibatch, then the large one
+    // (<= 4096 buckets: 2.9 M pairs); beyond that the library sort
     const size_t P_want = (N + LOC_AVG_BUCKET - 1) / LOC_AVG_BUCKET;
-    P = P_want <= (size_t)LOC_MAX_BUCKETS ? (int)std::max<size_t>(1, P_want) : 0;
-    if (P == 0 && N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
+    if (P_want <= (size_t)LOC_MAX_BUCKETS) P = (int)std::max<size_t>(1, P_want);
+    else if (N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
+    else if (P_want <= (size_t)LOC_BIG_BUCKETS) P = (int)P_want;
+    else if (N / LOC_BIG_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_BIG_BUCKETS;
   }
   if (P > 0 && !b->force_radix) {
     // hand-written sample sort (dfh_localize.hip)
@@ -2332,6 +2336,8 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     v.n = N;
     v.max_index = max_index;
     v.P = P;
+    const bool big = P > LOC_MAX_BUCKETS;
+    v.bstride = big ? LOC_BIG_BUCKETS : LOC_MAX_BUCKETS;
     v.ntiles = (int)((N + LOC_TILE - 1) / LOC_TILE);
     v.force_global = b->force_sort_fallback ? 1 : 0;
     v.tb = N > 1 ? std::min(16, __builtin_clz(N - 1)) : 16;  // (N - 1) << tb fits 32 bits
@@ -2369,12 +2375,17 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    hipLaunchKernelGGL(k_loc_count, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-    hipLaunchKernelGGL(k_loc_scatter, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    if (big) {
+      hipLaunchKernelGGL(k_loc_count<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+      hipLaunchKernelGGL(k_loc_scatter<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    } else {
+      hipLaunchKernelGGL(k_loc_count<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
+      hipLaunchKernelGGL(k_loc_scatter<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    }
 #ifndef DFH_LOC_GRID_CAP
 #define DFH_LOC_GRID_CAP 1024
 #endif
-    const unsigned gsort = (unsigned)std::min<int>(P, DFH_LOC_GRID_CAP);
+    const unsigned gsort = (unsigned)std::min<int>(P, big ? LOC_BIG_BUCKETS : DFH_LOC_GRID_CAP);
     hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
     if (probe)
       hipLaunchKernelGGL(k_loc_emit<true>, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,

@@ -58,7 +58,9 @@
 namespace dfh {
 
 constexpr int LOC_OVERSAMPLE = 8;      // bootstrap: samples per bucket
-constexpr int LOC_MAX_BUCKETS = 1024;
+constexpr int LOC_MAX_BUCKETS = 1024;   // the small size class: count / scatter keep 1024 splitters + a histogram in 16 KB of LDS
+constexpr int LOC_BIG_BUCKETS = 4096;   // round 4: the large size class (minibatches of 0.7 .. 2.9 M pairs): the same four kernels
+                                        // with 4096-bucket LDS tables (64 KB in k_loc_count), in place of the library radix sort
 constexpr int LOC_AVG_BUCKET = 384;    // target pairs per bucket
 constexpr int LOC_MIN_AVG = 48;        // stored splitters are reused while N / P stays in [MIN, MAX]
 constexpr int LOC_MAX_AVG = 700;
@@ -72,7 +74,6 @@ constexpr int LOC_LDS_CAP = 1024;      // pairs a bucket may hold to be sorted i
 constexpr int LOC_TILE = DFH_LOC_TILE;         // pairs per block in count / scatter
 constexpr int LOC_TILE_THREADS = DFH_LOC_TILE_THREADS;
 constexpr int LOC_PER_THREAD = LOC_TILE / LOC_TILE_THREADS;
-constexpr int LOC_BPT = LOC_MAX_BUCKETS / LOC_TILE_THREADS;  // buckets per thread in k_loc_scatter's scan
 constexpr int LOC_SORT_THREADS = 256;
 constexpr int LOC_EMIT_THREADS = 256;
 
@@ -81,6 +82,7 @@ struct LocView {
   uint32_t n;             // N
   uint64_t max_index;
   int P;                  // buckets
+  int bstride;            // row stride of btotal: LOC_MAX_BUCKETS or LOC_BIG_BUCKETS, the size class of this call
   int ntiles;
   int force_global;       // tests: sort every bucket through the global-memory path
   // The 32-bit tie-break carried through the sort is a TAG: pos << tb | (row of pos) mod 2^tb, tb = clz(N - 1) capped
@@ -258,11 +260,12 @@ __global__ void __launch_bounds__(256) k_loc_splitters(LocView v) {
 // ---------------------------------------------------------------------------------------
 // count: bucket + rank-in-(tile, bucket) of every pair; the tile's runs reserve their places
 // ---------------------------------------------------------------------------------------
+template <int MAXB>
 __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
                                                                 uint32_t* __restrict__ rowid) {
-  __shared__ uint64_t sk[LOC_MAX_BUCKETS];
-  __shared__ uint32_t sp[LOC_MAX_BUCKETS];
-  __shared__ uint32_t hist[LOC_MAX_BUCKETS];
+  __shared__ uint64_t sk[MAXB];
+  __shared__ uint32_t sp[MAXB];
+  __shared__ uint32_t hist[MAXB];
   const int P = v.P;
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     hist[b] = 0;
@@ -317,15 +320,17 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
   // result does not.
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     const uint32_t h = hist[b];
-    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[loc_xcd() * LOC_MAX_BUCKETS + b], h) : 0u;
+    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[loc_xcd() * MAXB + b], h) : 0u;
   }
 }
 
 
 // ---- scatter into bucket-major order; every block derives the bucket starts from the totals
 // (block 0 publishes them)
+template <int MAXB>
 __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
-  __shared__ uint32_t off[LOC_MAX_BUCKETS];
+  constexpr int LOC_BPT = MAXB / LOC_TILE_THREADS;  // buckets per thread in the scan of the bucket totals
+  __shared__ uint32_t off[MAXB];
   __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
   const int P = v.P;
   const uint32_t base = blockIdx.x * LOC_TILE;
@@ -351,7 +356,7 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
     ro[q] = v.run_off[blockIdx.x * P + bb];
 #pragma unroll
     for (int x = 0; x < LOC_XCDS; ++x) {
-      const uint32_t h = v.btotal[x * LOC_MAX_BUCKETS + bb];
+      const uint32_t h = v.btotal[x * MAXB + bb];
       tt[q] += h;
       ro[q] += (x < (int)loc_xcd() ? 1u : 0u) * h;  // the groups before this tile's
     }
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     __syncthreads();  // LDS of the previous bucket is done with
     const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
     const uint32_t n = end - beg;
-    if (threadIdx.x < LOC_XCDS) v.btotal[threadIdx.x * LOC_MAX_BUCKETS + b] = 0;  // consumed by k_loc_scatter: ready for the next call
+    if (threadIdx.x < LOC_XCDS) v.btotal[threadIdx.x * v.bstride + b] = 0;  // consumed by k_loc_scatter: ready for the next call
     if (n == 0) {
       if (threadIdx.x == 0) {
         v.nheads[b] = 0;
@@ -645,8 +650,17 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
       // the row of pos: the largest row congruent to the tag's low bits whose range starts at or before pos
       uint32_t row = tag & ((1u << v.tb) - 1u);
-      for (uint32_t c = row + (1u << v.tb); c < v.nrows; c += 1u << v.tb)
-        if (v.offset[c] <= pos) row = c;
+      {
+        // candidates row + k 2^tb, k = 0 .. kmax: their offsets ascend, the row is the last one that starts at or before pos
+        // (2 candidates at C3 size: the loop ends at once; the large size class has up to ~70: a binary search)
+        const uint32_t step = 1u << v.tb;
+        uint32_t lo = 0, hi = v.nrows > row ? (v.nrows - 1u - row) >> v.tb : 0u;  // k in [lo, hi]
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (v.offset[row + mid * step] <= pos) lo = mid; else hi = mid - 1u;
+        }
+        row += lo * step;
+      }
       s_row[i] = row;
       if (value) s_val[i] = value[pos];
       if (i == v.n - 1) {  // the end of the minibatch closes the last segment

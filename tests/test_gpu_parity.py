@@ -117,7 +117,8 @@ def test_literal_predict_accumulates(ctx, oracle):
 # ------------------------------------------------------------------ device Localizer
 @pytest.mark.parametrize("path", ["sample_sort", "radix", "sample_sort_fallback"])
 @pytest.mark.parametrize("case", ["rcv1", "hash1000", "random", "binary_big", "one_row", "all_same", "criteo_like",
-                                  "bias_feature", "sorted_input", "clustered", "tall_ragged", "max_sample_sort", "over_sample_sort"])
+                                  "bias_feature", "sorted_input", "clustered", "tall_ragged", "max_sample_sort", "over_sample_sort",
+                                  "big_class_c3_20000", "big_class_ragged_2M"])
 def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     rng = np.random.default_rng(11)
     mx = U64MAX
@@ -132,11 +133,18 @@ def test_device_localizer_bit_exact(capi, ctx, oracle, rcv1, case, path):
     elif case == "one_row":
         b = random_batch(rng, 1, 50, 30, empty_rows=False)
     elif case in ("max_sample_sort", "over_sample_sort"):
-        # 716 800 pairs is the most the hand-written sample sort takes (1024 buckets of <= 700 on average; 20-bit positions
-        # in the tags); one row more and the library sort's path serves the minibatch
+        # 716 800 pairs is the most the SMALL size class of the sample sort takes (1024 buckets of <= 700 on average); one row
+        # more and (since round 4) the large size class — 4096-bucket tables — serves the minibatch
         from difacto_amd import synth
         b = synth.CriteoSynth(total_ids=3000000, seed=5).batch(18379 if case == "max_sample_sort" else 18380)
         assert (int(b["offset"][-1]) <= 716800) == (case == "max_sample_sort")
+    elif case == "big_class_c3_20000":
+        # round 4: the large size class of the sample sort (4096-bucket tables): C3 rows, twice the batch size, 780 k pairs
+        from difacto_amd import synth
+        b = synth.CriteoSynth(total_ids=33000000, seed=9).batch(20000)
+    elif case == "big_class_ragged_2M":
+        # ~2.1 M pairs over 60 000 ragged rows (tags keep 10 row bits: ~59 candidate rows per pair in emit)
+        b = random_batch(rng, 60000, 2 ** 44, 70)
     elif case == "tall_ragged":
         b = random_batch(rng, 30000, 2 ** 40, 20)  # ~300 k pairs over 30 000 rows, many of them empty
     elif case == "criteo_like":
@@ -465,6 +473,18 @@ def test_full_size_c3_minibatches(capi, ctx, oracle):
     bt.close()
     kw = dict(l1=0.001, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
     n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 64, "hash", batches, 2, kw, capacity=1 << 19)
+    assert n_with_v > 1000
+
+
+def test_fused_step_on_a_minibatch_of_the_large_size_class(capi, ctx, oracle):
+    """round 4: 20 000 C3 rows = 780 000 pairs: beyond the 1024-bucket tables of the sample sort, served by its large size
+    class (4096 buckets) instead of the library radix sort; the update walks 2 033 list buckets.  Two epochs against the
+    oracle (Localizer bit-exact inside _run_fused_vs_oracle's device path, logits, progress, final model)"""
+    from difacto_amd import synth
+    gen = synth.CriteoSynth(total_ids=3_000_000, seed=21)
+    batches = [gen.batch(20000)]
+    kw = dict(l1=0.001, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 8, "hash", batches, 2, kw, capacity=1 << 20)
     assert n_with_v > 1000
 
 
