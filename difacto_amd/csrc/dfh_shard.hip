@@ -966,7 +966,8 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
                        W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo, AucFin{nullptr, 0u, nullptr});
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo, auc_pending(b));
+    b->auc_pending_n = 0;  // (the lookup's first block added up the AUC slots this batch object's previous step left)
     DFH_HIP(hipGetLastError());
   }
   // ---- K: the other keys (+ counts in epoch 0) to their owners.  Two message groups, one send and one receive
@@ -1024,7 +1025,10 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     MixSrc mix{any_remote ? s->w_rows[0] + 4 : nullptr, stride};
     rc = launch_forward(b, tsrc, k, kp, b->d_uw, W > 1 ? &mix : nullptr);
     if (rc) return rc;
-    if (b->compute_auc) {
+    // BinClassMetric::AUC of the minibatch: rides in the own keys' update launch of a training step (k_update_fused has idle
+    // VALUs), a launch of its own otherwise
+    bool auc_rides = b->compute_auc && is_train && any_own && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
+    if (b->compute_auc && !auc_rides) {
       rc = launch_auc(b);
       if (rc) return rc;
     }
@@ -1040,8 +1044,14 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       if (rc) return rc;
     }
     if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0);
+      const bool auc_wanted = auc_rides;
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0,
+                                 &auc_rides);
       if (rc) return rc;
+      if (auc_wanted && !auc_rides) {  // the minibatch is beyond the pair-counting size
+        rc = launch_auc(b);
+        if (rc) return rc;
+      }
     } else if (any_own) {
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
       DFH_HIP(hipGetLastError());
@@ -1148,7 +1158,8 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
                        (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr, b->d_col_ptr + cur.own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo, AucFin{nullptr, 0u, nullptr});
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo, auc_pending(b));
+    b->auc_pending_n = 0;
     DFH_HIP(hipGetLastError());
   }
   if (!cur.pulled) {  // pipeline fill: K, R, RW of this very minibatch, in the sync step's order (after L)
@@ -1168,6 +1179,9 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
   // ---- F: the worker's math: own keys on the table, the others on the pulled rows
   const KeyRange own{cur.own_lo, cur.own_hi, 0u}, others{cur.own_lo, cur.own_hi, 1u};
   const int q = cur.slot;
+  // BinClassMetric::AUC of the minibatch: rides in the own keys' update launch of a training step (k_update_fused has idle
+  // VALUs), a launch of its own otherwise
+  bool auc_rides = b && b->compute_auc && is_train && cur.any_own && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
   if (b) {
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     rc = ensure_xv(b, kp);
@@ -1182,7 +1196,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     MixSrc mix{cur.any_remote ? s->w_rows[q] + 4 : nullptr, stride};
     rc = launch_forward(b, tsrc, k, kp, b->d_uw, &mix);
     if (rc) return rc;
-    if (b->compute_auc) {
+    if (b->compute_auc && !auc_rides) {
       rc = launch_auc(b);
       if (rc) return rc;
     }
@@ -1203,8 +1217,14 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (is_train && cur.any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0);
+      const bool auc_wanted = auc_rides;
+      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0,
+                                 &auc_rides);
       if (rc) return rc;
+      if (auc_wanted && !auc_rides) {  // the minibatch is beyond the pair-counting size
+        rc = launch_auc(b);
+        if (rc) return rc;
+      }
     } else if (cur.any_own) {
       BatchView bv = batch_view(b);
       const int pgrid = cur.have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;

@@ -40,3 +40,25 @@ def test_pmc_summary_feeds_the_traffic_field():
     t = json.load(open(newest("r*_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")))
     fwd = [v for k, v in t.items() if k.startswith("k_forward<")]
     assert len(fwd) == 1 and fwd[0]["hbm_bytes_per_launch"] > 0
+
+
+def test_committed_sharded_line_has_the_same_shape():
+    """the N > 1 line (difacto_amd/sharded.py; here its one-rank run over RCCL, `bench.py --force-sharded`) carries
+    what the N = 1 line carries — cpu_baseline, roofline with a traffic figure and its source, and the exchange priced
+    against the xGMI links — so that the first run on a multi-GPU node counts"""
+    d = json.loads(open(newest("r0[4-9]*_bench_sharded_w1_full.json", "r04z_bench_sharded_w1_full.json")).read().strip().splitlines()[-1])
+    for k, typ in dict(metric=str, value=float, unit=str, n_gpus=int, steps=int, warmup=int, ms_per_step=float,
+                       higher_is_better=bool, scaling=str, dtype=str, data=str, config=dict).items():
+        assert isinstance(d[k], typ), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "f32"
+    c = d["cpu_baseline"]
+    assert c and c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] and r["traffic_source"].startswith("profiles/")
+    x = d["roofline_exchange"]
+    for k in ("bound", "bytes_per_gpu_step", "exchange_ms_per_step", "achieved", "peak", "unit", "frac", "links_in_use"):
+        assert k in x, k
+    assert x["bound"] == "xgmi" and abs(x["peak"] - 7 * 153.6) < 1e-9
+    assert "rccl" in d["config"]["transport_bound"] and d["config"]["auc_every_minibatch"] is True
+    assert set(d["stage_ms_per_step"]) == {"counts", "L", "K", "R", "RW", "F", "G", "P"}
