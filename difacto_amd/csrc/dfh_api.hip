@@ -795,6 +795,9 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
     return DFH_ERR_HIP;
   }
   DFH_HIP(hipSetDevice(device));
+  // DFH_SCHEDULE_SPIN=1 (experiment, tools/gpu_r04u.sh): host waits poll instead of blocking on an interrupt
+  if (const char* e = getenv("DFH_SCHEDULE_SPIN"))
+    if (atoi(e) == 1 && hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
   dfh_ctx* c = new (std::nothrow) dfh_ctx();
   DFH_ARG(c != nullptr, "out of host memory");
   c->device = device;
@@ -2590,7 +2593,7 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   if (rc) return rc;
   rc = prep_end(b);
   lap(5);  // lookup queued, ev_ready recorded
-  ++b->n_prof;
+  if (prof) ++b->n_prof;
   return rc;
 }
 

@@ -382,6 +382,9 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   std::vector<dfh_rowbuf*> bufs;
   std::vector<const uint32_t*> rows;
   std::vector<size_t> cnts;
+  const bool prof = getenv("DIFACTO_PROFILE") != nullptr;
+  double t_feed = 0;   // DIFACTO_PROFILE: inside "stage + localize + lookup", waiting for a buffer's upload (DeviceFeed::Of)
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   // prepare batch t+1 (H2D copy, Localizer, key lookup) while batch t trains
   auto prepare = [&](int slot) {
     const auto& blk = reader.Value();
@@ -413,11 +416,13 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
       bufs.resize(segs.size());
       rows.resize(segs.size());
       cnts.resize(segs.size());
+      const double tf = prof ? now() : 0;
       for (size_t g = 0; g < segs.size(); ++g) {
         bufs[g] = CHECK_NOTNULL(feed.Of(segs[g].buf));
         rows[g] = segs[g].rows.data();
         cnts[g] = segs[g].rows.size();
       }
+      if (prof) t_feed += now() - tf;
       // gather + Localizer (Localizer lc(-1, ...), sgd_learner.cc:203) + key lookup as one preparation phase
       // (DIFACTO_SPLIT_PREP=1: the three calls of round 3, for A/B)
       if (split_prep) {
@@ -443,9 +448,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   };
   // DIFACTO_PROFILE=1: where the host thread of this loop spends its time (reader wait + batch assembly,
   // staging + Localizer / lookup queueing, step queueing), printed at the end of the job
-  const bool prof = getenv("DIFACTO_PROFILE") != nullptr;
   double t_read = 0, t_prep = 0, t_step = 0;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = prof ? now() : 0;
   bool have = reader.Next();
   if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
@@ -476,7 +479,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   }
   if (prof)
     LOG(INFO) << "host loop over " << i << " minibatches: reader " << t_read << " s, stage + localize + lookup " << t_prep
-              << " s, step " << t_step << " s";
+              << " s (" << t_feed << " s of it waiting for a buffer's upload), step " << t_step << " s";
   for (auto& b : batch_) {
     if (!b) continue;
     dfh_progress p;

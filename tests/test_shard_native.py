@@ -188,6 +188,9 @@ def _worker(rank, world, port, out_dir, balanced, prefetch, mode="sync"):
         recv[:] = out.numpy()
 
     comm = capi.Comm.callback(ctx, rank, world, exchange)
+    comm.selfcheck(30.0)   # collective: every rank's id arrives everywhere, or an error instead of a hang
+    assert "callback" in comm.info()
+    comm.stats(reset=True)
     splits = None
     if balanced:
         ids = np.concatenate([b["index"] for r in range(world) for b in make_batches(r)])
@@ -235,8 +238,12 @@ def _worker(rank, world, port, out_dir, balanced, prefetch, mode="sync"):
     import types
     prog = types.SimpleNamespace(loss=sum(p.loss for p in progs), nrows=sum(p.nrows for p in progs),
                                  penalty=sum(p.penalty for p in progs))
-    tot = comm.allreduce_sum([prog.loss, prog.nrows, 1.0])
-    assert tot[2] == world
+    # dfh_comm_stats: bytes that left this rank for OTHER ranks / arrived from them.  Summed over the job they are equal,
+    # and with every minibatch's keys spread over all owners nobody's exchange is empty
+    sent, recv, groups = comm.stats()
+    assert groups >= i and sent > 0 and recv > 0
+    tot = comm.allreduce_sum([prog.loss, prog.nrows, 1.0, float(sent), float(recv)])
+    assert tot[2] == world and tot[3] == tot[4]
     from oracle import bindings as ob
     o = ob.Oracle()
     allkeys = np.unique(np.concatenate([o.localize(b["offset"], b["index"])["feaids"]
@@ -308,6 +315,9 @@ def test_shard_step_world1_over_rccl_matches_fused():
     from difacto_amd import capi
     ctx = capi.Context(0)
     comm = capi.Comm.rccl(ctx, 0, 1, capi.Comm.unique_id())
+    comm.selfcheck(30.0)
+    info = comm.info()   # which RCCL: version + the file it was bound from (the bench line logs it)
+    assert info.startswith("rccl ") and "librccl" in info and int(info.split()[1]) > 20000, info
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
     rng = np.random.default_rng(77)
     batches = [random_batch(rng, 200, 4000, 25, binary=(i == 1)) for i in range(3)]
@@ -333,6 +343,8 @@ def test_shard_step_world1_over_rccl_matches_fused():
     np.testing.assert_allclose(eb["scal"][ob_], ea["scal"][oa], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(eb["V"][ob_], ea["V"][oa], rtol=2e-5, atol=1e-6)
     assert comm.allreduce_sum([1.5, 2.0]).tolist() == [1.5, 2.0]
+    sent, recv, groups = comm.stats()
+    assert sent == 0 and recv == 0 and groups > 0   # one rank: nothing leaves it, the exchanges still ran
     for o in (sh, ba, bb, ta, tb, comm):
         o.close()
     ctx.close()
