@@ -133,6 +133,7 @@ struct dfh_batch {
   float* o_label = nullptr;
   // pinned staging of dfh_batch_load_host (one block: offsets | labels | ids | values), allocated on first use
   char* h_stage = nullptr;
+  size_t stage_bytes = 0;          // allocated size of h_stage (ensure_stage: the row-description paths need ~160 KB, load_host the whole batch)
   hipEvent_t ev_staged = nullptr;  // the copies out of h_stage (or the kernels that read it in place) have completed
   bool staged_pending = false;
   double t_prof[6] = {0, 0, 0, 0, 0, 0};  // DFH_PROFILE_PREP: host seconds inside dfh_batch_prepare_rows, by section
@@ -1907,6 +1908,24 @@ int dfh_batch_destroy(dfh_batch* b) {
   return DFH_OK;
 }
 
+// page-locked staging of a batch object, sized for what the calling path puts there: a minibatch DESCRIBED by row numbers
+// needs offsets + labels + row numbers (~160 KB), dfh_batch_load_host the ids and values too (9 MB at C3's sizes — 2.4 ms
+// of hipHostMalloc each, which the worker loop's twelve batch objects paid on their first minibatch before round 4)
+static int ensure_stage(dfh_batch* b, size_t need) {
+  if (b->h_stage && b->stage_bytes >= need) return DFH_OK;
+  if (b->h_stage) {
+    if (b->staged_pending) DFH_HIP(hipEventSynchronize(b->ev_staged));
+    b->staged_pending = false;
+    DFH_HIP(hipHostFree(b->h_stage));
+    b->h_stage = nullptr;
+    b->d_stage_view = nullptr;
+  }
+  DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), need, hipHostMallocDefault));
+  b->stage_bytes = need;
+  if (!b->ev_staged) DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
+  return DFH_OK;
+}
+
 int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const uint64_t* index, const float* value,
                         const float* label) {
   DFH_ARG(b && offset && label, "dfh_batch_load_host: NULL argument");
@@ -1929,10 +1948,8 @@ int dfh_batch_load_host(dfh_batch* b, size_t nrows, const size_t* offset, const 
   // alternately the transfer of minibatch t+1 overlaps the training of minibatch t.
   const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
                o_val = o_idx + b->max_nnz * 8, total = o_val + b->max_nnz * 4;
-  if (!b->h_stage) {
-    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), total, hipHostMallocDefault));
-    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
-  }
+  rc = ensure_stage(b, total);
+  if (rc) return rc;
   if (b->staged_pending) {  // the previous minibatch staged here has long left; this wait is a formality
     // (a query first: hipEventSynchronize costs ~100 us of host time even on an event that completed long ago)
     if (hipEventQuery(b->ev_staged) != hipSuccess) DFH_HIP(hipEventSynchronize(b->ev_staged));
@@ -2229,10 +2246,9 @@ int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, cons
   // offsets, labels and row numbers through the batch's pinned staging (the row numbers where load_host puts the ids)
   const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
                o_val = o_idx + b->max_nnz * 8, stage_total = o_val + b->max_nnz * 4;
-  if (!b->h_stage) {
-    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), stage_total, hipHostMallocDefault));
-    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
-  }
+  (void)stage_total;   // (the layout of dfh_batch_load_host; only the head of it is used here)
+  rc = ensure_stage(b, o_idx + (b->max_rows + 1) * 4);
+  if (rc) return rc;
   if (b->staged_pending) {
     // (a query first: hipEventSynchronize costs ~100 us of host time even on an event that completed long ago)
     if (hipEventQuery(b->ev_staged) != hipSuccess) DFH_HIP(hipEventSynchronize(b->ev_staged));
@@ -2502,10 +2518,9 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   // the same page-locked block as dfh_batch_load_host / dfh_batch_gather_rows: offsets | labels | (ids ->) row numbers
   const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
                o_val = o_idx + b->max_nnz * 8, stage_total = o_val + b->max_nnz * 4;
-  if (!b->h_stage) {
-    DFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), stage_total, hipHostMallocDefault));
-    DFH_HIP(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
-  }
+  (void)stage_total;   // (the layout of dfh_batch_load_host; only the head of it is used here)
+  rc = ensure_stage(b, o_idx + (b->max_rows + 1) * 4);
+  if (rc) return rc;
   if (!b->d_stage_view) DFH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_stage_view), b->h_stage, 0));
   lap(0);  // set-up, prep_begin (wait for the batch object's previous step)
   if (b->staged_pending) {

@@ -135,4 +135,29 @@ long ingest_read(const char* uri, const char* format, unsigned part, unsigned np
   return static_cast<long>(rows);
 }
 
+/**
+ * CriteoChunkParser on a buffer: mode 0 = the plain loop (ParseSlow), 1 = ParseFast (regular rows through the vector
+ * scan, everything else through the same ParseRow), 2 = whichever Parse() picks on this CPU.  Returns the number of
+ * rows, -1 when a capacity is too small, -2 when mode 1 is asked for on a CPU without AVX2 / BMI / POPCNT.
+ */
+long ingest_parse_criteo(const char* text, size_t len, int is_train, int mode, size_t row_cap, size_t nnz_cap, size_t* offset,
+                         float* label, uint64_t* index) {
+  RowChunk c;
+  c.Clear();
+  if (mode == 1) {
+    if (!(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt"))) return -2;
+    CriteoChunkParser::ParseFast(text, text + len, is_train != 0, &c);
+  } else if (mode == 0) {
+    CriteoChunkParser::ParseSlow(text, text + len, is_train != 0, &c);
+  } else {
+    CriteoChunkParser::Parse(text, text + len, is_train != 0, &c);
+  }
+  if (c.label.size() > row_cap || c.index.size() > nnz_cap) return -1;
+  if (c.offset.size() != c.label.size() + 1) return -3;
+  memcpy(offset, c.offset.data(), c.offset.size() * sizeof(size_t));
+  memcpy(label, c.label.data(), c.label.size() * sizeof(float));
+  memcpy(index, c.index.data(), c.index.size() * sizeof(uint64_t));
+  return static_cast<long>(c.label.size());
+}
+
 }  // extern "C"

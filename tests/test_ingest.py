@@ -490,3 +490,72 @@ def test_reference_format_code_live_when_built(ing, tmp_path):
     for n in list(range(0, 80)) + [127, 128, 129, 255, 256, 1000]:
         s = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
         assert R.city_checker_hash64(s) == ing.ingest_cityhash64(s, n) == oi.cityhash64(s), n
+
+
+def _parse_criteo_mode(L, text, train, mode):
+    L.ingest_parse_criteo.restype = C.c_long
+    L.ingest_parse_criteo.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    cap_rows, cap_nnz = text.count(b"\n") + 2, 40 * (text.count(b"\n") + 2)
+    off = np.zeros(cap_rows + 1, np.uint64)
+    lab = np.zeros(cap_rows, np.float32)
+    idx = np.zeros(cap_nnz, np.uint64)
+    # the text sits at the very end of its own allocation (no slack behind it): ParseFast's 8-byte loads must stay inside
+    buf = C.create_string_buffer(text, len(text)) if text else C.create_string_buffer(1)
+    n = L.ingest_parse_criteo(buf, len(text), int(train), mode, cap_rows, cap_nnz, off.ctypes.data, lab.ctypes.data, idx.ctypes.data)
+    if n == -2:
+        pytest.skip("no AVX2 / BMI / POPCNT on this CPU: Parse() keeps the plain loop")
+    assert n >= 0, n
+    return off[:n + 1].copy(), lab[:n].copy(), idx[:int(off[n])].copy()
+
+
+def test_criteo_fast_parser_equals_the_plain_loop(ing):
+    """CriteoChunkParser::ParseFast (vector scan for '\\t' / '\\n', straight-line CityHash for 1-7 and 8 bytes) takes the rows
+    it recognises as regular and leaves every other row to the reference-shaped ParseRow: same rows, labels and ids as
+    ParseSlow on the golden texts of the reference's parser (CRLF, short rows, blank lines, no final newline) and on
+    fuzzed text — rows that span scan windows, long integer tokens, junk in integer fields, rows short of fields"""
+    from oracle import ingest as oi
+    g = np.load(GOLDEN_INGEST)
+    i = 0
+    while "criteo_text_%d" % i in g:
+        text = g["criteo_text_%d" % i].tobytes()
+        train = bool(g["criteo_%d_train" % i])
+        for mode in (0, 1, 2):
+            off, lab, idx = _parse_criteo_mode(ing, text, train, mode)
+            assert np.array_equal(off, g["criteo_%d_offset" % i]) and np.array_equal(lab, g["criteo_%d_label" % i]), (i, mode)
+            assert np.array_equal(idx, g["criteo_%d_index" % i]), (i, mode)
+        i += 1
+    rng = np.random.default_rng(41)
+    labels = [b"1", b"0", b"0.5", b"-1", b"12", b"1e0"]
+    nrows_total = 0
+    for it in range(160):
+        train = it % 5 != 0
+        flavour = it % 8      # 5: CRLF, 6: rows short of categorical fields + junk in integer fields, 7: no final newline
+        rows = int(rng.integers(1, 700 if it % 16 == 0 else 60))
+        lines = []
+        for r in range(rows):
+            if rng.integers(17) == 0:
+                lines.append(b"")   # blank line
+            f = [labels[int(rng.integers(len(labels)))]] if train else []
+            weird = flavour == 6 and rng.integers(3) == 0
+            for _ in range(13):
+                tok = b""
+                if rng.integers(4):
+                    tok = str(int(rng.integers(10 ** 12)))[:int(rng.integers(1, 13))].encode()
+                    if rng.integers(9) == 0:
+                        tok = b"-" + tok
+                    if weird and rng.integers(7) == 0:
+                        tok += b" x"
+                f.append(tok)
+            ncat = int(rng.integers(1, 26)) if weird and rng.integers(2) else 26   # (>= 1: the 13th integer field ends with a tab)
+            f += [b"%08x" % int(rng.integers(1 << 32)) if rng.integers(6) else b"" for _ in range(ncat)]
+            lines.append(b"\t".join(f))
+        eol = b"\r\n" if flavour == 5 else b"\n"
+        text = eol.join(lines) + (b"" if flavour == 7 else eol)
+        a = _parse_criteo_mode(ing, text, train, 0)
+        b = _parse_criteo_mode(ing, text, train, 1)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), (it, flavour)
+        nrows_total += len(a[1])
+        if flavour < 5 and it % 4 == 0:   # regular text: the Python transcription agrees too
+            off, lab, idx = oi.parse_criteo(text, is_train=train)
+            assert np.array_equal(a[0], off) and np.array_equal(a[1], lab) and np.array_equal(a[2], idx)
+    assert nrows_total > 3000

@@ -5,7 +5,7 @@ with the C3 hyper-parameters.  Every format is run on the generated file (`rows`
 repeated `rep` times; the difference of the two wall times over the difference of the row counts is the
 steady-state rate (process start, table allocation and the first-touch costs cancel).
 usage: e2e_cli.py [rows [rep]] -> one JSON object per format on stdout"""
-import json, os, subprocess, sys, tempfile, time
+import json, os, re, subprocess, sys, tempfile, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -51,10 +51,14 @@ def run(path, fmt):
                        capture_output=True, text=True, timeout=900, env=env)
     dt = time.time() - t0
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
+    loop_s = None
     for l in r.stderr.splitlines():
         if "host loop over" in l or "reader: " in l or "batch reader" in l:   # DIFACTO_PROFILE=1
             sys.stderr.write(fmt + " " + exe + ": " + l.split("INFO")[-1].strip() + "\n")
-    return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:])
+        m = re.search(r"host loop over (\d+) minibatches: reader ([0-9.e+-]+) s, stage \+ localize \+ lookup ([0-9.e+-]+) s.*step ([0-9.e+-]+) s", l)
+        if m:   # the worker loop's own clock: process start, HIP initialisation and the table allocation are outside it
+            loop_s = float(m.group(2)) + float(m.group(3)) + float(m.group(4))
+    return dt, r.returncode, (loss[-1].split("INFO")[-1].strip() if loss else r.stderr[-300:]), loop_s
 
 
 for fmt in os.environ.get("E2E_FORMATS", "criteo,libsvm,rec").split(","):
@@ -66,11 +70,19 @@ for fmt in os.environ.get("E2E_FORMATS", "criteo,libsvm,rec").split(","):
             out.write(blob)
     for exe in EXES:
         # the faster of two runs each: the difference of two wall times is sensitive to a hiccup in either
-        dt1, rc1, line1 = min(run(path, fmt), run(path, fmt))
-        dt2, rc2, line2 = min(run(big, fmt), run(big, fmt))
+        runs1 = [run(path, fmt) for _ in range(3)]
+        runs2 = [run(big, fmt) for _ in range(3)]
+        dt1, rc1, line1, _ = min(runs1)
+        dt2, rc2, line2, _ = min(runs2)
         steady = rows * (rep - 1) / max(dt2 - dt1, 1e-9)
+        # the same difference by the worker loop's own clock (DIFACTO_PROFILE=1): the wall times carry ~0.4 s of process
+        # start whose run-to-run spread (+-0.1 s) is as large as the epoch itself
+        l1 = [x[3] for x in runs1 if x[3] is not None]
+        l2 = [x[3] for x in runs2 if x[3] is not None]
+        loop = dict(loop_s=min(l1), loop_s_big=min(l2), loop_rows_per_s_big=rows * rep / min(l2),
+                    steady_rows_per_s_by_loop_clock=rows * (rep - 1) / max(min(l2) - min(l1), 1e-9)) if l1 and l2 else {}
         print(json.dumps(dict(format=fmt, exe=exe, rows=rows, file_mb=os.path.getsize(path) / 1e6, wall_s=dt1, rows_per_s=rows / dt1,
                               rc=rc1, line=line1, rows_big=rows * rep, wall_s_big=dt2, rows_per_s_big=rows * rep / dt2, rc_big=rc2,
-                              steady_rows_per_s=steady, steady_mb_per_s=steady * os.path.getsize(path) / rows / 1e6, line_big=line2)),
+                              steady_rows_per_s=steady, steady_mb_per_s=steady * os.path.getsize(path) / rows / 1e6, line_big=line2, **loop)),
               flush=True)
     os.remove(big)

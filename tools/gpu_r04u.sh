@@ -28,8 +28,9 @@ ARGS="data_format=rec task=train learner=sgd batch_size=10000 max_num_epochs=1 V
 run() {  # name env...
   n=$1; shift
   for f in small big big; do
-    /usr/bin/time -f "$n $f wall %e s" env "$@" $R/build/difacto data_in=/tmp/$f.rec $ARGS > $O/run_${n}_$f.log 2>&1
-    tail -1 $O/run_${n}_$f.log
+    t0=$(date +%s.%N)
+    env "$@" $R/build/difacto data_in=/tmp/$f.rec $ARGS > $O/run_${n}_$f.log 2>&1
+    echo "$n $f wall $(python3 -c "import time,sys; print(round(time.time()-float(sys.argv[1]),3))" $t0) s"
   done
   grep -hE "host loop|reader: |prepare_rows x|load_host x|batch reader" $O/run_${n}_big.log | sed 's/.*\] //' | cut -c1-330 | sort | uniq -c | sort -rn | head -12
 }
