@@ -595,16 +595,33 @@ class Reader {
       LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test and rec)";
     }
     if (nthreads <= 0) {
-      // DIFACTO_PARSER_THREADS, else an eighth of the hardware threads (several readers may be alive: one per
-      // rank of a node, a training and a validation reader), at least 1, at most 16 (round 4, 256-thread host:
-      // 32 / 48 threads parse SLOWER — 9 / 16 s of summed parsing time against 6.4 s for the same criteo text — and the
-      // end-to-end rate drops with them)
+      // DIFACTO_PARSER_THREADS, else an eighth of the CPUs this process may use (several readers may be alive: one per
+      // rank of a node, a training and a validation reader), at least 1, at most 16.  "May use" = the hardware threads
+      // or the container's CPU-time quota, whichever is smaller: the GPU boxes of this build give a container 16 cores'
+      // worth (cgroup cpu.max "1600000 100000") of a 256-thread host, and threads beyond the quota only get the whole
+      // process throttled (round 4: 32 / 48 parser threads there summed to 9 / 16 s of parsing against 6.4 s with 16,
+      // end to end -25 %; 8 .. 16 threads are within 3 % of each other since the parsers got faster)
       const char* e = getenv("DIFACTO_PARSER_THREADS");
-      nthreads = e ? atoi(e) : static_cast<int>(std::thread::hardware_concurrency() / 8);
+      nthreads = e ? atoi(e) : std::max(static_cast<int>(std::thread::hardware_concurrency() / 8), 1);
+      if (!e) nthreads = std::min(nthreads, std::max(1, QuotaCpus() - 4));   // the loop, the uploads and the cutters run too
       nthreads = std::max(1, std::min(nthreads, 16));
     }
     slots_.resize(2 * static_cast<size_t>(nthreads));
     for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { Work(); });
+  }
+  /*! \brief CPUs' worth of time the container's cgroup allows (cgroup v2 cpu.max "quota period"), or the hardware threads */
+  static int QuotaCpus() {
+    int cpus = static_cast<int>(std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32];
+      long period = 0;
+      if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+        const long quota = atol(q);
+        if (quota > 0) cpus = std::min<long>(cpus, std::max<long>(1, (quota + period - 1) / period));
+      }
+      fclose(f);
+    }
+    return std::max(cpus, 1);
   }
   ~Reader() {
     {

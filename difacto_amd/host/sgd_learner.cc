@@ -336,7 +336,13 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   const bool push_cnt = train && job.epoch == 0;  // sgd_learner.cc:201-202
   dfh_ctx* ctx = DeviceContext::Get();
   dfh_table* table = GetUpdater()->table();
-  DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
+  // preparation streams (DIFACTO_PREP_STREAMS=1..4).  With the device feed the preparation of a minibatch is the row gather
+  // + Localizer + probe — a chain as long as the step itself — and two streams let consecutive preparations overlap:
+  // same box, by this loop's clock, .rec 53.6 -> 59.4 and criteo text 48.0 -> 50.6 M rows/s (tools/gpu_r04x.sh).  bench.py,
+  // whose inputs are already in HBM (no gather), loses 5 % with two: it keeps one
+  const char* ps = getenv("DIFACTO_PREP_STREAMS");
+  const bool feed_wanted = job.type == sgd::Job::kTraining && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
+  DFH_CALL(dfh_ctx_set_pipeline(ctx, ps ? std::max(1, std::min(atoi(ps), 4)) : (feed_wanted ? 2 : 1)));
   // minibatches are cut (permutation + row selection) two ahead on the reader's own thread, the reference's reader /
   // executor overlap (sgd_learner.cc:196-224).  Training with a shuffle buffer: the buffers go to HBM and the rows are
   // gathered there (device feed; DIFACTO_HOST_FEED=1 keeps the host-side gather)
