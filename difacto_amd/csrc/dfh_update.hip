@@ -104,6 +104,37 @@ __device__ __forceinline__ uint32_t ld_rowword(const uint2* p) {  // .x of {row 
   return DFH_UPD_NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)) : p->x;
 }
 
+// Keys whose V row is to be initialised (lazy InitV, hash mode) by this block: noted by the lane that takes the decision
+// (upd_apply), written by the whole block once its role is through (upd_init_rows) — 16 B of V and of the accumulators per
+// lane instead of one lane's 2 kp scalar stores, and outside the roles' loops, whose register budget it does not touch
+// (written inline at the end of upd_apply the same stores cost the warm step 1.4 %).  One array per block in LDS.
+constexpr uint32_t UPD_INIT_CAP = 511;
+__device__ __forceinline__ uint32_t* upd_init_list() {
+  __shared__ uint32_t list[1 + UPD_INIT_CAP];  // [0]: entries noted (may exceed the capacity: the surplus was written inline)
+  return list;
+}
+__device__ __forceinline__ void upd_init_rows(const UpdArgs& a, int L) {
+  __syncthreads();
+  const uint32_t* il = upd_init_list();
+  const uint32_t n = min(il[0], UPD_INIT_CAP);
+  const int k = a.k, kp = a.kp;
+  for (uint32_t e = threadIdx.x / L; e < n; e += UPD_THREADS / L) {
+    const uint32_t u = il[1 + e];
+    const uint32_t r = a.uw[u].x & kRowMask;
+    const uint64_t key = a.feaids[u];
+    float* va = a.va + (size_t)r * (size_t)(2 * kp);
+    for (int d0 = (threadIdx.x % L) * 4; d0 < kp; d0 += L * 4) {
+      float4 nv;
+      nv.x = d0 + 0 < k ? hash_init_value(key, d0 + 0, a.p.seed, a.p.V_init_scale) : 0.f;
+      nv.y = d0 + 1 < k ? hash_init_value(key, d0 + 1, a.p.seed, a.p.V_init_scale) : 0.f;
+      nv.z = d0 + 2 < k ? hash_init_value(key, d0 + 2, a.p.seed, a.p.V_init_scale) : 0.f;
+      nv.w = d0 + 3 < k ? hash_init_value(key, d0 + 3, a.p.seed, a.p.V_init_scale) : 0.f;
+      st4_nt(va + d0, nv);
+      st4_nt(va + kp + d0, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
 // SGDUpdater::Update(kGradient) for one key whose sums are complete: executed by the L lanes of ONE
 // group (the caller masks the others).  h0 = {w, has_V, sqrt_g, z}; vv / ac: this lane's V and
 // accumulator slices; g4: sum of (XV p) x over the occurrences.
@@ -132,10 +163,19 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
     // lazy InitV when w leaves zero (sgd_updater.cc:122-126); a key without V had its count pushed by k_lookup
     if (w_old == 0 && w_new != 0 && k > 0 && !has_v && fc > (float)a.p.V_threshold) {
       if (a.p.init_mode == DFH_INIT_HASH) {
-        const uint64_t key = a.feaids[u];
-        for (int j = 0; j < kp; ++j) {
-          va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
-          va[kp + j] = 0.0f;
+        // the row is written at the end of the block by all of its lanes (upd_init_rows); here only its name is noted.
+        // Until round 4 this lane wrote the row alone, 2 kp scalar stores behind 2 kp hashes: with every key of a
+        // minibatch new (an empty table's first steps) the launch took 147 us against 61 (profiles/r04t_cold_start.txt)
+        uint32_t* il = upd_init_list();
+        const uint32_t slot = atomicAdd(&il[0], 1u);
+        if (slot < UPD_INIT_CAP) {
+          il[1 + slot] = u;
+        } else {  // list full: as before
+          const uint64_t key = a.feaids[u];
+          for (int j = 0; j < kp; ++j) {
+            va[j] = j < k ? hash_init_value(key, j, a.p.seed, a.p.V_init_scale) : 0.0f;
+            va[kp + j] = 0.0f;
+          }
         }
         hv = 1u;
       } else {
@@ -492,6 +532,8 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
     if (blockIdx.x < auc_units(a.nrows)) auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_part);
     return;
   }
+  if (threadIdx.x == 0) upd_init_list()[0] = 0u;
+  __syncthreads();
   float pen = 0.f;
   const uint32_t w = threadIdx.x >> 6;
   // block -> role.  The list roles (hot, mid, few) are chains of dependent round trips on few bytes, the singles
@@ -534,6 +576,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
     if (DFH_UPD_ROLES & 4)
     upd_few_role<L, EXACT, HAS_VAL>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
   }
+  upd_init_rows(a, L);
   upd_flush_penalty(a.prog, pen);
 }
 

@@ -3,7 +3,7 @@
 # wavefront (find_or_insert) against one per key (tools/var_base_alloc.so = the tree before), same box; then the
 # warm default line of both, the sharded-store tests and the whole GPU suite on the final tree
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-O=$R/gpurun_out/r04t; mkdir -p $O; cd $R
+O=$R/gpurun_out/${OUT:-r04t}; mkdir -p $O; cd $R
 cp $R/difacto_amd/libdifacto_hip.so /tmp/keep.so
 line() {  # name args...
   n=$1; shift
@@ -17,7 +17,7 @@ except Exception as e: print('$n ERR', e); print(open('$O/b_$n.err').read()[-800
 }
 COLD="--no-prefill --warmup 0 --max-reps 1 --min-time 0 --no-timing"
 for v in new base; do
-  [ $v = base ] && cp $R/tools/var_base_alloc.so $R/difacto_amd/libdifacto_hip.so
+  [ $v = base ] && cp $R/tools/var_${VARIANT:-base_alloc}.so $R/difacto_amd/libdifacto_hip.so
   line cold16_$v $COLD --steps 16
   line cold64_$v $COLD --steps 64
   line cold256_$v $COLD --steps 256
