@@ -796,9 +796,12 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
     return DFH_ERR_HIP;
   }
   DFH_HIP(hipSetDevice(device));
-  // DFH_SCHEDULE_SPIN=1 (experiment, tools/gpu_r04u.sh): host waits poll instead of blocking on an interrupt
-  if (const char* e = getenv("DFH_SCHEDULE_SPIN"))
-    if (atoi(e) == 1 && hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
+  // DFH_SCHEDULE = spin | yield | blocking (experiment, tools/gpu_r04u.sh): how host threads wait for the device
+  if (const char* e = getenv("DFH_SCHEDULE")) {
+    const unsigned f = !strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield
+                       : !strcmp(e, "blocking") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+    if (hipSetDeviceFlags(f) != hipSuccess) (void)hipGetLastError();
+  }
   dfh_ctx* c = new (std::nothrow) dfh_ctx();
   DFH_ARG(c != nullptr, "out of host memory");
   c->device = device;

@@ -38,4 +38,4 @@ run plain A=1
 run prof DIFACTO_PROFILE=1 DFH_PROFILE_PREP=1
 run up1 DIFACTO_PROFILE=1 DIFACTO_UPLOAD_THREADS=1
 run up4 DIFACTO_PROFILE=1 DIFACTO_UPLOAD_THREADS=4
-run spin DIFACTO_PROFILE=1 DFH_SCHEDULE_SPIN=1
+run spin DIFACTO_PROFILE=1 DFH_SCHEDULE=spin
