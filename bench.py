@@ -165,7 +165,16 @@ def host_info():
                 break
     except OSError:
         pass
-    return dict(nproc=os.cpu_count(), cpu_model=model)
+    # the CPU time the container may use (cgroup v2 cpu.max "quota period"): the GPU boxes of this build allow 16 cores' worth
+    # of a 256-thread host, and threads beyond the quota only get the process throttled
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(period) > 0:
+            quota = max(1, -(-int(q) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return dict(nproc=os.cpu_count(), cpu_quota=quota, cpu_model=model)
 
 
 def cpu_baseline(batches, V_dim, nbatches, hyper, with_auc=True):
@@ -174,7 +183,7 @@ def cpu_baseline(batches, V_dim, nbatches, hyper, with_auc=True):
     sample is `nbatches` batches of the GPU run's own stream; a first, untimed pass over them fills
     the model (every touched key gets its entry, state and V row, like the GPU's pre-filled table),
     the timed pass is the second.  Two thread settings: as shipped (2 OpenMP threads in
-    the loss and the Localizer, single-threaded updater) and scaled to the host (min(nproc, 49))."""
+    the loss and the Localizer, single-threaded updater) and scaled to the host (min(nproc, the container's CPU quota, 49))."""
     from oracle import bindings as ob
     info = host_info()
     kind = "reference" if ob.have_ref() else "port"
@@ -196,7 +205,7 @@ def cpu_baseline(batches, V_dim, nbatches, hyper, with_auc=True):
         return dict(value=rows / t_total, unit="examples/sec", cores=1, kind=kind, sample=sample, **info)
     R = ob.Ref()
     out = None
-    for label, nthreads in (("as_shipped", 2), ("scaled", max(2, min(info["nproc"] or 2, 49)))):
+    for label, nthreads in (("as_shipped", 2), ("scaled", max(2, min(info["nproc"] or 2, info["cpu_quota"] or 49, 49)))):
         st = R.store_create(V_dim=V_dim, **hyper)
         stage = dict(localize=0.0, push_count=0.0, pull=0.0, predict_calcgrad=0.0, evaluate_auc=0.0, push_grad=0.0)
         rows = 0
