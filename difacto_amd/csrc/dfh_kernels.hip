@@ -240,6 +240,18 @@ __device__ __forceinline__ void init_v_hash_row(const TableView& t, uint32_t r, 
   }
 }
 
+// the same for one lane's 16 B slice (coordinates d .. d + 3, d < kp) of a row that a whole lane group initialises
+__device__ __forceinline__ void init_v_hash_slice(const TableView& t, uint32_t r, uint64_t key, int d) {
+  float* va = t.va + (size_t)r * (2 * t.kp);
+  float4 nv;
+  nv.x = d + 0 < t.k ? hash_init_value(key, d + 0, t.p.seed, t.p.V_init_scale) : 0.0f;
+  nv.y = d + 1 < t.k ? hash_init_value(key, d + 1, t.p.seed, t.p.V_init_scale) : 0.0f;
+  nv.z = d + 2 < t.k ? hash_init_value(key, d + 2, t.p.seed, t.p.V_init_scale) : 0.0f;
+  nv.w = d + 3 < t.k ? hash_init_value(key, d + 3, t.p.seed, t.p.V_init_scale) : 0.0f;
+  st4(va + d, nv);
+  st4(va + t.kp + d, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
 #ifndef DFH_BWD_SMALL
 #define DFH_BWD_SMALL 8
 #endif
@@ -1618,7 +1630,9 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
       // lazy InitV when w leaves zero (sgd_updater.cc:122-126); the pulled rows had no V, so no
       // gradient of this step touches the fresh values
       if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
-        if (sub == 0) init_v_hash_row(t, r, key);
+        // every lane of the group reaches this with the same w: each writes its own 16 B of V and of the accumulators
+        // (one lane alone: 2 kp scalar stores behind 2 kp hashes, see upd_init_rows in dfh_update.hip)
+        if (d_ok) init_v_hash_slice(t, r, key, d);
         has_v = 1;
       }
       if (had_v && d_ok) {

@@ -559,3 +559,20 @@ def test_criteo_fast_parser_equals_the_plain_loop(ing):
             off, lab, idx = oi.parse_criteo(text, is_train=train)
             assert np.array_equal(a[0], off) and np.array_equal(a[1], lab) and np.array_equal(a[2], idx)
     assert nrows_total > 3000
+    # the fast path's own corner cases: (i) CRLF appearing only late in a chunk (regular rows before it went through the vector
+    # scan, everything from the first '\r' on goes through ParseRow); (ii) an integer field longer than a scan window (16 KB:
+    # the row's line end is not in sight after one scan); (iii) rows whose line end sits in the last 8 bytes of the buffer
+    def row(train=True, eol=b"\n", long_int=0):
+        f = [b"1"] if train else []
+        f += [b"7" * long_int if (i == 3 and long_int) else (b"%d" % (i * 37)) for i in range(13)]
+        f += [b"%08x" % (0x9e3779b9 * (i + 1) & 0xffffffff) for i in range(26)]
+        return b"\t".join(f) + eol
+    texts = [row() * 900 + row(eol=b"\r\n") * 40 + row() * 10,
+             row() * 30 + row(long_int=20000) + row() * 30 + row(long_int=40000) + row() * 5,
+             row() * 3 + row()[:-9] + b"\n",                      # last row short of one categorical field, '\n' at the very end
+             row() * 3 + row(eol=b"")]                              # no final newline: the last row ends with the buffer
+    for t_i, text in enumerate(texts):
+        a = _parse_criteo_mode(ing, text, True, 0)
+        b = _parse_criteo_mode(ing, text, True, 1)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), t_i
+        assert len(a[1]) == text.count(b"\n") + (0 if text.endswith(b"\n") else 1)
