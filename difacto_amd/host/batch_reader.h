@@ -177,16 +177,28 @@ class LibsvmChunkParser : public ChunkParser {
     for (;;) {
       while (p < eol && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
       if (p >= eol) break;
-      const feaid_t id = strtoull(p, &e, 10);
-      CHECK(e != p && e <= eol) << "bad libsvm token in: " << std::string(p, eol - p);
-      p = e;
+      // 1 .. 19 plain digits (what every id is): read in place — strtoull gives the same number for them and is called
+      // for everything else (a sign, 20+ digits with its overflow rule, garbage with its error)
+      feaid_t id = 0;
+      const char* q = p;
+      while (q < eol && static_cast<unsigned>(*q - '0') < 10u) id = id * 10 + static_cast<feaid_t>(*q++ - '0');
+      if (q == p || q - p > 19) {
+        id = strtoull(p, &e, 10);
+        CHECK(e != p && e <= eol) << "bad libsvm token in: " << std::string(p, eol - p);
+        q = e;
+      }
+      p = q;
       float v = 1.0f;
       if (p < eol && *p == ':') {
         ++p;
         CHECK(p < eol && !isspace(static_cast<unsigned char>(*p))) << "libsvm feature " << id << " has no value after ':'";
-        v = strtof(p, &e);
-        CHECK(e != p && e <= eol) << "bad libsvm value of feature " << id;
-        p = e;
+        if (*p == '1' && (p + 1 == eol || p[1] == ' ' || p[1] == '\t' || p[1] == '\r')) {   // ":1", the binary files' value
+          ++p;
+        } else {
+          v = strtof(p, &e);
+          CHECK(e != p && e <= eol) << "bad libsvm value of feature " << id;
+          p = e;
+        }
       }
       out->index.push_back(id);
       out->value.push_back(v);
