@@ -808,12 +808,15 @@ def test_device_row_gather_matches_host_load(capi, oracle, streams):
              [(1, rng.permutation(500)[:150])], [(1, rng.permutation(500)[:60]), (0, np.array([5, 5, 7, 5]))],
              [(2, np.arange(300))]]
     results = []
-    for device in (False, True, "one_call"):
+    for mode in (False, True, "one_call", "alternating"):
         tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_HASH, **kw)
         bt = capi.Batch(ctx, 400, 400 * 40)
         out = []
         for step, segments in enumerate(plans * 2):
             mb = host_minibatch(segments)
+            # "alternating": the three ways in turn on ONE batch object — its page-locked staging is sized by the path that
+            # uses it (a described minibatch needs the offsets, labels and row numbers only) and grows under a pending read
+            device = ("one_call", False, True)[step % 3] if mode == "alternating" else mode
             if device == "one_call":   # dfh_batch_prepare_rows: gather (description read in place) + Localizer + key lookup
                 bt.prepare_rows(tb, mb["offset"], mb["label"], [(rbs[g], rows) for g, rows in segments])
             elif device:
@@ -824,7 +827,7 @@ def test_device_row_gather_matches_host_load(capi, oracle, streams):
                 bt.localize()
             got = bt.get_localized()
             want = oracle.localize(mb["offset"], mb["index"])
-            assert np.array_equal(got["feaids"], want["feaids"]) and np.array_equal(got["index"], want["index"]), (device, step)
+            assert np.array_equal(got["feaids"], want["feaids"]) and np.array_equal(got["index"], want["index"]), (mode, step)
             bt.sgd_step(tb, is_train=True, push_cnt=step < len(plans))
             out.append(bt.pred())
         keys = np.unique(np.concatenate([hb["index"] for hb in bufs_host]))
