@@ -4,11 +4,12 @@
  *
  * The reference hashes every criteo token with it (src/reader/criteo_parser.h:96-101, behind
  * USE_CITY=1; the library is the third-party dependency cityhash 1.1.1 that dmlc-core's build
- * downloads — absent here, like dmlc-core itself, and there is no network).  Parity status: the
- * implementation is pinned only to the one known answer available offline, CityHash64("") = k2 =
- * 0x9ae16a3b2f90404f; criteo tokens are 1-16 bytes long and take the HashLen0to16 branch only.
- * tests/test_ingest.py checks this file against an independent Python transcription of the same
- * published algorithm (oracle/cityhash.py) on all length classes: "parity unpinned" beyond that.
+ * downloads — absent here, like dmlc-core itself, and there is no network).  Parity status: pinned
+ * (round 4) to Google's own code of the algorithm found in the image — Abseil's
+ * hash_internal::CityHash64 (CityHash v1.1) inside pyarrow's libarrow_compute.so — on every length
+ * class (tests/test_ingest.py::test_cityhash64_against_abseil), besides the published constant
+ * CityHash64("") = k2 = 0x9ae16a3b2f90404f and an independent Python transcription (oracle/ingest.py).
+ * Criteo tokens are 1-16 bytes long and take the HashLen0to16 branch only.
  */
 #ifndef DIFACTO_HOST_CITYHASH_H_
 #define DIFACTO_HOST_CITYHASH_H_

@@ -1,9 +1,10 @@
 // oracle/city_checker.cc — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 // CityHash64 (Google cityhash v1.1, city.cc) restated from the published algorithm for the checker side:
 // it serves `CityHash64` to the reference's criteo parser compiled into oracle/_ref (ref_shim/city.h).
-// Parity status: UNPINNED beyond the published constant CityHash64("") == k2 — the library is absent from this
-// image and the reference holds no vectors for it; the tests cross-check this text, the Python transcription in
-// oracle/ingest.py and the product's host/cityhash.h against each other.
+// Parity status: the library is absent from this image and the reference holds no vectors for it; the tests
+// cross-check this text, the Python transcription in oracle/ingest.py and the product's host/cityhash.h against each
+// other, and (round 4) the latter two against Abseil's hash_internal::CityHash64 — Google's code of CityHash v1.1,
+// found inside pyarrow's libarrow_compute.so — on every length class (tests/test_ingest.py).
 #include <cstdint>
 #include <cstring>
 #include <utility>

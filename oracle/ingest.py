@@ -3,8 +3,9 @@
 
   cityhash64(bytes)       CityHash64 v1.1, transcribed from the published algorithm (the third-party
                           dependency cityhash 1.1.1 of the reference — pulled by dmlc-core's build — is
-                          absent here).  Pinned to the one known answer available offline,
-                          CityHash64(b"") = 0x9ae16a3b2f90404f: PARITY UNPINNED beyond that.
+                          absent here).  Pinned since round 4 to Google's own code of the algorithm: Abseil's
+                          hash_internal::CityHash64 (CityHash v1.1), exported by pyarrow's libarrow_compute.so in
+                          this image — tests/test_ingest.py::test_cityhash64_against_abseil, every length class.
   parse_criteo(text)      CriteoParser::ParseNext (/root/reference/src/reader/criteo_parser.h:40-94)
   lz4_compress(bytes)     LZ4_compress_default of the REAL liblz4 present in this image (ctypes): fixtures
                           for the from-scratch decoder, so that one IS pinned to the library the reference links

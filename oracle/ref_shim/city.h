@@ -3,8 +3,9 @@
 // installed on this image, so the declaration is served by oracle/city_checker.cc, a
 // from-scratch transcription of the published CityHash64 v1.1 algorithm kept on the checker side.  It is
 // independent text from the product's difacto_amd/host/cityhash.h; the tests compare the two (and the Python
-// transcription in oracle/ingest.py).  CityHash64 itself stays UNPINNED beyond CityHash64("") = k2: no
-// reference build of the library and no published vectors exist here.
+// transcription in oracle/ingest.py).  The library itself is absent, but Google's code of the same algorithm is in
+// the image (Abseil's hash_internal::CityHash64 inside pyarrow's libarrow_compute.so): the product's and the Python
+// transcription are pinned to it (tests/test_ingest.py::test_cityhash64_against_abseil), this one through them.
 #ifndef ORACLE_REF_SHIM_CITY_H_
 #define ORACLE_REF_SHIM_CITY_H_
 #include <cstddef>

@@ -55,6 +55,57 @@ def test_cityhash64_known_answer_and_transcription(ing):
         assert ing.ingest_cityhash64(tok, len(tok)) == oi.cityhash64(tok)
 
 
+def _abseil_cityhash64():
+    """Google's own CityHash64 as compiled into this image: Abseil's hash_internal::CityHash64 (absl/hash/internal/city.cc,
+    the CityHash v1.1 code) is exported by pyarrow's libarrow_compute.so.  None when it cannot be found."""
+    import re
+    import subprocess
+    try:
+        import pyarrow
+        import pyarrow.compute  # noqa: F401  (loads libarrow.so, which libarrow_compute.so needs)
+        d = os.path.dirname(pyarrow.__file__)
+        for name in sorted(os.listdir(d)):
+            if not name.startswith("libarrow_compute.so"):
+                continue
+            path = os.path.join(d, name)
+            syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, timeout=60).stdout
+            for line in syms.splitlines():
+                if re.search(r"hash_internal10CityHash64EPKcm$", line):
+                    f = getattr(C.CDLL(path), line.split()[-1])
+                    f.restype = C.c_uint64
+                    f.argtypes = [C.c_char_p, C.c_size_t]
+                    return f
+    except Exception:  # noqa: BLE001
+        return None
+    return None
+
+
+def test_cityhash64_against_abseil(ing):
+    """pins CityHash64 beyond the one published constant: the product's implementation (difacto_amd/host/cityhash.h) and
+    the checker's transcription (oracle/ingest.py) against Google's own code of the same algorithm — Abseil's
+    hash_internal::CityHash64, CityHash v1.1 (what cityhash 1.1.1, the reference's dependency, computes) — on every
+    length class: 0-16, 17-32, 33-64 and the 64-byte loop, plus the tokens a criteo row is made of"""
+    from oracle import ingest as oi
+    ref = _abseil_cityhash64()
+    if ref is None:
+        pytest.skip("no Abseil CityHash64 symbol in this image (pyarrow's libarrow_compute.so)")
+    assert ref(b"", 0) == 0x9ae16a3b2f90404f
+    rng = np.random.default_rng(17)
+    n = 0
+    for ln in list(range(0, 260)) + [511, 512, 513, 1000, 4097]:
+        for _ in range(4):
+            s = rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes()
+            want = ref(s, ln)
+            assert ing.ingest_cityhash64(s, ln) == want, ln
+            if ln <= 80 or ln % 64 < 2:
+                assert oi.cityhash64(s) == want, ln
+            n += 1
+    for tok in [b"%d" % v for v in list(range(0, 1200, 7)) + [-1, -2, 10 ** 6, 2 ** 31, 10 ** 12]] + \
+               [b"%08x" % v for v in rng.integers(0, 1 << 32, size=300)]:
+        assert ing.ingest_cityhash64(tok, len(tok)) == ref(tok, len(tok)) == oi.cityhash64(tok)
+    assert n > 1000
+
+
 def test_lz4_block_decoder_against_liblz4(ing):
     from oracle import ingest as oi
     rng = np.random.default_rng(5)
@@ -388,8 +439,8 @@ def test_parser_pool_keeps_file_order(ing, tmp_path, monkeypatch, threads):
 # pinned to the REFERENCE'S OWN format code: tests/golden/ref_ingest.npz was written by
 # tools/make_golden_ingest.py through oracle/_ref = the reference's CompressedRowBlock::Compress
 # (src/data/compressed_row_block.h:23-50) and CriteoParser::ParseNext (src/reader/criteo_parser.h:40-94).
-# RecordIO framing (dmlc-core, absent) stays checked against oracle/ingest.py only; CityHash64 is unpinned
-# beyond k2 (three independent transcriptions agree: host/cityhash.h, oracle/ingest.py, oracle/city_checker.cc).
+# RecordIO framing (dmlc-core, absent) stays checked against oracle/ingest.py only; CityHash64 is pinned to Abseil's
+# copy of Google's code (test_cityhash64_against_abseil), the three transcriptions here agree with each other.
 # ---------------------------------------------------------------------------------------------------------
 GOLDEN_INGEST = os.path.join(ROOT, "tests", "golden", "ref_ingest.npz")
 
@@ -430,7 +481,7 @@ def test_rec_reader_on_blocks_compressed_by_the_reference(ing, tmp_path):
 def test_criteo_parser_on_the_reference_parsers_output(ing, tmp_path):
     """CriteoChunkParser against what the reference's CriteoParser::ParseNext made of the same text (golden fixture):
     missing fields, rows short of categorical features, CRLF, blank lines, a chunk ending without a newline, odd
-    labels and integer tokens, the criteo_test format.  (CityHash64: unpinned beyond k2 — the ids pin the slot tag,
+    labels and integer tokens, the criteo_test format.  (CityHash64 itself: test_cityhash64_against_abseil — the ids here pin the slot tag,
     the field splitting and the row cutting.)"""
     g = np.load(GOLDEN_INGEST)
     i = 0

@@ -7,6 +7,8 @@ reference build (oracle/_ref) to the reference's OWN golden vectors:
 
 and the oracle to the reference itself on random inputs.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -267,3 +269,18 @@ def test_golden_lbfgs_trajectories(request, rcv1, impl, case):
     else:
         got = LB.run(loss_grad, loc["U"], 5, 0.1, 0.01, 5, 19, init=LB.withv_initializer)
         assert np.max(np.abs(np.array(got) - np.array(LB.WITHV_OBJV))) < 1e-4
+
+
+def test_reference_build_recipe_from_scratch(tmp_path):
+    """oracle/Makefile compiles the reference's own sources against third_party_shim from scratch (a copy of oracle/ in a
+    scratch directory: the in-tree oracle/_ref is up to date most of the time, which once hid a shim change the
+    reference's headers did not compile against)"""
+    import shutil
+    import subprocess
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("/root/reference absent: oracle/_ref travels prebuilt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "oracle"
+    shutil.copytree(os.path.join(root, "oracle"), work, ignore=shutil.ignore_patterns("_ref", "*.so", "__pycache__"))
+    subprocess.check_call(["make", "-s", "-C", str(work), "SHIM=" + os.path.join(root, "third_party_shim"), "ref"])
+    assert os.path.getsize(work / "_ref" / "libdifacto_ref.so") > 100000

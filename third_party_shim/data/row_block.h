@@ -34,8 +34,14 @@ struct RowBlockContainer {
   std::vector<size_t> offset;
   std::vector<real_t> label;
   std::vector<real_t> weight;
+#ifdef DMLC_SHIM_STD_VECTORS
+  // oracle/_ref: the reference's own headers take these arrays as plain std::vector<T>* (compressed_row_block.h:56-75)
+  std::vector<IndexType> index;
+  std::vector<real_t> value;
+#else
   std::vector<IndexType, DefaultInitAllocator<IndexType>> index;
   std::vector<real_t, DefaultInitAllocator<real_t>> value;
+#endif
   /*! \brief the largest index stored — exact after Push(Row) and after an assignment (Localizer::RemapIndex sets it,
    *  src/data/localizer.cc:102); Push(RowBlock) and bulk appenders only mark it stale (the scan was a second pass over
    *  every byte the shuffle buffer's assembly copies): read it through GetMaxIndex(), which rescans when needed */

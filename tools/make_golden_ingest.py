@@ -8,7 +8,7 @@ container, where /root/reference exists; the fixture travels, the reference does
   criteo_text_<i>  a chunk of criteo text; criteo_<i>_{offset,label,index}: what CriteoParser::ParseNext made of it
                    (criteo_<i>_train = 0: the criteo_test format, no label column)
 CityHash64 inside the parser is oracle/city_checker.cc (the library is absent): the ids pin slot tagging, field
-splitting and row cutting, not the hash (unpinned beyond CityHash64("") = k2).
+splitting and row cutting, not the hash (that one is pinned to Abseil's CityHash64 in tests/test_ingest.py).
 """
 import os
 import sys
