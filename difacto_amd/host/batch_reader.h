@@ -209,6 +209,54 @@ class LibsvmChunkParser : public ChunkParser {
 };
 
 /**
+ * \brief adfea CTR text (src/reader/adfea_parser.h:33-88): blank-separated tokens.  `idx:gid` is a feature, its id
+ * EncodeFeaGrpID(idx, gid, 12) (:62-64; "the top bits store the feature group id"); the plain numbers come in threes —
+ * a line id, a count, the label — of which the third opens a row and is 1 iff its first character is '1' (:67-76).
+ * Line ends are blanks like any other: the reference parses a chunk as one token stream, and so does this (a chunk
+ * starts at a line start, i.e. at a line id).  Numbers are read the way dmlc-core's strtoull reads them: digits
+ * accumulated without an overflow check.
+ */
+class AdfeaChunkParser : public ChunkParser {
+ public:
+  AdfeaChunkParser(const std::string& uri, unsigned part, unsigned nparts, size_t chunk_bytes) : src_(uri, part, nparts, chunk_bytes) {}
+  bool Fetch(RawChunk* raw) override { return src_.Next(raw); }
+  void Parse(const RawChunk& raw, RowChunk* out) const override {
+    out->Clear();
+    Parse(raw.data, raw.data + raw.size, out);
+  }
+  static void Parse(const char* p, const char* end, RowChunk* blk) {
+    auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f'; };
+    auto digit = [](char c) { return c >= '0' && c <= '9'; };
+    int i = 0;
+    while (p != end && blank(*p)) ++p;
+    while (p != end) {
+      const char* head = p;
+      feaid_t num = 0;
+      while (p != end && digit(*p)) num = num * 10 + static_cast<feaid_t>(*p++ - '0');
+      CHECK(head != p) << "adfea: a token that does not start with a digit: " << std::string(head, std::min<size_t>(end - head, 24));
+      if (p != end && *p == ':') {
+        ++p;
+        feaid_t gid = 0;
+        while (p != end && digit(*p)) gid = gid * 10 + static_cast<feaid_t>(*p++ - '0');
+        CHECK_LT(gid, static_cast<feaid_t>(1) << 12) << "adfea: feature group id beyond 12 bits";   // EncodeFeaGrpID, base.h:60-63
+        blk->index.push_back((num << 12) | gid);
+      } else if (i == 2) {  // skip the line id and the first count
+        i = 0;
+        if (!blk->label.empty()) blk->offset.push_back(blk->index.size());
+        blk->label.push_back(*head == '1' ? 1.0f : 0.0f);
+      } else {
+        ++i;
+      }
+      while (p != end && blank(*p)) ++p;
+    }
+    if (!blk->label.empty()) blk->offset.push_back(blk->index.size());
+  }
+
+ private:
+  TextChunks src_;
+};
+
+/**
  * \brief criteo CTR text (src/reader/criteo_parser.h:40-94): tab-separated
  *   <label> <13 integer features> <26 categorical features of 8 hex characters>
  * an empty field is a missing feature; feature i of a row becomes the id
@@ -601,10 +649,12 @@ class Reader {
       parser_.reset(new CriteoChunkParser(uri, part, nparts, chunk_bytes, true));
     } else if (format == "criteo_test") {
       parser_.reset(new CriteoChunkParser(uri, part, nparts, chunk_bytes, false));
+    } else if (format == "adfea") {
+      parser_.reset(new AdfeaChunkParser(uri, part, nparts, chunk_bytes));
     } else if (format == "rec") {
       parser_.reset(new CrbRecordParser(uri, part, nparts));
     } else {
-      LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test and rec)";
+      LOG(FATAL) << "unknown format " << format << " (this build reads libsvm, criteo, criteo_test, adfea and rec)";
     }
     if (nthreads <= 0) {
       // DIFACTO_PARSER_THREADS, else an eighth of the CPUs this process may use (several readers may be alive: one per

@@ -301,6 +301,9 @@ class Ref:
             L.ref_crb_decompress.argtypes = [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp]
             L.ref_criteo_parse.restype = C.c_long
             L.ref_criteo_parse.argtypes = [C.c_char_p, sz, i32, sz, sz, vp, vp, vp, vp]
+            if hasattr(L, "ref_adfea_parse"):
+                L.ref_adfea_parse.restype = C.c_long
+                L.ref_adfea_parse.argtypes = [C.c_char_p, sz, sz, sz, vp, vp, vp, vp]
             L.ref_city_checker_hash64.restype = u64
             L.ref_city_checker_hash64.argtypes = [C.c_char_p, sz]
         self._loss = {}
@@ -345,6 +348,17 @@ class Ref:
         nnz = C.c_long(0)
         n = self.L.ref_criteo_parse(text, len(text), 1 if is_train else 0, row_cap, nnz_cap, _p(off), _p(lab), _p(idx),
                                     C.byref(nnz))
+        assert n >= 0
+        return off[:n + 1].copy(), lab[:n].copy(), idx[:nnz.value].copy()
+
+    def adfea_parse(self, text, row_cap=1 << 16, nnz_cap=1 << 22):
+        """AdfeaParser::ParseNext over one chunk -> (offset, label, index)"""
+        text = bytes(text)
+        off = np.zeros(row_cap + 1, np.uint64)
+        lab = np.zeros(row_cap, np.float32)
+        idx = np.zeros(nnz_cap, np.uint64)
+        nnz = C.c_long(0)
+        n = self.L.ref_adfea_parse(text, len(text), row_cap, nnz_cap, _p(off), _p(lab), _p(idx), C.byref(nnz))
         assert n >= 0
         return off[:n + 1].copy(), lab[:n].copy(), idx[:nnz.value].copy()
 

@@ -7,6 +7,7 @@
                           hash_internal::CityHash64 (CityHash v1.1), exported by pyarrow's libarrow_compute.so in
                           this image — tests/test_ingest.py::test_cityhash64_against_abseil, every length class.
   parse_criteo(text)      CriteoParser::ParseNext (/root/reference/src/reader/criteo_parser.h:40-94)
+  parse_adfea(text)       AdfeaParser::ParseNext (/root/reference/src/reader/adfea_parser.h:33-88)
   lz4_compress(bytes)     LZ4_compress_default of the REAL liblz4 present in this image (ctypes): fixtures
                           for the from-scratch decoder, so that one IS pinned to the library the reference links
   write_crb_record(...)   CompressedRowBlock::Compress (/root/reference/src/data/compressed_row_block.h:26-54)
@@ -154,6 +155,32 @@ def parse_criteo(text, is_train=True):
         for i, tok in enumerate(f[:39]):
             if tok:
                 idx.append(encode_fea_grp_id(cityhash64(tok), i, 12))
+        off.append(len(idx))
+    return np.array(off, np.uint64), np.array(lab, np.float32), np.array(idx, np.uint64)
+
+
+def parse_adfea(text):
+    """-> (offset, label, index): AdfeaParser::ParseNext over one chunk (adfea_parser.h:50-84).  Blank-separated tokens;
+    `idx:gid` is a feature, id = EncodeFeaGrpID(idx, gid, 12); the plain numbers come in threes — line id, a count, the
+    label (1 iff its first character is '1') — and the third one opens a row"""
+    off, lab, idx = [0], [], []
+    i = 0
+    for tok in text.split():
+        assert tok[:1].isdigit(), tok
+        head, sep, rest = tok.partition(b":")
+        if sep:
+            assert rest == b"" or rest.isdigit(), tok   # (anything else ends the reference's run in a CHECK, :59)
+            gid = int(rest or b"0")
+            assert 0 <= gid < 4096
+            idx.append(((int(head) << 12) | gid) & (2 ** 64 - 1))
+        elif i == 2:
+            i = 0
+            if lab:
+                off.append(len(idx))
+            lab.append(1.0 if tok[:1] == b"1" else 0.0)
+        else:
+            i += 1
+    if lab:
         off.append(len(idx))
     return np.array(off, np.uint64), np.array(lab, np.float32), np.array(idx, np.uint64)
 

@@ -5,6 +5,7 @@
  *   difacto::CompressedRowBlock   src/data/compressed_row_block.h:20-142  (DIFACTO_USE_LZ4=1, the image's liblz4)
  *   difacto::CriteoParser         src/reader/criteo_parser.h:40-101       (DIFACTO_USE_CITY=1; CityHash64 is served
  *                                 by oracle/city_checker.cc — the library is absent, see ref_shim/city.h)
+ *   difacto::AdfeaParser          src/reader/adfea_parser.h:33-88         (dmlc-core's strtonum.h helpers: ref_shim/data/strtonum.h)
  * against the interface stand-ins in ref_shim/ (dmlc::InputSplit, dmlc::data::ParserImpl).
  * Used by tests/ and tools/make_golden_ingest.py to pin the product's .rec decoder and criteo parser
  * (difacto_amd/host/batch_reader.h) and the Python writers in oracle/ingest.py.  The RecordIO framing around
@@ -18,6 +19,7 @@
 #include "difacto/base.h"
 #include "data/compressed_row_block.h"
 #include "reader/criteo_parser.h"
+#include "reader/adfea_parser.h"
 
 using namespace difacto;
 
@@ -91,6 +93,43 @@ long ref_criteo_parse(const char* text, size_t len, int is_train, size_t row_cap
   const dmlc::data::RowBlockContainer<feaid_t>& blk = data[0];
   const size_t nrows = blk.offset.size() - 1;
   if (nrows > row_cap || blk.index.size() > nnz_cap) return -1;
+  memcpy(offset, blk.offset.data(), (nrows + 1) * sizeof(size_t));
+  memcpy(label, blk.label.data(), blk.label.size() * sizeof(float));
+  memcpy(index, blk.index.data(), blk.index.size() * sizeof(uint64_t));
+  *nnz = static_cast<long>(blk.index.size());
+  return static_cast<long>(nrows);
+}
+
+/** AdfeaParser::ParseNext (src/reader/adfea_parser.h:33-88) over one chunk of text (NUL-terminated here: the parser reads
+ *  the character behind the chunk, :58 / :62).  Returns rows, -1 when a capacity is too small. */
+long ref_adfea_parse(const char* text, size_t len, size_t row_cap, size_t nnz_cap, size_t* offset, float* label, uint64_t* index,
+                     long* nnz) {
+  std::string z(text, len);
+  z.push_back('\0');
+  class ZSplit : public dmlc::InputSplit {
+   public:
+    ZSplit(std::string* s, size_t n) : s_(s), n_(n), done_(false) {}
+    void BeforeFirst() override { done_ = false; }
+    bool NextChunk(Blob* out) override {
+      if (done_ || n_ == 0) return false;
+      out->dptr = &(*s_)[0];
+      out->size = n_;
+      done_ = true;
+      return true;
+    }
+   private:
+    std::string* s_;
+    size_t n_;
+    bool done_;
+  };
+  AdfeaParser parser(new ZSplit(&z, len));
+  std::vector<dmlc::data::RowBlockContainer<feaid_t> > data;
+  offset[0] = 0;
+  *nnz = 0;
+  if (!parser.ParseNext(&data)) return 0;
+  const dmlc::data::RowBlockContainer<feaid_t>& blk = data[0];
+  const size_t nrows = blk.offset.size() - 1;
+  if (nrows > row_cap || blk.index.size() > nnz_cap || blk.label.size() > row_cap) return -1;
   memcpy(offset, blk.offset.data(), (nrows + 1) * sizeof(size_t));
   memcpy(label, blk.label.data(), blk.label.size() * sizeof(float));
   memcpy(index, blk.index.data(), blk.index.size() * sizeof(uint64_t));

@@ -145,8 +145,8 @@ def test_cli_two_ranks_share_the_gpu_over_files(built, tmp_path):
 @pytest.mark.gpu
 def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
     """data_format = criteo (CityHash64 + slot tag) and data_format = rec (RecordIO of LZ4 compressed row
-    blocks): the formats of the reference's example/criteo_sgd.conf.  The same rows in both formats
-    must give the same training trajectory."""
+    blocks): the formats of the reference's example/criteo_sgd.conf — and data_format = adfea (`lineid count label
+    idx:gid ...`, src/reader/adfea_parser.h).  The same rows in the three formats must give the same training trajectory."""
     import numpy as np
     from oracle import ingest as oi
     from test_ingest import _criteo_text
@@ -161,18 +161,24 @@ def test_cli_trains_from_criteo_text_and_rec(built, tmp_path):
         recs.append(oi.write_crb_record(o, lab[a:a + 500], idx[int(off[a]):int(off[a + 500])]))
     rec = os.path.join(tmp_path, "train.rec")
     open(rec, "wb").write(oi.write_recordio(recs))
+    assert set(np.unique(lab)) <= {0.0, 1.0}
+    adf = os.path.join(tmp_path, "train.adfea")
+    with open(adf, "w") as f:   # id = EncodeFeaGrpID(id >> 12, id & 0xfff, 12): the same 64-bit ids
+        for r in range(3000):
+            ids = idx[int(off[r]):int(off[r + 1])]
+            f.write(" ".join(["%d" % r, "%d" % len(ids), "%d" % lab[r]] + ["%d:%d" % (int(v) >> 12, int(v) & 0xFFF) for v in ids]) + "\n")
     common = ["task=train", "learner=sgd", "batch_size=500", "max_num_epochs=3", "V_dim=4", "V_threshold=0", "l1=.01", "lr=.1",
               "V_lr=.05", "V_init=hash", "table_capacity=262144", "stop_rel_objv=0",
               "num_jobs_per_epoch=1",   # one data part: byte-range parts of a text file and of a RecordIO file hold different rows
               "shuffle=0"]              # file order: the two readers cut the stream into different shuffle buffers
     runs = []
-    for fmt, path in (("criteo", txt), ("rec", rec)):
+    for fmt, path in (("criteo", txt), ("rec", rec), ("adfea", adf)):
         r = subprocess.run([os.path.join(built, "difacto"), "data_in=" + path, "data_format=" + fmt] + common,
                            capture_output=True, text=True, timeout=180, cwd=ROOT)
         print(r.stderr[-1500:])
         assert r.returncode == 0
         runs.append(_losses(r.stderr))
-    assert len(runs[0]) == 3 and runs[0] == runs[1], runs
+    assert len(runs[0]) == 3 and runs[0] == runs[1] == runs[2], runs
     assert runs[0][-1] < runs[0][0]
 
 

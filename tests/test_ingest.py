@@ -498,6 +498,48 @@ def test_criteo_parser_on_the_reference_parsers_output(ing, tmp_path):
     assert i >= 9
 
 
+def test_adfea_reader_on_the_reference_parsers_output(ing, tmp_path):
+    """data_format = adfea (src/reader/reader.h:40-41): AdfeaChunkParser against what the reference's own
+    AdfeaParser::ParseNext made of the same text (golden fixture, written through oracle/_ref) — CRLF, blank lines, tabs and
+    form feeds between tokens, rows without features, labels that merely start with '1', 2^64 - 1 and an id that wraps,
+    no final newline — and against the Python transcription; then a larger file read in parts"""
+    from oracle import ingest as oi
+    g = np.load(GOLDEN_INGEST)
+    i = 0
+    while "adfea_text_%d" % i in g:
+        text = g["adfea_text_%d" % i].tobytes()
+        path = tmp_path / ("a%d.txt" % i)
+        path.write_bytes(text)
+        got = read_all(ing, path, "adfea", batch=7)
+        want = [g["adfea_%d_%s" % (i, k)] for k in ("offset", "label", "index")]
+        assert np.array_equal(got["offset"], want[0]) and np.array_equal(got["label"], want[1]), i
+        assert np.array_equal(got["index"], want[2]) and not got["has_value"], i
+        py = oi.parse_adfea(text)
+        assert all(np.array_equal(a, b) for a, b in zip(py, want)), i
+        i += 1
+    assert i >= 7
+    rng = np.random.default_rng(23)
+    lines = []
+    for r in range(3000):
+        n = int(rng.integers(0, 40))
+        lines.append(" ".join(["%d" % r, "%d" % n, "%d" % rng.integers(0, 2)] +
+                              ["%d:%d" % (rng.integers(0, 2 ** 50), rng.integers(0, 4096)) for _ in range(n)]))
+    text = ("\n".join(lines) + "\n").encode()
+    path = tmp_path / "big.adfea"
+    path.write_bytes(text)
+    off, lab, idx = oi.parse_adfea(text)
+    os.environ["DIFACTO_CHUNK_BYTES"] = "20000"   # many chunks: a chunk starts at a line start, i.e. at a line id
+    try:
+        whole = read_all(ing, path, "adfea", batch=100)
+        parts = [read_all(ing, path, "adfea", part=p, nparts=4, batch=64) for p in range(4)]
+    finally:
+        del os.environ["DIFACTO_CHUNK_BYTES"]
+    assert np.array_equal(whole["offset"], off) and np.array_equal(whole["label"], lab) and np.array_equal(whole["index"], idx)
+    assert sum(len(p["label"]) for p in parts) == 3000
+    assert np.array_equal(np.concatenate([p["index"] for p in parts]), idx)
+    assert np.array_equal(np.concatenate([p["label"] for p in parts]), lab)
+
+
 def test_reference_format_code_live_when_built(ing, tmp_path):
     """in the build container (oracle/_ref with the data-format half): random row blocks through the reference's
     Compress -> product reader, oracle/ingest.py's writer -> the reference's Decompress, random criteo text through
@@ -541,6 +583,18 @@ def test_reference_format_code_live_when_built(ing, tmp_path):
     for n in list(range(0, 80)) + [127, 128, 129, 255, 256, 1000]:
         s = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
         assert R.city_checker_hash64(s) == ing.ingest_cityhash64(s, n) == oi.cityhash64(s), n
+    # random adfea text through the reference's AdfeaParser and the product's reader
+    lines = []
+    for r in range(500):
+        n = int(rng.integers(0, 30))
+        lines.append("\t".join(["%d" % r, "%d" % n, "%d" % rng.integers(0, 3)] +
+                               ["%d:%d" % (rng.integers(0, 2 ** 62), rng.integers(0, 4096)) for _ in range(n)]))
+    text = ("\n".join(lines) + "\n").encode()
+    p3 = tmp_path / "live.adfea"
+    p3.write_bytes(text)
+    off, lab, idx = R.adfea_parse(text)
+    got = read_all(ing, p3, "adfea", batch=64)
+    assert np.array_equal(got["offset"], off) and np.array_equal(got["label"], lab) and np.array_equal(got["index"], idx)
 
 
 def _parse_criteo_mode(L, text, train, mode):

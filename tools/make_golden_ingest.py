@@ -7,6 +7,8 @@ container, where /root/reference exists; the fixture travels, the reference does
   crb_<i>_{offset,label,index,value,weight}   the block that went in (value / weight absent when NULL)
   criteo_text_<i>  a chunk of criteo text; criteo_<i>_{offset,label,index}: what CriteoParser::ParseNext made of it
                    (criteo_<i>_train = 0: the criteo_test format, no label column)
+  adfea_text_<i>   a chunk of adfea text; adfea_<i>_{offset,label,index}: what AdfeaParser::ParseNext
+                   (src/reader/adfea_parser.h:33-88) made of it
 CityHash64 inside the parser is oracle/city_checker.cc (the library is absent): the ids pin slot tagging, field
 splitting and row cutting, not the hash (that one is pinned to Abseil's CityHash64 in tests/test_ingest.py).
 """
@@ -59,6 +61,26 @@ def criteo_cases(rng):
     return cases
 
 
+def adfea_row(rng, lineid, nfeat=None, sep=" ", label=None):
+    n = int(rng.integers(0, 30)) if nfeat is None else nfeat
+    feats = ["%d:%d" % (int(rng.integers(0, 2 ** 52)), int(rng.integers(0, 4096))) for _ in range(n)]
+    lab = str(int(rng.integers(0, 2))) if label is None else label
+    return sep.join([str(lineid), str(n), lab] + feats)
+
+
+def adfea_cases(rng):
+    """chunks of adfea text (src/reader/adfea_parser.h): `lineid count label idx:gid ...`, blanks of any kind between tokens"""
+    cases = []
+    cases.append("\n".join(adfea_row(rng, 100 + i) for i in range(16)) + "\n")                       # plain
+    cases.append("\r\n".join(adfea_row(rng, i) for i in range(8)) + "\r\n")                            # CRLF
+    cases.append("  \n\n" + "\n \t\n".join(adfea_row(rng, i, sep="\t ") for i in range(9)) + " \f\n\n")  # blank lines, tabs, form feed
+    cases.append("\n".join(adfea_row(rng, i, nfeat=0) for i in range(5)) + "\n")                      # rows without features
+    cases.append("\n".join(adfea_row(rng, i, label=l) for i, l in enumerate(["1", "0", "10", "01", "11", "7"])) + "\n")  # label = first char == '1'
+    cases.append("7 2 1 18446744073709551615:4095 99999999999999999999999:3\n8 1 0 0:0\n")               # 2^64 - 1, and an idx that wraps
+    cases.append("\n".join(adfea_row(rng, i) for i in range(6)))                                      # no final newline
+    return cases
+
+
 def crb_blocks(rng):
     blocks = []
     for b in range(8):
@@ -100,10 +122,17 @@ def main():
         out["criteo_text_%d" % i] = np.frombuffer(tb, np.uint8)
         out["criteo_%d_train" % i] = np.array(train)
         out["criteo_%d_offset" % i], out["criteo_%d_label" % i], out["criteo_%d_index" % i] = off, lab, idx
+    rng2 = np.random.default_rng(20260927)   # (its own stream: the arrays above stay what they were before adfea was added)
+    for i, text in enumerate(adfea_cases(rng2)):
+        tb = text.encode()
+        off, lab, idx = R.adfea_parse(tb)
+        out["adfea_text_%d" % i] = np.frombuffer(tb, np.uint8)
+        out["adfea_%d_offset" % i], out["adfea_%d_label" % i], out["adfea_%d_index" % i] = off, lab, idx
     path = os.path.join(ROOT, "tests", "golden", "ref_ingest.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", sum(1 for k in out if k.startswith("crb_rec_")), "row blocks,",
-          sum(1 for k in out if k.startswith("criteo_text_")), "criteo texts")
+          sum(1 for k in out if k.startswith("criteo_text_")), "criteo texts,", sum(1 for k in out if k.startswith("adfea_text_")),
+          "adfea texts")
 
 
 if __name__ == "__main__":
