@@ -38,8 +38,8 @@ KWArgs SGDLearner::Init(const KWArgs& kwargs) {
   auto remain = Learner::Init(kwargs);
   remain = param_.InitAllowUnknown(remain);
   CHECK(param_.data_format == "libsvm" || param_.data_format == "criteo" || param_.data_format == "criteo_test" ||
-        param_.data_format == "rec")
-      << "data_format " << param_.data_format << " is not supported by this build (libsvm, criteo, criteo_test, rec)";
+        param_.data_format == "adfea" || param_.data_format == "rec")
+      << "data_format " << param_.data_format << " is not one of the reference's (libsvm, criteo, criteo_test, adfea, rec)";
   auto updater = new DeviceSGDUpdater();
   remain = updater->Init(remain);
   remain.push_back(std::make_pair("V_dim", std::to_string(updater->param().V_dim)));
