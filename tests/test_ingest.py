@@ -384,6 +384,46 @@ def test_reader_threads_under_tsan(tmp_path):
     assert r.stdout.startswith("rows ")
 
 
+def test_readers_on_corrupted_files_under_asan(tmp_path):
+    """the four file formats under AddressSanitizer + UBSan (tools/fuzz_readers.cc): good criteo / .rec / adfea / libsvm
+    files with byte flips, truncations, bursts and splices — rows or an error, never a read or write outside a buffer (the
+    .rec records are views of the mapped file and the LZ4 decoder copies short sequences with fixed-size moves; ParseFast
+    loads 8 bytes per categorical field)"""
+    import shutil
+    import subprocess
+    from oracle import ingest as oi
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_readers")
+    cc = ["g++", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-O1", "-g", "-std=c++14", "-fopenmp",
+          "-Wno-unknown-pragmas", "-Wno-sign-compare", "-DDMLC_LOG_FATAL_THROW=1", "-I" + os.path.join(ROOT, "include"),
+          "-I" + os.path.join(ROOT, "third_party_shim"), "-I" + os.path.join(ROOT, "difacto_amd", "host"), "-o", exe,
+          os.path.join(ROOT, "tools", "fuzz_readers.cc"), "-lpthread"]
+    r = subprocess.run(cc, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "asan" in (r.stderr or "").lower():
+        pytest.skip("AddressSanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(3)
+    text = _criteo_text(rng, 300)
+    off, lab, idx = oi.parse_criteo(text)
+    files = {"criteo": text}
+    files["rec"] = oi.write_recordio([oi.write_crb_record(off[a:a + 101] - off[a], lab[a:a + 100], idx[int(off[a]):int(off[a + 100])])
+                                      for a in range(0, 300, 100)])
+    rows = [idx[int(off[r]):int(off[r + 1])] for r in range(300)]
+    files["adfea"] = "".join(" ".join(["%d" % r, "%d" % len(ids), "%d" % lab[r]] + ["%d:%d" % (int(v) >> 12, int(v) & 0xFFF) for v in ids]) + "\n"
+                             for r, ids in enumerate(rows)).encode()
+    files["libsvm"] = "".join(" ".join(["%d" % lab[r]] + ["%d:%g" % (int(v) >> 12, 0.5 + (int(v) & 7)) for v in ids]) + "\n"
+                              for r, ids in enumerate(rows)).encode()
+    for fmt, blob in files.items():
+        good = tmp_path / ("good." + fmt)
+        good.write_bytes(blob)
+        r = subprocess.run([exe, fmt, str(good), "120", str(tmp_path / "scratch.bin")], capture_output=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        out = r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+        assert r.returncode == 0 and "AddressSanitizer" not in out and "runtime error" not in out, (fmt, out[-2500:])
+        assert "120 corrupted inputs" in out
+
+
 @pytest.mark.parametrize("threads", [1, 3, 8])
 def test_parser_pool_keeps_file_order(ing, tmp_path, monkeypatch, threads):
     """the chunks of a part are parsed by a pool of threads (batch_reader.h: Reader) and must reach the
