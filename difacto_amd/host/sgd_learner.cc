@@ -234,10 +234,28 @@ struct DeviceFeed {
   std::deque<Job> jobs;
   std::vector<std::thread> workers;
   bool stop = false;
-  void Start() {
+  // rows / nnz: what a shuffle buffer is expected to hold.  Every upload thread creates one row buffer of that size right
+  // away — the buffer's arrays, its stream (a hardware queue: milliseconds) and events — while the reader is still parsing
+  // the first chunks, instead of when the first shuffle buffer is already waiting for its upload (DIFACTO_FEED_PRECREATE=0:
+  // as before).  A buffer that turns out too small stays spare and a fitting one is created then, as always.
+  void Start(size_t rows, size_t nnz) {
     const char* e = getenv("DIFACTO_UPLOAD_THREADS");
     const int n = std::max(1, std::min(e ? atoi(e) : 2, 8));
-    for (int t = 0; t < n; ++t) workers.emplace_back([this] { Work(); });
+    const char* pc = getenv("DIFACTO_FEED_PRECREATE");
+    const bool precreate = rows > 0 && !(pc && atoi(pc) == 0);
+    for (int t = 0; t < n; ++t)
+      workers.emplace_back([this, rows, nnz, precreate] {
+        if (precreate) {
+          dfh_rowbuf* rb = nullptr;
+          if (dfh_rowbuf_create(ctx, rows, std::max<size_t>(nnz, 1), &rb) == DFH_OK) {
+            std::lock_guard<std::mutex> lk(mu);
+            all.push_back(rb);
+            cap[rb] = {rows, std::max<size_t>(nnz, 1)};
+            spare.push_back(rb);
+          }
+        }
+        Work();
+      });
   }
   void Upload(const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {   // builder's thread
     Job j;
@@ -350,7 +368,8 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   feed.ctx = ctx;
   const bool device_feed = train && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
   BatchReader::SliceFn upload;
-  if (device_feed) feed.Start();
+  // (48 ids per row: the criteo rows of the reference's example have 39)
+  if (device_feed) feed.Start(static_cast<size_t>(param_.batch_size) * param_.shuffle, static_cast<size_t>(param_.batch_size) * param_.shuffle * 48);
   if (device_feed)
     upload = [&feed](const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {
       feed.Upload(blk, slices, serial);
@@ -456,6 +475,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   // staging + Localizer / lookup queueing, step queueing), printed at the end of the job
   double t_read = 0, t_prep = 0, t_step = 0;
   double t0 = prof ? now() : 0;
+  // the batch objects while the reader parses its first chunks (sizes: this job's batch_size at 48 ids per row, or what an
+  // earlier job left; a bigger minibatch re-creates them, as before)
+  if (device_feed && !all_there() && !(getenv("DIFACTO_FEED_PRECREATE") && atoi(getenv("DIFACTO_FEED_PRECREATE")) == 0))
+    ensure(param_.batch_size, static_cast<size_t>(param_.batch_size) * 48);
   bool have = reader.Next();
   if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
   int i = 0;
