@@ -20,6 +20,10 @@ import argparse
 import glob
 import json
 import os
+
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument`
+# otherwise); the boxes export it already, a hand-made environment may not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import time
 
