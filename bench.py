@@ -96,6 +96,15 @@ def parse_args():
     ap.add_argument("--transport", choices=["native", "torch"], default="native",
                     help="N>1: the exchange inside libdifacto_hip.so (dfh_shard_step, RCCL ncclSend/ncclRecv; the product path) or "
                          "the test harness over torch.distributed (tests/sharded_harness.py)")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="W",
+                    help="PROJECTION (never the headline): this ONE GPU carries the load of rank r of a W-rank job through the "
+                         "loop-back transport (peers' keys / counts / gradient rows synthesised from W - 1 other streams of the "
+                         "generator restricted to the rank's key range; wires modelled) — every kernel of dfh_shard_step at N = W "
+                         "at its real size on a quiet chip")
+    ap.add_argument("--emulate-rank", default="all", help="which rank(s) to emulate: an index, or `all` (one after the other; the "
+                                                          "projection takes the slowest, like a job's barrier would)")
+    ap.add_argument("--emulate-wire", choices=["off", "peak", "achievable"], default="achievable",
+                    help="which wire model the projected `value` is quoted under (all three are in the line)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     args = ap.parse_args()
@@ -283,6 +292,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         return subprocess.call(cmd)
+    if args.emulate_world > 1:
+        from difacto_amd import sharded
+        return sharded.bench_main_emulated(args, args.hyper)
     if args.gpus > 1 or world > 1 or args.force_sharded:
         if args.transport == "native":
             from difacto_amd import sharded

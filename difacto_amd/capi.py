@@ -31,7 +31,9 @@ SYMBOLS = [
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
     "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
+    "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
 ]
+XCHG_COUNTS, XCHG_KEYS, XCHG_CNT, XCHG_ROWS, XCHG_GRADS, XCHG_OTHER = range(6)
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
 K_COUNT = 8
 K_LOCALIZE, K_LOOKUP, K_FORWARD, K_BACKWARD, K_PULL, K_PUSH, K_MISC, K_AUC = range(8)
@@ -188,6 +190,10 @@ def lib():
     L.dfh_comm_selfcheck.argtypes = [vp, C.c_double]
     L.dfh_shard_balanced_splits.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfh_shard_set_exchange.argtypes = [vp, i32]
+    L.dfh_comm_create_loopback.argtypes = [vp, i32, i32, PP(vp)]
+    L.dfh_comm_loopback_feed.argtypes = [vp, i32, vp, i32]
+    L.dfh_comm_loopback_wire.argtypes = [vp, C.c_double, C.c_double]
+    L.dfh_comm_loopback_wire_time.argtypes = [vp, i32, PP(C.c_double)]
     L.dfh_shard_set_timing.argtypes = [vp, i32]
     L.dfh_shard_get_timing.argtypes = [vp, i32, vp, PP(u64)]
     _lib = L
@@ -678,6 +684,26 @@ class Comm:
         h = C.c_void_p()
         _ck(lib().dfh_comm_create_callback(ctx.h, rank, world, cb, None, C.byref(h)))
         return cls(h, keep=cb)
+
+    @classmethod
+    def loopback(cls, ctx, rank, world):
+        """measurement only: rank `rank` of a `world`-rank job alone on its GPU; the peers' messages are device copies
+        out of buffers fed with feed() (include/difacto_hip.h, dfh_comm_create_loopback)"""
+        h = C.c_void_p()
+        _ck(lib().dfh_comm_create_loopback(ctx.h, rank, world, C.byref(h)))
+        return cls(h)
+
+    def feed(self, kind, d_src, sticky=False):
+        """source (device pointer) of the next exchange of `kind` (XCHG_*), laid out like its receive side"""
+        _ck(lib().dfh_comm_loopback_feed(self.h, kind, d_src, 1 if sticky else 0))
+
+    def wire(self, link_gbps, latency_us):
+        _ck(lib().dfh_comm_loopback_wire(self.h, float(link_gbps), float(latency_us)))
+
+    def wire_time_us(self, reset=True):
+        v = C.c_double(0)
+        _ck(lib().dfh_comm_loopback_wire_time(self.h, 1 if reset else 0, C.byref(v)))
+        return v.value
 
     def allreduce_sum(self, vals):
         a = np.ascontiguousarray(vals, np.float64).copy()

@@ -35,6 +35,7 @@
 #include <link.h>
 
 #include <chrono>
+#include <deque>
 #include <thread>
 
 namespace dfh {
@@ -127,6 +128,53 @@ __global__ void k_shard_counts(const int64_t* __restrict__ bounds, int world, in
   }
 }
 
+// ---- loop-back transport (dfh_comm_create_loopback): the copies of one exchange in ONE launch
+struct LoopSegs {
+  const char* src[64];
+  char* dst[64];            // NULL: a send — the bytes are read and dropped
+  unsigned long long bytes[64];
+  int n;
+};
+
+// block b walks the segments in 16 B (or, for a misaligned segment, 4 B) units, grid-stride.  A "send" is read in full
+// (one xor per unit, stored only if it hits a value it cannot hit: the loads stay) — on real wires the send buffer is
+// read out of this GPU's HBM once and nothing is written here.  Thread 0 of block 0 stamps the wall clock for k_loop_wait.
+__global__ void __launch_bounds__(256) k_loop_copy(LoopSegs g, unsigned long long* __restrict__ stamp, unsigned* __restrict__ sink) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stamp) *stamp = wall_clock64();
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  unsigned acc = 0;
+  for (int i = 0; i < g.n; ++i) {
+    const char* s = g.src[i];
+    char* d = g.dst[i];
+    const size_t nb = g.bytes[i];
+    const bool wide = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 15) == 0;
+    if (wide) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (size_t j = tid; j < nb / 16; j += nth) {
+        const uint4 v = s4[j];
+        if (d) d4[j] = v; else acc ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+    } else {
+      const unsigned* s1 = reinterpret_cast<const unsigned*>(s);
+      unsigned* d1 = reinterpret_cast<unsigned*>(d);
+      for (size_t j = tid; j < nb / 4; j += nth) {
+        const unsigned v = s1[j];
+        if (d) d1[j] = v; else acc ^= v;
+      }
+    }
+  }
+  if (acc == 0x9E3779B9u && sink) *sink = acc;
+}
+
+// holds the stream until `ticks` wall-clock ticks after the stamp k_loop_copy left: the modelled wire time of the exchange
+__global__ void k_loop_wait(const unsigned long long* __restrict__ stamp, unsigned long long ticks) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = *stamp;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 }  // namespace dfh
 
 using namespace dfh;
@@ -142,6 +190,14 @@ struct dfh_comm {
   size_t h_cap = 0;
   // payload this rank handed to / took from OTHER ranks since the last reset, and the message groups it took
   uint64_t bytes_sent = 0, bytes_recv = 0, groups = 0;
+  // loop-back transport (measurement): fed sources per kind of exchange, the wire model
+  bool loopback = false;
+  std::deque<const void*> feed[DFH_XCHG_KINDS];
+  const void* sticky[DFH_XCHG_KINDS] = {nullptr};
+  unsigned long long* d_stamp = nullptr;   // [0]: wall clock at the start of the current exchange's copies; [1]: sink
+  double link_gbps = 0, latency_us = 0;
+  double wall_khz = 100000.0;              // hipDeviceAttributeWallClockRate
+  double wire_us_sum = 0;                  // modelled wire time of all exchanges since the last stats reset
 };
 
 struct dfh_shard {
@@ -217,7 +273,7 @@ struct XPart {
 
 // alltoallv of device buffers; nparts parts would share ONE message group (callers pass one part: one send and
 // one receive per peer and group)
-int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = nullptr) {
+int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = nullptr, int kind = DFH_XCHG_OTHER) {
   hipStream_t s = on ? on : c->ctx->stream;
   const int W = c->world;
   for (int i = 0; i < nparts; ++i)
@@ -227,6 +283,61 @@ int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = 
         c->bytes_recv += parts[i].recv_b[p];
       }
   ++c->groups;
+  if (c->loopback) {
+    // every message of the exchange as a device copy of its exact size, one launch per part
+    for (int i = 0; i < nparts; ++i) {
+      const XPart& x = parts[i];
+      const char* fed = nullptr;
+      if (!c->feed[kind].empty()) {
+        fed = static_cast<const char*>(c->feed[kind].front());
+        c->feed[kind].pop_front();
+      } else if (c->sticky[kind]) {
+        fed = static_cast<const char*>(c->sticky[kind]);
+      }
+      LoopSegs g;
+      g.n = 0;
+      size_t so = 0, ro = 0, total = 0, largest = 0;
+      for (int p = 0; p < W; ++p) {
+        const size_t sp = x.send_off ? x.send_off[p] : so, rp = x.recv_off ? x.recv_off[p] : ro;
+        const size_t sb = x.send_b[p], rb = x.recv_b[p];
+        if (p == c->rank) {  // the rank's own slot: a real self-copy
+          const size_t nb = std::min(sb, rb);
+          if (nb) {
+            g.src[g.n] = static_cast<const char*>(x.d_send) + sp;
+            g.dst[g.n] = static_cast<char*>(x.d_recv) + rp;
+            g.bytes[g.n++] = nb;
+          }
+        } else {
+          if (sb) {  // out: read and dropped
+            g.src[g.n] = static_cast<const char*>(x.d_send) + sp;
+            g.dst[g.n] = nullptr;
+            g.bytes[g.n++] = sb;
+          }
+          if (rb) {  // in: from the fed source (laid out like the receive side), or an echo of what this rank sends
+            g.src[g.n] = fed ? fed + rp : static_cast<const char*>(x.d_send) + sp;
+            g.dst[g.n] = static_cast<char*>(x.d_recv) + rp;
+            g.bytes[g.n++] = fed ? rb : std::min(sb, rb);
+            if (!g.bytes[g.n - 1]) --g.n;
+          }
+          largest = std::max(largest, std::max(sb, rb));
+        }
+        total += sb + rb;
+        so += sb;
+        ro += rb;
+      }
+      if (!total) continue;
+      const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, total / (256 * 64)));
+      hipLaunchKernelGGL(k_loop_copy, dim3(blocks), dim3(256), 0, s, g, c->d_stamp, reinterpret_cast<unsigned*>(c->d_stamp + 1));
+      DFH_HIP(hipGetLastError());
+      if (c->link_gbps > 0 && largest) {
+        const double us = c->latency_us + (double)largest / (c->link_gbps * 1e3);
+        c->wire_us_sum += us;
+        hipLaunchKernelGGL(k_loop_wait, dim3(1), dim3(64), 0, s, c->d_stamp, (unsigned long long)(us * 1e-3 * c->wall_khz));
+        DFH_HIP(hipGetLastError());
+      }
+    }
+    return DFH_OK;
+  }
   if (c->rccl) {
     RcclApi* a = rccl_api();
     bool any = false;
@@ -291,9 +402,10 @@ int comm_exchange(dfh_comm* c, const XPart* parts, int nparts, hipStream_t on = 
   return DFH_OK;
 }
 
-int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b, hipStream_t on = nullptr) {
+int comm_alltoallv(dfh_comm* c, const void* d_send, const size_t* send_b, void* d_recv, const size_t* recv_b, hipStream_t on = nullptr,
+                   int kind = DFH_XCHG_OTHER) {
   XPart x{d_send, send_b, nullptr, d_recv, recv_b, nullptr};
-  return comm_exchange(c, &x, 1, on);
+  return comm_exchange(c, &x, 1, on, kind);
 }
 
 template <typename T>
@@ -361,10 +473,60 @@ int dfh_comm_create_callback(dfh_ctx* ctx, int rank, int world, dfh_alltoallv_fn
   return DFH_OK;
 }
 
+int dfh_comm_create_loopback(dfh_ctx* ctx, int rank, int world, dfh_comm** out) {
+  DFH_ARG(ctx && out && world >= 1 && world <= 32 && rank >= 0 && rank < world, "dfh_comm_create_loopback: bad argument (1 <= world <= 32)");
+  DFH_HIP(hipSetDevice(ctx->device));
+  dfh_comm* c = new (std::nothrow) dfh_comm();
+  DFH_ARG(c != nullptr, "out of host memory");
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->loopback = true;
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_stamp), 2 * sizeof(unsigned long long)) != hipSuccess) {
+    delete c;
+    set_error("dfh_comm_create_loopback: hipMalloc failed");
+    return DFH_ERR_HIP;
+  }
+  (void)hipMemset(c->d_stamp, 0, 2 * sizeof(unsigned long long));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) == hipSuccess && khz > 0) c->wall_khz = khz;
+  *out = c;
+  return DFH_OK;
+}
+
+int dfh_comm_loopback_feed(dfh_comm* c, int kind, const void* d_src, int sticky) {
+  DFH_ARG(c && c->loopback && kind >= 0 && kind < DFH_XCHG_KINDS, "dfh_comm_loopback_feed: a loop-back communicator and a DFH_XCHG_* kind");
+  if (sticky) {
+    c->sticky[kind] = d_src;
+  } else {
+    DFH_ARG(d_src, "dfh_comm_loopback_feed: NULL source");
+    c->feed[kind].push_back(d_src);
+  }
+  return DFH_OK;
+}
+
+int dfh_comm_loopback_wire(dfh_comm* c, double link_gbps, double latency_us) {
+  DFH_ARG(c && c->loopback && link_gbps >= 0 && latency_us >= 0, "dfh_comm_loopback_wire: a loop-back communicator, link_gbps >= 0, latency_us >= 0");
+  c->link_gbps = link_gbps;
+  c->latency_us = latency_us;
+  return DFH_OK;
+}
+
+int dfh_comm_loopback_wire_time(dfh_comm* c, int reset, double* us) {
+  DFH_ARG(c && c->loopback && us, "dfh_comm_loopback_wire_time: bad argument");
+  *us = c->wire_us_sum;
+  if (reset) c->wire_us_sum = 0;
+  return DFH_OK;
+}
+
 int dfh_comm_destroy(dfh_comm* c) {
   if (!c) return DFH_OK;
   hipSetDevice(c->ctx->device);
   hipStreamSynchronize(c->ctx->stream);
+  if (c->d_stamp) {
+    hipDeviceSynchronize();  // exchanges of the collectives' stream may still read the stamp
+    hipFree(c->d_stamp);
+  }
   if (c->rccl) {
     RcclApi* a = rccl_api();
     if (a) a->CommDestroy(c->rccl);
@@ -423,6 +585,15 @@ int dfh_comm_info(dfh_comm* c, char* buf, size_t n) {
     if (a && a->GetVersion) a->GetVersion(&v);
     t = "rccl " + std::to_string(v) + " from " + (a ? a->path : std::string("?")) +
         (a && a->was_loaded ? " (already loaded by the host process)" : " (loaded by libdifacto_hip)");
+  } else if (c->loopback) {
+    char w[160];
+    snprintf(w, sizeof w, "loop-back transport (measurement: rank %d of %d alone on its GPU; wire model %s", c->rank, c->world,
+             c->link_gbps > 0 ? "" : "off)");
+    t = w;
+    if (c->link_gbps > 0) {
+      snprintf(w, sizeof w, "%.1f GB/s per link and direction + %.1f us per exchange)", c->link_gbps, c->latency_us);
+      t += w;
+    }
   } else {
     t = "host callback transport";
   }
@@ -435,6 +606,7 @@ int dfh_comm_info(dfh_comm* c, char* buf, size_t n) {
 // makes this return DFH_ERR_STATE after timeout_s seconds instead of hanging the job in its first step.
 int dfh_comm_selfcheck(dfh_comm* c, double timeout_s) {
   DFH_ARG(c && timeout_s > 0, "dfh_comm_selfcheck: bad argument");
+  if (c->loopback) return DFH_OK;  // there are no peers to hear from
   dfh_ctx* ctx = c->ctx;
   DFH_HIP(hipSetDevice(ctx->device));
   const int W = c->world;
@@ -612,7 +784,7 @@ int queue_counts(dfh_shard* s, dfh_batch* b, hipStream_t on = nullptr) {
                      (int64_t)(b != nullptr ? 1 : 0), s->d_cnt);
   DFH_HIP(hipGetLastError());
   std::vector<size_t> cb(W, 2 * sizeof(int64_t));
-  int rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data(), st);
+  int rc = comm_alltoallv(c, s->d_cnt, cb.data(), s->d_cnt + 2 * W, cb.data(), st, DFH_XCHG_COUNTS);
   if (rc) return rc;
   DFH_HIP(hipMemcpyAsync(s->h_cnt, s->d_cnt, 4 * (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   return DFH_OK;
@@ -733,7 +905,7 @@ int flight_K(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
   std::vector<size_t> sb, rb, so;
   flight_bytes(f, W, sizeof(uint64_t), sb, rb, so);
   XPart xk{f.have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys[f.slot], rb.data(), nullptr};
-  int rc = comm_exchange(c, &xk, 1, s->cs);
+  int rc = comm_exchange(c, &xk, 1, s->cs, DFH_XCHG_KEYS);
   if (rc) return rc;
   if (push_cnt) {
     if (f.have && !b->has_cnt) {
@@ -743,7 +915,7 @@ int flight_K(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
     }
     flight_bytes(f, W, sizeof(float), sb, rb, so);
     XPart xc{f.have ? b->d_feacnt : nullptr, sb.data(), so.data(), s->r_cnt[f.slot], rb.data(), nullptr};
-    rc = comm_exchange(c, &xc, 1, s->cs);
+    rc = comm_exchange(c, &xc, 1, s->cs, DFH_XCHG_CNT);
     if (rc) return rc;
   }
   DFH_HIP(hipEventRecord(s->ev_k[f.slot], s->cs));
@@ -779,7 +951,7 @@ int flight_R_RW(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
     std::vector<size_t> sb, rb, so;
     flight_bytes(f, W, stride * sizeof(float), sb, rb, so);
     XPart x{s->r_rows[q], rb.data(), nullptr, s->w_rows[q], sb.data(), so.data()};
-    rc = comm_exchange(c, &x, 1, s->cs);
+    rc = comm_exchange(c, &x, 1, s->cs, DFH_XCHG_ROWS);
     if (rc) return rc;
     DFH_HIP(hipEventRecord(s->ev_rw[q], s->cs));
   }
@@ -976,7 +1148,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     StageScope ts(s, DFH_SHARD_STAGE_K, st);
     bytes(sizeof(uint64_t), sb, rb, so);
     XPart xk{have ? b->d_feaids : nullptr, sb.data(), so.data(), s->r_keys[0], rb.data(), nullptr};
-    rc = comm_exchange(c, &xk, 1);
+    rc = comm_exchange(c, &xk, 1, nullptr, DFH_XCHG_KEYS);
     if (rc) return rc;
     if (push_cnt) {
       if (have && !b->has_cnt) {
@@ -986,7 +1158,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
       }
       bytes(sizeof(float), sb2, rb2, so2);
       XPart xc{have ? b->d_feacnt : nullptr, sb2.data(), so2.data(), s->r_cnt[0], rb2.data(), nullptr};
-      rc = comm_exchange(c, &xc, 1);
+      rc = comm_exchange(c, &xc, 1, nullptr, DFH_XCHG_CNT);
       if (rc) return rc;
     }
   }
@@ -1007,7 +1179,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     StageScope ts(s, DFH_SHARD_STAGE_RW, st);
     bytes(stride * sizeof(float), sb, rb, so);
     XPart x{s->r_rows[0], rb.data(), nullptr, s->w_rows[0], sb.data(), so.data()};
-    rc = comm_exchange(c, &x, 1);
+    rc = comm_exchange(c, &x, 1, nullptr, DFH_XCHG_ROWS);
     if (rc) return rc;
   }
   // ---- F: the worker's math: own keys on the table, the others on the pulled rows
@@ -1078,7 +1250,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     XPart x{s->w_grads[0], sb.data(), so.data(), s->r_rows[0], rb.data(), nullptr};
     {
       StageScope ts(s, DFH_SHARD_STAGE_G, st);
-      rc = comm_exchange(c, &x, 1);
+      rc = comm_exchange(c, &x, 1, nullptr, DFH_XCHG_GRADS);
       if (rc) return rc;
     }
     if (nrecv) {
@@ -1255,7 +1427,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     DFH_HIP(hipStreamWaitEvent(cs, s->ev_f, 0));
     flight_bytes(cur, W, stride * sizeof(float), sb, rb, so);
     XPart x{s->w_grads[q], sb.data(), so.data(), s->r_rows[q], rb.data(), nullptr};
-    rc = comm_exchange(c, &x, 1, cs);
+    rc = comm_exchange(c, &x, 1, cs, DFH_XCHG_GRADS);
     if (rc) return rc;
     DFH_HIP(hipEventRecord(s->ev_g, cs));
   }

@@ -296,3 +296,257 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
     ctx.close()
     dist.destroy_process_group()
     return 0
+
+
+# --------------------------------------------------------------------------- projection: one GPU as rank r of W
+XGMI_LINK_DIR_GBPS = XGMI_LINK_GBPS / 2   # one direction of one link
+WIRE_MODELS = (("off", 0.0, 0.0), ("peak", XGMI_LINK_DIR_GBPS, 10.0), ("achievable", 0.6 * XGMI_LINK_DIR_GBPS, 20.0))
+
+
+def _localized_keys(hb):
+    """(ascending unique reversed keys, occurrence counts f32) of a host minibatch: Localizer::Compact's feaids / feacnt
+    (src/data/localizer.cc:11-50), in numpy — only to SYNTHESISE what peers would send; the emulated rank's own
+    minibatches go through the device Localizer like everywhere else"""
+    from . import synth
+    k, c = np.unique(synth.reverse_bytes_np(hb["index"]), return_counts=True)
+    return k, c.astype(np.float32)
+
+
+def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
+    """bench.py --emulate-world W [--emulate-rank r|all]: ONE GPU carries the load it would carry as rank r of a W-rank job
+    (loop-back dfh_comm, include/difacto_hip.h): it trains its own B-row minibatches against the key range it would own
+    (1/W of the balanced splits); the keys / counts it receives are those of the W - 1 other workers' minibatches (other
+    streams of the same generator) restricted to that range, the rows it pulls for its remote keys come from a shadow buffer
+    of valid rows, the gradient rows it receives are W - 1 peers' worth of valid gradient rows.  Everything
+    dfh_shard_step launches at N = W runs at its real size on a quiet chip.  A PROJECTION, never the headline: the line says
+    so; wire time is modelled (xGMI, one link per peer and direction) at the peak link rate and at a stated fraction of it."""
+    import concurrent.futures
+    from . import capi, synth
+    from .build import build_hip
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    build_hip()
+    W = args.emulate_world
+    B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
+    ranks = list(range(W)) if args.emulate_rank == "all" else [int(args.emulate_rank)]
+    hyper = dict(hyper)
+    hyper["lr"] = hyper["lr"] / W
+    hyper["V_lr"] = hyper["V_lr"] / W
+    nd = max(2, min(args.distinct, 64))
+    gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
+    t0 = time.time()
+    all_keys = [synth.reverse_bytes_np(gen.all_ids(g)) for g in range(S)] if args.ids <= 40_000_000 else None
+    if all_keys is not None:
+        splits = balanced_splits(np.concatenate([a[::61] for a in all_keys]), W)
+    else:   # a sample of every slot's ids is enough for the quantiles
+        splits = balanced_splits(np.concatenate([synth.reverse_bytes_np(gen.ids_of(g, np.arange(0, int(gen.vocab[g]), 997, dtype=np.uint64)))
+                                                 for g in range(S)]), W)
+    # the W workers' streams (one generator object each: every worker draws its own data part, sgd_learner.cc:78-89).  Only the
+    # emulated ranks' minibatches are kept as raw CSR; of the others only the localized key lists are needed.
+    def stream(p):
+        g = synth.CriteoSynth(total_ids=args.ids, seed=42)
+        g.rng = np.random.default_rng(1000 + p)
+        raw, loc = [], []
+        for _ in range(nd):
+            hb = g.batch(B)
+            loc.append(_localized_keys(hb))
+            raw.append(hb if p in ranks else None)
+        return raw, loc
+    with concurrent.futures.ThreadPoolExecutor(min(W, 8)) as pool:
+        streams = list(pool.map(stream, range(W)))
+    t_streams = time.time() - t0
+    stride = capi.row_stride(k)
+    results = []
+    for r in ranks:
+        results.append(_emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride, nd))
+    worst = max(results, key=lambda x: x["models"][args.emulate_wire]["ms_per_step"])
+    headline = worst["models"][args.emulate_wire]
+    proj = {m: W * B / (max(x["models"][m]["ms_per_step"] for x in results) * 1e-3) for m in worst["models"]}
+    out = {
+        "projection": True,
+        "metric": "PROJECTED examples/sec of a %d-GPU job from ONE GPU carrying the load of rank r of %d (loop-back transport; "
+                  "FM SGD worker step, Criteo-shape, V_dim=%d)" % (W, W, k),
+        "value": proj[args.emulate_wire], "unit": "examples/sec", "n_gpus": 1, "emulated_world": W, "emulated_ranks": ranks,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": headline["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_note": "W x B / (slowest emulated rank's step) under the `%s` wire model; NOT a measurement of %d GPUs: every "
+                      "kernel of dfh_shard_step ran at its real size on one quiet GPU, the wires are a model" % (args.emulate_wire, W),
+        "projected_examples_per_sec": proj,
+        "wire_models": {n: dict(link_gbps_per_direction=g, latency_us_per_exchange=l) for n, g, l in WIRE_MODELS},
+        "wire_model_note": "an exchange holds its stream for latency + largest per-peer message / link rate (full mesh: one xGMI link "
+                           "per peer, 153.6 GB/s per link both directions together = 76.8 per direction); `achievable` = 0.6 of that "
+                           "+ 20 us per grouped ncclSend/ncclRecv exchange (assumed, not measured: no second GPU here)",
+        "config": {"workload": "C4/C5 projection: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, model row-sharded by key range "
+                               "over %d ranks, rank(s) %s emulated on 1 MI355X" % (args.ids, k, W, ranks),
+                   "rows_per_step_per_gpu": B, "parallelism": "shard%d (emulated)" % W, "exchange": args.exchange, "hyper": hyper,
+                   "distinct_batches_per_rank": nd, "key_ranges": "balanced on the id space",
+                   "transport": "loop-back (device copies of the exact message sizes; sends read once, receives copied from fed buffers)"},
+        "ranks": results,
+        "streams_seconds": t_streams,
+    }
+    print(json.dumps(out))
+    return 0
+
+
+def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride, nd):
+    from . import capi, synth
+    B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
+    lo = 0 if r == 0 else int(splits[r - 1])
+    hi = (1 << 64) if r == W - 1 else int(splits[r])
+    ctx = capi.Context(0)
+    ctx.set_pipeline(1)
+    comm = capi.Comm.loopback(ctx, r, W)
+    # this rank's shard of the model, pre-filled (every id of its range present with V, like the N = 1 line)
+    t0 = time.time()
+    owned = 0
+    mine = []
+    for g in range(S):
+        keys = all_keys[g] if all_keys is not None else synth.reverse_bytes_np(gen.all_ids(g))
+        sel = keys[(keys >= np.uint64(lo)) & (keys <= np.uint64(hi - 1))]
+        mine.append(sel)
+        owned += len(sel)
+    table = capi.Table(ctx, int(owned * 1.05) + 8 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
+    for m in mine:
+        for o in range(0, len(m), 1 << 22):
+            part = np.ascontiguousarray(m[o:o + (1 << 22)])
+            db = capi.DeviceBuffer.from_numpy(ctx, part)
+            table.warm_start(db.ptr, len(part), w0=0.01, cnt0=100.0)
+            ctx.sync()
+            db.close()
+    del mine
+    t_prefill = time.time() - t0
+    shard = capi.Shard(table, comm, splits)
+    if args.exchange == "overlap":
+        shard.set_exchange("overlap")
+    raw, own_loc = streams[r]
+    # per minibatch: what the W - 1 peers send this owner (their keys inside [lo, hi), ascending per peer, peer order)
+    feeds = []
+    n_in, n_out, u_own = [], [], []
+    max_recv = 0
+    for i in range(nd):
+        cnt_words = np.zeros((W, 2), np.int64)
+        ks, cs = [], []
+        for p in range(W):
+            if p == r:
+                continue
+            pk, pc = streams[p][1][i]
+            a, b = np.searchsorted(pk, [np.uint64(lo), np.uint64(hi - 1)], side="left")
+            b = b + (1 if b < len(pk) and int(pk[b]) == hi - 1 else 0)
+            ks.append(pk[a:b])
+            cs.append(pc[a:b])
+            cnt_words[p] = (b - a, 1)
+        keys = np.concatenate(ks) if ks else np.zeros(0, np.uint64)
+        cnts = np.concatenate(cs) if cs else np.zeros(0, np.float32)
+        max_recv = max(max_recv, len(keys))
+        ok, _ = own_loc[i]
+        a, b = np.searchsorted(ok, [np.uint64(lo), np.uint64(hi - 1)], side="left")
+        b = b + (1 if b < len(ok) and int(ok[b]) == hi - 1 else 0)
+        n_in.append(len(keys))
+        n_out.append(len(ok) - (b - a))
+        u_own.append(b - a)
+        feeds.append((capi.DeviceBuffer.from_numpy(ctx, cnt_words), capi.DeviceBuffer.from_numpy(ctx, keys),
+                      capi.DeviceBuffer.from_numpy(ctx, cnts)))
+    max_U = max(len(x[0]) for x in own_loc)
+    rng = np.random.default_rng(7 + r)
+    # rows another owner would answer with: [w, has_V = 1, 0, 0 | V];  gradient rows the peers would push: [gw, had_V = 1, 0, 0 | gV]
+    def shadow(n, a, b):
+        m = np.zeros((n + 1024, stride), np.float32)
+        m[:, 0] = rng.normal(size=len(m)) * a
+        m[:, 1] = 1.0
+        m[:, 4:4 + k] = rng.normal(size=(len(m), k)) * b
+        return capi.DeviceBuffer.from_numpy(ctx, m)
+    rows_shadow = shadow(max_U, 0.01, 0.01)
+    grads_shadow = shadow(max_recv, 1e-3, 1e-4)
+    comm.feed(capi.XCHG_ROWS, rows_shadow.ptr, sticky=True)
+    comm.feed(capi.XCHG_GRADS, grads_shadow.ptr, sticky=True)
+    dev = [(capi.DeviceBuffer.from_numpy(ctx, hb["offset"].astype(np.uint32)), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
+            capi.DeviceBuffer.from_numpy(ctx, hb["label"])) for hb in raw]
+    bts = [capi.Batch(ctx, B, B * S) for _ in range(3)]
+    if not getattr(args, "no_auc", False):
+        for b_ in bts:
+            b_.set_option("compute_auc", 1)
+    fed = [0]
+
+    def prep(i):
+        o, x, l = dev[i % nd]
+        b = bts[i % len(bts)]
+        b.attach_device(B, B * S, o.ptr, x.ptr, None, l.ptr)
+        b.localize()
+        assert fed[0] == i
+        c_, k_, f_ = feeds[i % nd]
+        comm.feed(capi.XCHG_COUNTS, c_.ptr)
+        comm.feed(capi.XCHG_KEYS, k_.ptr)
+        comm.feed(capi.XCHG_CNT, f_.ptr)
+        fed[0] += 1
+
+    def step(i):
+        prep(i + 1)
+        shard.prefetch_counts(bts[(i + 1) % len(bts)])
+        shard.step(bts[i % len(bts)], is_train=True, push_cnt=True)
+
+    prep(0)
+    done = 0
+    for _ in range(args.warmup):
+        step(done)
+        done += 1
+    ctx.sync()
+    torch.cuda.synchronize()
+    table.check()
+    models = {}
+    min_time = max(0.3, args.min_time / 3)
+    stage = {}
+    for name, gbps, lat in WIRE_MODELS:
+        comm.wire(gbps, lat)
+        for _ in range(8):
+            step(done)
+            done += 1
+        reps, t_all = [], 0.0
+        comm.stats(reset=True)
+        comm.wire_time_us(reset=True)
+        while t_all < min_time and len(reps) < args.max_reps:
+            ctx.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(done)
+                done += 1
+            ctx.sync()
+            torch.cuda.synchronize()
+            reps.append(time.perf_counter() - t0)
+            t_all += reps[-1]
+        dt = float(sorted(reps)[len(reps) // 2])
+        sent, recv, groups = comm.stats(reset=True)
+        nsteps = len(reps) * args.steps
+        models[name] = dict(ms_per_step=dt / args.steps * 1e3, repetitions=len(reps),
+                            examples_per_sec_this_gpu=args.steps * B / dt,
+                            modelled_wire_ms_per_step=comm.wire_time_us(reset=True) / nsteps * 1e-3,
+                            bytes_sent_per_step=sent / nsteps, bytes_recv_per_step=recv / nsteps, message_groups_per_step=groups / nsteps)
+        if not args.no_timing:
+            shard.set_timing(True)
+            shard.get_timing(reset=True)
+            n_inst = min(args.steps, 40)
+            for _ in range(n_inst):
+                step(done)
+                done += 1
+            ms, n_cov = shard.get_timing(reset=True)
+            shard.set_timing(False)
+            stage[name] = {n: round(ms[n] / max(n_cov, 1), 5) for n in capi.SHARD_STAGES}
+    table.check()
+    progs = [b.progress(reset=True) for b in bts]
+    stride_b = stride * 4
+    res = dict(rank=r, owned_keys=int(owned), key_range=[lo, hi - 1], prefill_seconds=t_prefill,
+               unique_keys_per_batch=float(np.mean([len(x[0]) for x in own_loc])),
+               own_keys_per_batch=float(np.mean(u_own)), remote_keys_out_per_batch=float(np.mean(n_out)),
+               keys_in_per_batch=float(np.mean(n_in)),
+               bytes_per_gpu_step=dict(K_out=float(np.mean(n_out)) * 12, K_in=float(np.mean(n_in)) * 12,
+                                       RW_out=float(np.mean(n_in)) * stride_b, RW_in=float(np.mean(n_out)) * stride_b,
+                                       G_out=float(np.mean(n_out)) * stride_b, G_in=float(np.mean(n_in)) * stride_b),
+               models=models, stage_ms_per_step=stage,
+               stage_ms_per_step_note="instrumented pass per wire model (HIP events around the stages on the stream each runs on); "
+                                      "K / RW / G include the modelled wire wait when the model is on",
+               train_logloss_per_example=sum(p.loss for p in progs) / max(sum(p.nrows for p in progs), 1))
+    for o_ in [shard] + bts + [table, comm, rows_shadow, grads_shadow] + [x for f in feeds for x in f] + [x for d in dev for x in d]:
+        o_.close()
+    ctx.close()
+    torch.cuda.empty_cache()
+    return res

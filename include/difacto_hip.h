@@ -356,6 +356,24 @@ int dfh_comm_create_rccl(dfh_ctx* ctx, int rank, int world, const void* id128, d
  * a test, a gloo / MPI / socket fabric of the host). */
 typedef int (*dfh_alltoallv_fn)(void* user, const void* send, const size_t* send_bytes, void* recv, const size_t* recv_bytes);
 int dfh_comm_create_callback(dfh_ctx* ctx, int rank, int world, dfh_alltoallv_fn fn, void* user, dfh_comm** out);
+/* Loop-back transport — MEASUREMENT ONLY: rank `rank` of a `world`-rank job alone on its GPU.  Every exchange of
+ * dfh_shard_step moves messages of the exact sizes a real job would move, as device-to-device copies instead of wires:
+ * what this rank "sends" is read out of its send buffer (and dropped), what it "receives" is copied out of a buffer the
+ * caller has FED for that kind of exchange (dfh_comm_loopback_feed) — laid out like the receive side of the exchange
+ * (contiguous in peer order, or at the receive offsets) — so that every owner-side and worker-side kernel of the step
+ * runs at its real size on valid data, on a chip no other rank shares (Store::Push / Pull of the reference with the
+ * seven other workers played back: include/difacto/store.h:53-93, src/sgd/sgd_learner.cc:78-89).  The rank's own slot
+ * of an exchange is a real self-copy.  An exchange whose kind was not fed echoes the rank's own send data.
+ * Optional wire model: an exchange holds its stream for latency_us + (largest per-peer message, either direction) /
+ * link_gbps (one xGMI link per peer and direction), whichever of that and the copies is longer; link_gbps = 0: copies only. */
+enum { DFH_XCHG_COUNTS = 0, DFH_XCHG_KEYS, DFH_XCHG_CNT, DFH_XCHG_ROWS, DFH_XCHG_GRADS, DFH_XCHG_OTHER, DFH_XCHG_KINDS };
+int dfh_comm_create_loopback(dfh_ctx* ctx, int rank, int world, dfh_comm** out);
+/* the source of the NEXT exchange of `kind` (a FIFO per kind; sticky != 0: of every later exchange of that kind
+ * until the next feed).  d_src must stay valid until that exchange has run. */
+int dfh_comm_loopback_feed(dfh_comm* c, int kind, const void* d_src, int sticky);
+int dfh_comm_loopback_wire(dfh_comm* c, double link_gbps, double latency_us);
+/* modelled wire time (microseconds) of all exchanges since the last reset */
+int dfh_comm_loopback_wire_time(dfh_comm* c, int reset, double* us);
 int dfh_comm_destroy(dfh_comm* c);
 int dfh_comm_rank(dfh_comm* c);
 int dfh_comm_world(dfh_comm* c);

@@ -265,7 +265,8 @@ def _worker(rank, world, port, out_dir, balanced, prefetch, mode="sync"):
 @pytest.mark.gpu
 @pytest.mark.parametrize("WORLD,balanced,prefetch,exchange", [(2, False, False, "sync"), (2, True, True, "sync"), (4, True, False, "sync"),
                                                               (4, False, True, "sync"), (2, True, True, "overlap"),
-                                                              (4, False, True, "overlap")])
+                                                              (4, False, True, "overlap"), (8, True, True, "overlap"),
+                                                              (8, False, False, "sync")])
 def test_shard_step_ranks_share_one_gpu(tmp_path, oracle, WORLD, balanced, prefetch, exchange):
     port = 29700 + (os.getpid() % 80) + WORLD + (10 if prefetch else 0) + (20 if exchange == "overlap" else 0)
     mp.spawn(_worker, args=(WORLD, port, str(tmp_path), balanced, prefetch, exchange), nprocs=WORLD, join=True)
