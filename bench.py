@@ -89,7 +89,13 @@ def parse_args():
     ap.add_argument("--no-relocalize", action="store_true",
                     help="diagnostic (NOT the metric): localize every batch object once and time lookup + forward + backward alone")
     ap.add_argument("--uniform-ranges", action="store_true",
-                    help="N>1: uniform key ranges (owner = key / ceil(2^64/N)) instead of ranges balanced on the id space")
+                    help="N>1: uniform key ranges (owner = key / ceil(2^64/N)); same as --key-ranges uniform")
+    ap.add_argument("--key-ranges", choices=["data", "ids", "blend", "uniform"], default=None,
+                    help="N>1: what the owners' key ranges balance — the keys the minibatches carry (`data`: every owner receives "
+                         "the same number of keys per step; the default, and what the C++ store's shard_ranges = balanced does), "
+                         "the rows every shard holds (`ids`), a mixture (`blend`, --blend-alpha; the default of the c5 preset, "
+                         "whose model is near the HBM capacity), or the key space (`uniform`)")
+    ap.add_argument("--blend-alpha", type=float, default=0.5)
     ap.add_argument("--exchange", choices=["sync", "overlap"], default="overlap",
                     help="N>1: two minibatches in flight with the exchange hidden behind compute (staleness <= 1, what the "
                          "reference's batch tracker does, sgd_learner.cc:219-223; the default), or one at a time (zero staleness)")
@@ -119,6 +125,8 @@ def parse_args():
     if args.v_threshold is not None:
         hyper["V_threshold"] = args.v_threshold
     args.hyper = hyper
+    if args.key_ranges is None:
+        args.key_ranges = "blend" if args.preset == "c5-slice" else "data"
     return args
 
 

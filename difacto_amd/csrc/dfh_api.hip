@@ -49,6 +49,7 @@ struct dfh_ctx {
   int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
   int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
   int auc_in_update = 1;       // a training step's AUC as the first blocks of k_update_fused (1) or a launch of its own (0)
+  int shard_mixed_update = 1;  // sharded step: one k_update_fused<MIXED> launch for own + others' keys (1) or round 4's two launches (0)
   int grow_initial_rows = 1 << 20;  // first allocation of a growing table (dfh_table_create with capacity_rows = 0)
   // cross-stream events without the system-scope fence (no L2 write-back / invalidate at the record): every
   // consumer of these events is a stream of this device
@@ -644,17 +645,26 @@ UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* nee
   a.auc_label = nullptr;
   a.auc_part = nullptr;
   a.nb_auc = 0;
+  a.rrows = nullptr;
+  a.grows = nullptr;
+  a.rstride = 0;
   return a;
 }
 
 // the fused update on the resident table (k_update_fused, dfh_update.hip): needs the {row | flags, w} words this
 // step's k_lookup left per unique key
+// rrows / grows (sharded store): the keys of other ranks (kRemoteRow in uw) read the rows their owners sent and leave
+// gradient rows, in the same launch that updates this rank's own keys in place (k_update_fused<..., MIXED>)
 int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt,
-                        bool with_auc = false) {
+                        bool with_auc = false, const float* rrows = nullptr, float* grows = nullptr, size_t rstride = 0) {
   dfh_ctx* c = b->ctx;
   hipStream_t s = c->stream;
   const int L = lanes_for(kp);
   UpdArgs a = upd_args(b, tv, k, kp, need, uw, rg, add_cnt);
+  const bool mixed = rrows != nullptr && grows != nullptr;
+  a.rrows = rrows;
+  a.grows = grows;
+  a.rstride = (uint32_t)rstride;
   if (with_auc) {  // the minibatch's AUC rides in this launch (dfh_sgd_step, compute_auc)
     a.auc_pred = b->d_pred;
     a.auc_label = b->d_label;
@@ -683,9 +693,14 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   const dim3 grid((unsigned)(a.nb_auc + a.nb_hot + a.nb_mid + a.nb_few + nb_single)), block(UPD_THREADS);
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
-#define DFH_UPD(EXACT, HV)                                                                              \
-  if (ea && eb) hipExtLaunchKernelGGL((k_update_fused<LL, EXACT, HV>), grid, block, 0, s, ea, eb, 0, a); \
-  else hipLaunchKernelGGL((k_update_fused<LL, EXACT, HV>), grid, block, 0, s, a)
+#define DFH_UPD(EXACT, HV)                                                                                         \
+  if (mixed) {                                                                                                     \
+    if (ea && eb) hipExtLaunchKernelGGL((k_update_fused<LL, EXACT, HV, true>), grid, block, 0, s, ea, eb, 0, a);    \
+    else hipLaunchKernelGGL((k_update_fused<LL, EXACT, HV, true>), grid, block, 0, s, a);                           \
+  } else {                                                                                                         \
+    if (ea && eb) hipExtLaunchKernelGGL((k_update_fused<LL, EXACT, HV, false>), grid, block, 0, s, ea, eb, 0, a);   \
+    else hipLaunchKernelGGL((k_update_fused<LL, EXACT, HV, false>), grid, block, 0, s, a);                          \
+  }
     if (kp == 4 * LL) {
       if (b->has_value) { DFH_UPD(true, true); } else { DFH_UPD(true, false); }
     } else {
@@ -892,6 +907,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "auc_in_update") {
     DFH_ARG(value == 0 || value == 1, "auc_in_update must be 0 (k_auc_pairs as its own launch) or 1 (a role of k_update_fused)");
     c->auc_in_update = value;
+  } else if (n == "shard_mixed_update") {
+    DFH_ARG(value == 0 || value == 1, "shard_mixed_update must be 0 or 1");
+    c->shard_mixed_update = value;
   } else if (n == "upd_interleave") {
     DFH_ARG(value >= 0 && value <= 64, "upd_interleave must be in [0, 64]");
     c->upd_interleave = value;

@@ -484,11 +484,13 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
 // the pulled-rows buffer belongs to key u; the slots of this rank's own keys [lo, hi) are unused)
 __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,
-                            uint32_t hi, uint2* __restrict__ uw) {
+                            uint32_t hi, uint2* __restrict__ uw, const uint32_t* __restrict__ col_ptr) {
   const uint32_t U = *d_U;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
     if (u - lo < hi - lo) continue;
-    uw[u] = make_uint2(u | kRemoteRow, __float_as_uint(rows[(size_t)u * stride]));
+    // (bit 30: the key occurs once in the minibatch — the singles role of the mixed update launch takes it)
+    const uint32_t single = (col_ptr && col_ptr[u + 1] - col_ptr[u] == 1u) ? kSingleRow : 0u;
+    uw[u] = make_uint2(u | kRemoteRow | single, __float_as_uint(rows[(size_t)u * stride]));
   }
 }
 
@@ -721,9 +723,11 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
 // (inv = 0) or outside (inv = 1) [lo, hi): the sharded store runs the keys this rank owns through the
 // fused in-place update and the others through the gradient-row form.  Default: every key.
 struct KeyRange {
-  uint32_t lo, hi, inv;
+  uint32_t lo, hi, inv;  // inv bit 0: the keys OUTSIDE [lo, hi); bit 1: the gradient-row form also adds up the penalty of the
+                         // rows it reads (EvaluatePenalty over the weights pulled from other owners, sgd_learner.cc:249-273)
 };
-__device__ __forceinline__ bool key_in(const KeyRange& kr, uint32_t u) { return ((u - kr.lo < kr.hi - kr.lo) ? 1u : 0u) != kr.inv; }
+__device__ __forceinline__ bool key_in(const KeyRange& kr, uint32_t u) { return ((u - kr.lo < kr.hi - kr.lo) ? 1u : 0u) != (kr.inv & 1u); }
+__device__ __forceinline__ bool key_pen(const KeyRange& kr) { return (kr.inv & 2u) != 0; }
 
 struct KeySums {
   float gw;    // sum p x
@@ -769,7 +773,7 @@ __device__ __forceinline__ KeyRow load_key_row(const RowSrc& src, const TableVie
 template <int L, bool FUSED>
 __device__ __forceinline__ void finish_key(const BatchView& b, const TableView& t, uint32_t u, const KeyRow& kr, int sub,
                                            bool sub_ok, KeySums s, float* __restrict__ grads, size_t gstride, int k,
-                                           int kp, uint32_t* __restrict__ need_init, double& pen_acc) {
+                                           int kp, uint32_t* __restrict__ need_init, double& pen_acc, bool pen_rows = false) {
   float4 gv = s.gv;
   const float4 v = kr.v;
   if (kr.has_v) {
@@ -780,6 +784,10 @@ __device__ __forceinline__ void finish_key(const BatchView& b, const TableView& 
     float* g = grads + (size_t)u * gstride;
     if (sub == 0) st4(g, make_float4(s.gw, kr.has_v ? 1.0f : 0.0f, 0.f, 0.f));
     if (sub_ok && k > 0) st4(g + 4 + sub * 4, kr.has_v ? gv : make_float4(0.f, 0.f, 0.f, 0.f));
+    if (pen_rows) {  // the rows came from another owner: their penalty is nobody else's to count
+      if (kr.has_v && sub_ok) pen_acc += (double)(0.5f * t.p.V_l2 * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+      if (sub == 0) pen_acc += (double)(t.p.l1 * fabsf(kr.w_old) + 0.5f * t.p.l2 * kr.w_old * kr.w_old);
+    }
     return;
   }
   // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
@@ -932,7 +940,7 @@ __device__ __forceinline__ void mid_role(const BatchView& b, const RowSrc& src, 
       // 14 registers fewer alive through the loop (the kernel runs at 64 registers, 8 waves per SIMD)
       if (grp == 0) {
         const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);
-        finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+        finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc, key_pen(rg));
       }
     }
   }
@@ -987,7 +995,7 @@ __device__ __forceinline__ void hot_role(const BatchView& b, const RowSrc& src, 
         }
       }
       const KeyRow kr = load_key_row<FUSED>(src, t, u, sub, sub_ok, k, kp);  // after the sums, as in the mid role
-      finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc);
+      finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, tot, grads, gstride, k, kp, need_init, pen_acc, key_pen(rg));
     }
   }
   }
@@ -1041,7 +1049,7 @@ __device__ __forceinline__ void small_role(const BatchView& b, const RowSrc& src
           s.gv.z += (a[q].z * pp) * xx; s.gv.w += (a[q].w * pp) * xx;
         }
       }
-      if (mine) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc);
+      if (mine) finish_key<L, FUSED>(b, t, u, kr, sub, sub_ok, s, grads, gstride, k, kp, need_init, pen_acc, key_pen(rg));
     }
   }
 }
@@ -1270,7 +1278,7 @@ __global__ void __launch_bounds__(BWD_THREADS, DFH_BWD_WAVES) k_backward_all(Bat
       small_role<L, FUSED>(b, src, t, grads, gstride, k, kp, need_init, wave, nwaves, rg, pen_acc);
     }
   }
-  if (FUSED) flush_penalty(b, pen_acc);
+  if (FUSED || key_pen(rg)) flush_penalty(b, pen_acc);
 #ifdef DFH_BWD_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 8192) {  // measurement build only (tools/): per-block role and wall-clock span
     g_bwd_trace[blockIdx.x * 3 + 0] = is_big ? (big_id < nb_hot ? 0ull : 1ull) : 2ull;
@@ -1443,7 +1451,7 @@ __global__ void __launch_bounds__(256) k_pull_resolved(TableView t, const uint32
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   for (uint32_t u = group; u < n; u += ngroups) {
-    const uint32_t r = rowid[u];
+    const uint32_t r = rowid[u] & 0x1FFFFFFFu;  // (k_resolve_multi marks a key's worker entry in bit 31)
     const float4 h0 = ld4(reinterpret_cast<const float*>(t.hdr + r));  // {w, has_V, sqrt_g, z}
     const bool hv = __float_as_uint(h0.y) != 0u;
     float* out = rows + (size_t)u * stride;
@@ -1464,7 +1472,7 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   for (uint32_t u = group; u < n; u += ngroups) {
-    const uint32_t r = rowid[u];
+    const uint32_t r = rowid[u] & 0x1FFFFFFFu;
     const float* g = grads + (size_t)u * stride;
     const float4 g0 = ld4(g);
     const bool had_v = g0.y != 0.0f;
@@ -1508,77 +1516,112 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
 // ---------------------------------------------------------------------------
 // Owner side, one launch for ALL source ranks of a step.  The received keys are the
 // concatenation of nsrc ascending lists (SegOff).  k_resolve_multi resolves every entry to
-// its row and ORs the entry's source into a per-row mask (RowHdr::pad[0]).  In the Push
-// kernels the entry of the LOWEST source carrying a key is the key's leader: it finds the
-// key in the later sources (binary search in their ascending lists), applies their values
-// one after the other in source order — exactly what per-source launches would do — and
-// stores the row once.  The last Push of a step (or k_release_rows) clears the mask.
+// its row and LINKS the entries that carry the same key: the row's list head (RowHdr::pad[slot])
+// is exchanged for entry + 1 and the previous head becomes the entry's link.  The entry that finds
+// the head empty — the first of its key to arrive — is the key's WORKER (bit 31 of its row word):
+// in the Push kernels it walks the list (at most nsrc - 1 dependent loads from an L2-resident
+// array; round 4 searched every later source's list by bisection, 14 dependent loads per source),
+// orders the entries by source — sources are concatenated in ascending order, so by entry index —
+// and applies their values one after the other in source order — exactly what per-source launches
+// would do — storing the row once.  Every other entry skips on its row word alone (no header
+// read).  The last Push of a step (or k_release_rows) clears the list head.
+// rowid holds 2 n words: [0, n) the row words, [n, 2 n) the links.
 // ---------------------------------------------------------------------------
 struct SegOff {
   uint32_t off[33];  // entries of source s are [off[s], off[s+1])
   int nsrc;
-  int slot;          // which of the two per-row source masks (RowHdr::pad[0..1]) this step uses: two steps
+  int slot;          // which of the two per-row list heads (RowHdr::pad[0..1]) this step uses: two steps
                      // may be in flight on an owner (one resolved and pulled, the other awaiting its gradients)
 };
-
-__device__ __forceinline__ int seg_source(const SegOff& g, uint32_t e) {
-  int s = 0;
-  while (s + 1 < g.nsrc && e >= g.off[s + 1]) ++s;
-  return s;
-}
-
-// position of `key` in keys[lo, hi) (ascending, present by construction)
-__device__ __forceinline__ uint32_t seg_find(const uint64_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint64_t key) {
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (keys[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
+constexpr uint32_t ROW_ID_MASK = 0x1FFFFFFFu;  // a table holds fewer than 2^29 rows
+constexpr uint32_t ROW_WORKER = 0x80000000u;
+constexpr int MULTI_FAST = 8;                  // entries per key collected in registers (one node: 7 peers)
 
 __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, SegOff g, uint32_t* __restrict__ rowid) {
   const uint32_t n = g.off[g.nsrc];
+  uint32_t* __restrict__ link = rowid + n;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const uint32_t r = find_or_insert(t, keys[e]);
-    rowid[e] = r;
-    atomicOr(&t.hdr[r].pad[g.slot], 1u << seg_source(g, e));
+    const uint32_t prev = atomicExch(&t.hdr[r].pad[g.slot], e + 1);
+    link[e] = prev;
+    rowid[e] = r | (prev == 0 ? ROW_WORKER : 0u);
   }
 }
 
 __global__ void k_release_rows(TableView t, const uint32_t* __restrict__ rowid, uint32_t n, int slot) {
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) t.hdr[rowid[e]].pad[slot] = 0;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const uint32_t rw = rowid[e];
+    if (rw & ROW_WORKER) t.hdr[rw & ROW_ID_MASK].pad[slot] = 0;
+  }
 }
 
-// Push(kFeaCount) of all sources: one thread per entry, the leader adds every source's count
+// the entries of one key, ascending (= source order), from the list that starts at `head` (entry + 1; 0 ends it).
+// Up to MULTI_FAST entries are collected in registers and ordered by a small network; *more = 1 if the list is longer
+// (a job of more than 8 sources: the caller then walks the list once per entry, see multi_next_above).
+__device__ __forceinline__ int multi_collect(const uint32_t* __restrict__ link, uint32_t head, uint32_t (&ent)[MULTI_FAST], bool* more) {
+  int m = 0;
+  uint32_t p = head;
+#pragma unroll
+  for (int i = 0; i < MULTI_FAST; ++i) {
+    ent[i] = 0xFFFFFFFFu;
+    if (p) {
+      ent[i] = p - 1;
+      p = link[p - 1];
+      ++m;
+    }
+  }
+  *more = p != 0;
+  // odd-even transposition sort of 8 registers (unused slots hold ~0 and stay last)
+#pragma unroll
+  for (int pass = 0; pass < MULTI_FAST; ++pass) {
+#pragma unroll
+    for (int i = pass & 1; i + 1 < MULTI_FAST; i += 2) {
+      const uint32_t lo = min(ent[i], ent[i + 1]), hi = max(ent[i], ent[i + 1]);
+      ent[i] = lo;
+      ent[i + 1] = hi;
+    }
+  }
+  return m;
+}
+
+// the smallest entry of the list that is greater than `after` (or ~0): the slow path for more than MULTI_FAST sources
+__device__ __forceinline__ uint32_t multi_next_above(const uint32_t* __restrict__ link, uint32_t head, uint32_t after, bool first) {
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint32_t p = head; p; p = link[p - 1]) {
+    const uint32_t e = p - 1;
+    if ((first || e > after) && e < best) best = e;
+  }
+  return best;
+}
+
+// Push(kFeaCount) of all sources: one thread per entry, the key's worker adds every source's count
 // (small integers: the sum is exact in any order) and then takes the InitV decision once —
 // w does not change during count pushes and fea_cnt only grows, so the outcome equals the
 // sequential one (sgd_updater.cc:62-73)
 __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ rowid, const uint64_t* __restrict__ keys,
                                    SegOff g, const float* __restrict__ cnt) {
   const uint32_t n = g.off[g.nsrc];
+  const uint32_t* __restrict__ link = rowid + n;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const uint32_t r = rowid[e];
+    const uint32_t rw = rowid[e];
+    if (!(rw & ROW_WORKER)) continue;  // another entry of this key works for it
+    const uint32_t r = rw & ROW_ID_MASK;
     RowHdr& h = t.hdr[r];
-    const uint32_t mask = h.pad[g.slot];
-    const int s = seg_source(g, e);
-    if ((mask & (0u - mask)) != (1u << s)) continue;  // an earlier source carries this key: its entry leads
-    const uint64_t key = keys[e];
-    float fc = h.fea_cnt + cnt[e];
-    for (uint32_t m = mask & ~(1u << s); m; m &= m - 1) {
-      const int s2 = __ffs((int)m) - 1;
-      fc += cnt[seg_find(keys, g.off[s2], g.off[s2 + 1], key)];
-    }
+    float fc = h.fea_cnt;
+    for (uint32_t p = h.pad[g.slot]; p; p = link[p - 1]) fc += cnt[p - 1];
     h.fea_cnt = fc;
     if (t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold) {
-      init_v_hash_row(t, r, key);
+      init_v_hash_row(t, r, keys[e]);
       h.has_V = 1;
     }
   }
 }
 
-// Push(kGradient) of all sources: L lanes per entry; the leader applies the sources' gradient rows
+// Push(kGradient) of all sources: L lanes per entry; the key's worker applies the sources' gradient rows
 // one after the other (FTRL on w with lazy InitV, AdaGrad on V iff the rows were pulled with V) on
-// registers and stores the row once; clears the row's source mask
+// registers and stores the row once; clears the row's list head.  The header, the worker's own gradient
+// row and the V / accumulator slices are requested together, before anything is known about the key
+// (80 % of the keys come from one source: their chain is row word -> {header, row, gradient} -> store).
 template <int L>
 __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
                                                          const uint64_t* __restrict__ keys, SegOff g,
@@ -1589,58 +1632,80 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   const uint32_t n = g.off[g.nsrc];
+  const uint32_t* __restrict__ link = rowid + n;
+  const int d = sub * 4;
+  const bool d_ok = d < t.kp;  // this lane's V slice (4 * L >= kp by dispatch: one float4 per lane covers the row)
   for (uint32_t e = group; e < n; e += ngroups) {
-    const uint32_t r = rowid[e];
+    const uint32_t rw = rowid[e];
+    if (!(rw & ROW_WORKER)) continue;
+    const uint32_t r = rw & ROW_ID_MASK;
     RowHdr* hp = t.hdr + r;
-    const uint32_t mask = hp->pad[g.slot];
-    const int s = seg_source(g, e);
-    if ((mask & (0u - mask)) != (1u << s)) continue;
-    const uint64_t key = keys[e];
+    float* va = t.va + (size_t)r * (2 * t.kp);
+    // lanes beyond the row (and V_dim = 0) read valid addresses they do not use: the loads stay unconditional
+    const int goff = d_ok ? 4 + d : 0;
+    const float* vp = d_ok ? va + d : reinterpret_cast<const float*>(hp);
+    const float* ap = d_ok ? va + t.kp + d : reinterpret_cast<const float*>(hp);
+    // one round trip: header (both halves), own gradient row, V and accumulator slices
     const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+    const float fea_cnt = hp->fea_cnt;
+    const uint32_t head = hp->pad[g.slot];
+    const float* g_own = grads + (size_t)e * stride;
+    const float4 go0 = ld4(g_own);
+    const float4 go_v = ld4(g_own + goff);
+    float4 v = ld4(vp), acc = ld4(ap);
     float w = h0.x, sqrt_g = h0.z, z = h0.w;
     uint32_t has_v = __float_as_uint(h0.y);
-    const float fea_cnt = hp->fea_cnt;
-    const float* g_own = grads + (size_t)e * stride;
-    const bool had_v = ld4(g_own).y != 0.0f;  // every source pulled the same model version: one answer
-    if (had_v && !has_v) {                    // CHECK(e.V != nullptr), sgd_updater.cc:92
+    const bool had_v = go0.y != 0.0f;  // every source pulled the same model version: one answer
+    if (had_v && !has_v) {             // CHECK(e.V != nullptr), sgd_updater.cc:92
       if (sub == 0) atomicOr(t.err, 4u);
       if (sub == 0) hp->pad[g.slot] = 0;
       continue;
     }
-    float* va = t.va + (size_t)r * (2 * t.kp);
-    // this lane's V slice (4 * L >= kp by dispatch: one float4 per lane covers the row)
-    const int d = sub * 4;
-    const bool d_ok = d < t.kp;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), acc = v;
-    if (had_v && d_ok) {
-      v = ld4(va + d);
-      acc = ld4(va + t.kp + d);
-    }
-    for (uint32_t m = mask; m; m &= m - 1) {
-      const int s2 = __ffs((int)m) - 1;
-      uint32_t p = e;
-      if (s2 != s) {
-        if (sub == 0) p = seg_find(keys, g.off[s2], g.off[s2 + 1], key);
-        p = __shfl(p, (lane / L) * L, 64);
-      }
-      const float* gp = grads + (size_t)p * stride;
-      const float gw = ld4(gp).x;
+    if (!(had_v && d_ok)) v = acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint64_t key = keys[e];
+    auto apply = [&](float gw, const float4& gv) {
       const float w_old = w;
       w = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
       // lazy InitV when w leaves zero (sgd_updater.cc:122-126); the pulled rows had no V, so no
       // gradient of this step touches the fresh values
       if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
         // every lane of the group reaches this with the same w: each writes its own 16 B of V and of the accumulators
-        // (one lane alone: 2 kp scalar stores behind 2 kp hashes, see upd_init_rows in dfh_update.hip)
         if (d_ok) init_v_hash_slice(t, r, key, d);
         has_v = 1;
       }
       if (had_v && d_ok) {
-        const float4 gv = ld4(gp + 4 + d);
         adagrad_update_v(gv.x, v.x, acc.x, t.p);
         adagrad_update_v(gv.y, v.y, acc.y, t.p);
         adagrad_update_v(gv.z, v.z, acc.z, t.p);
         adagrad_update_v(gv.w, v.w, acc.w, t.p);
+      }
+    };
+    if (head == e + 1) {  // the usual case: one source carries the key (the worker arrived first AND last)
+      apply(go0.x, go_v);
+    } else {
+      uint32_t ent[MULTI_FAST];
+      bool more;
+      const int m = multi_collect(link, head, ent, &more);
+      if (!more) {
+        // all gradient rows requested before the first is applied (unconditional loads on clamped entries)
+        float gws[MULTI_FAST];
+        float4 gvs[MULTI_FAST];
+#pragma unroll
+        for (int i = 0; i < MULTI_FAST; ++i) {
+          const float* gp = grads + (size_t)(i < m ? ent[i] : e) * stride;
+          gws[i] = ld4(gp).x;
+          gvs[i] = ld4(gp + goff);
+        }
+#pragma unroll
+        for (int i = 0; i < MULTI_FAST; ++i)
+          if (i < m) apply(gws[i], gvs[i]);
+      } else {
+        uint32_t cur = multi_next_above(link, head, 0u, true);
+        while (cur != 0xFFFFFFFFu) {
+          const float* gp = grads + (size_t)cur * stride;
+          apply(ld4(gp).x, ld4(gp + goff));
+          cur = multi_next_above(link, head, cur, false);
+        }
       }
     }
     if (sub == 0) {

@@ -862,7 +862,7 @@ int flight_bufs(dfh_shard* s, const dfh_shard::Flight& f, size_t stride) {
   }
   if (f.nrecv > s->r_cap[q]) {
     const size_t cap = f.nrecv + f.nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) || (rc = grow(&s->r_rowid[q], cap, st)) ||
+    if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) || (rc = grow(&s->r_rowid[q], 2 * cap, st)) ||
         (rc = grow(&s->r_rows[q], cap * stride, st)))
       return rc;
     s->r_cap[q] = cap;
@@ -1106,7 +1106,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   // ---- buffers
   if (nrecv > s->r_cap[0]) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], cap, st)) ||
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], 2 * cap, st)) ||
         (rc = grow(&s->r_rows[0], cap * stride, st)))
       return rc;
     s->r_cap[0] = cap;
@@ -1183,7 +1183,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     if (rc) return rc;
   }
   // ---- F: the worker's math: own keys on the table, the others on the pulled rows
-  const KeyRange own{own_lo, own_hi, 0u}, others{own_lo, own_hi, 1u};
+  const KeyRange own{own_lo, own_hi, 0u}, others{own_lo, own_hi, 1u}, others_pen{own_lo, own_hi, 3u};
   if (b) {
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     rc = ensure_xv(b, kp);
@@ -1191,7 +1191,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (any_remote) {
       hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(U, ctx)), dim3(256), 0, st, s->w_rows[0], stride, b->d_U, own_lo, own_hi,
-                         b->d_uw);
+                         b->d_uw, b->d_col_ptr);
       DFH_HIP(hipGetLastError());
     }
     MixSrc mix{any_remote ? s->w_rows[0] + 4 : nullptr, stride};
@@ -1199,34 +1199,46 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     if (rc) return rc;
     // BinClassMetric::AUC of the minibatch: rides in the own keys' update launch of a training step (k_update_fused has idle
     // VALUs), a launch of its own otherwise
-    bool auc_rides = b->compute_auc && is_train && any_own && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
+    // round 5: with keys of other ranks in the minibatch ONE launch of k_update_fused<MIXED> serves all keys — gradient rows for
+    // the others' keys, the in-place update for the own ones (ctx option shard_mixed_update = 0: the two launches of round 4)
+    const bool mixed = is_train && any_remote && ctx->upd_kernel != 0 && ctx->shard_mixed_update != 0;
+    bool auc_rides = b->compute_auc && is_train && (any_own || mixed) && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
     if (b->compute_auc && !auc_rides) {
       rc = launch_auc(b);
       if (rc) return rc;
     }
     BatchView bv = batch_view(b);
     const int pgrid = have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
-    if (any_remote) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
+    if (any_remote && !is_train) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows[0], k), t->v, k, kp, others);
       DFH_HIP(hipGetLastError());
     }
-    if (is_train && any_remote) {
-      TableView dummy{};
-      rc = launch_backward<false>(b, packed_src(s->w_rows[0], k), dummy, s->w_grads[0], stride, k, kp, nullptr, others);
+    if (mixed) {
+      const bool with_auc = auc_rides && b->nrows <= AUC_PAIRS_MAX_N && UPD_THREADS == 256;
+      rc = launch_update_fused(b, t->v, k, kp, b->d_need, b->d_uw, kAllKeys, push_cnt != 0, with_auc, s->w_rows[0], s->w_grads[0], stride);
       if (rc) return rc;
-    }
-    if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
-      const bool auc_wanted = auc_rides;
-      rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0,
-                                 &auc_rides);
-      if (rc) return rc;
-      if (auc_wanted && !auc_rides) {  // the minibatch is beyond the pair-counting size
+      if (auc_rides && !with_auc) {  // the minibatch is beyond the pair-counting size
         rc = launch_auc(b);
         if (rc) return rc;
       }
-    } else if (any_own) {
-      hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
-      DFH_HIP(hipGetLastError());
+    } else {
+      if (is_train && any_remote) {  // the gradient-row launch reads every pulled row anyway: it adds up their penalty too
+        rc = launch_backward<false>(b, packed_src(s->w_rows[0], k), t->v, s->w_grads[0], stride, k, kp, nullptr, others_pen);
+        if (rc) return rc;
+      }
+      if (is_train && any_own) {  // the fused in-place update accumulates the own keys' penalty itself
+        const bool auc_wanted = auc_rides;
+        rc = launch_backward<true>(b, tsrc, t->v, nullptr, 0, k, kp, b->d_need, own, b->d_uw, push_cnt != 0 && ctx->upd_kernel != 0,
+                                   &auc_rides);
+        if (rc) return rc;
+        if (auc_wanted && !auc_rides) {  // the minibatch is beyond the pair-counting size
+          rc = launch_auc(b);
+          if (rc) return rc;
+        }
+      } else if (any_own) {
+        hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, tsrc, t->v, k, kp, own);
+        DFH_HIP(hipGetLastError());
+      }
     }
   }
   // ---- the counts of the FOLLOWING step (dfh_shard_prefetch_counts): on their way to the host while this
@@ -1349,11 +1361,12 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     DFH_HIP(hipEventRecord(s->cnt_ev, cs));
   }
   // ---- F: the worker's math: own keys on the table, the others on the pulled rows
-  const KeyRange own{cur.own_lo, cur.own_hi, 0u}, others{cur.own_lo, cur.own_hi, 1u};
+  const KeyRange own{cur.own_lo, cur.own_hi, 0u}, others{cur.own_lo, cur.own_hi, 1u}, others_pen{cur.own_lo, cur.own_hi, 3u};
   const int q = cur.slot;
   // BinClassMetric::AUC of the minibatch: rides in the own keys' update launch of a training step (k_update_fused has idle
   // VALUs), a launch of its own otherwise
-  bool auc_rides = b && b->compute_auc && is_train && cur.any_own && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
+  const bool mixed = b && is_train && cur.any_remote && ctx->upd_kernel != 0 && ctx->shard_mixed_update != 0;  // (see the sync step)
+  bool auc_rides = b && b->compute_auc && is_train && (cur.any_own || mixed) && ctx->auc_in_update != 0 && ctx->upd_kernel != 0;
   if (b) {
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     rc = ensure_xv(b, kp);
@@ -1362,7 +1375,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (cur.any_remote) {
       hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, s->w_rows[q], stride, b->d_U, cur.own_lo,
-                         cur.own_hi, b->d_uw);
+                         cur.own_hi, b->d_uw, b->d_col_ptr);
       DFH_HIP(hipGetLastError());
     }
     MixSrc mix{cur.any_remote ? s->w_rows[q] + 4 : nullptr, stride};
@@ -1374,18 +1387,25 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     }
     BatchView bv = batch_view(b);
     const int pgrid = cur.have ? std::min(grid_for_waves(b->nnz, ctx), PROG_SLOTS) : 1;
-    if (cur.any_remote) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
+    if (cur.any_remote && !is_train) {  // EvaluatePenalty over the pulled weights (sgd_learner.cc:249-273)
       hipLaunchKernelGGL((k_penalty<1>), dim3(pgrid), dim3(256), 0, st, bv, packed_src(s->w_rows[q], k), t->v, k, kp, others);
       DFH_HIP(hipGetLastError());
     }
-    if (is_train && cur.any_remote) {
-      TableView dummy{};
-      rc = launch_backward<false>(b, packed_src(s->w_rows[q], k), dummy, s->w_grads[q], stride, k, kp, nullptr, others);
+    if (mixed) {  // gradient rows of the others' keys AND the own keys' in-place update, one launch
+      const bool with_auc = auc_rides && b->nrows <= AUC_PAIRS_MAX_N && UPD_THREADS == 256;
+      rc = launch_update_fused(b, t->v, k, kp, b->d_need, b->d_uw, kAllKeys, push_cnt != 0, with_auc, s->w_rows[q], s->w_grads[q], stride);
+      if (rc) return rc;
+      if (auc_rides && !with_auc) {
+        rc = launch_auc(b);
+        if (rc) return rc;
+      }
+    } else if (is_train && cur.any_remote) {  // the gradient-row launch reads every pulled row anyway: it adds up their penalty too
+      rc = launch_backward<false>(b, packed_src(s->w_rows[q], k), t->v, s->w_grads[q], stride, k, kp, nullptr, others_pen);
       if (rc) return rc;
     }
   }
   if (is_train) DFH_HIP(hipEventRecord(s->ev_f, st));  // the gradient rows are complete: G may start ...
-  if (b) {  // ... while the own keys are updated in place
+  if (b && !mixed) {  // ... while the own keys are updated in place
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (is_train && cur.any_own) {  // the fused in-place update accumulates the own keys' penalty itself
@@ -1496,7 +1516,7 @@ int host_call_bufs(dfh_shard* s, size_t nrecv, size_t n, size_t stride) {
   int rc;
   if (nrecv > s->r_cap[0]) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], cap, st)) ||
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], 2 * cap, st)) ||
         (rc = grow(&s->r_rows[0], cap * stride, st)))
       return rc;
     s->r_cap[0] = cap;

@@ -89,6 +89,13 @@ struct UpdArgs {
   const float* auc_label;
   uint32_t* auc_part;       // the units' slots (auc_pairs_block); finalised by a later launch (auc_finalize_block)
   uint32_t nb_auc;
+  // MIXED (sharded store, round 5): the keys OTHER ranks own (kRemoteRow in the row word; their "row" is the key's rank u)
+  // read [w, has_V, 0, 0 | V] from the rows those owners sent and leave [gw, has_V, 0, 0 | gV] for them — CalcGrad in the
+  // exchange layout, what k_backward_all<FUSED = false> did in a launch of its own — while this rank's own keys are
+  // updated in place, all in ONE launch
+  const float* rrows;       // pulled rows, rstride floats each, indexed by the key's rank
+  float* grows;             // gradient rows out, same layout
+  uint32_t rstride;
 };
 
 // Model rows (V, accumulators) are loaded and stored with streaming (nt) hints.  Measured dead end, kept as
@@ -138,10 +145,10 @@ __device__ __forceinline__ void upd_init_rows(const UpdArgs& a, int L) {
 // SGDUpdater::Update(kGradient) for one key whose sums are complete: executed by the L lanes of ONE
 // group (the caller masks the others).  h0 = {w, has_V, sqrt_g, z}; vv / ac: this lane's V and
 // accumulator slices; g4: sum of (XV p) x over the occurrences.
-template <bool EXACT>
+template <bool EXACT, bool MIXED = false>
 __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t u, const float4 h0, const float4 vv, const float4 ac,
                                           float gw, float xxp, float4 g4, int sub, bool sub_ok, int k, int kp, float& pen, float fc,
-                                          float cnt, bool cnt_later) {
+                                          float cnt, bool cnt_later, bool remote = false) {
   const float w_old = h0.x;
   const bool has_v = k > 0 && __float_as_uint(h0.y) != 0u;
   RowHdr* hp = a.hdr + r;
@@ -151,6 +158,15 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
     g4.x -= vv.x * xxp; g4.y -= vv.y * xxp; g4.z -= vv.z * xxp; g4.w -= vv.w * xxp;
     // penalty of the PULLED weights (SGDLearner::EvaluatePenalty, sgd_learner.cc:249-273)
     if (sub_ok) pen += 0.5f * a.p.V_l2 * (vv.x * vv.x + vv.y * vv.y + vv.z * vv.z + vv.w * vv.w);
+  }
+  if (MIXED && remote) {  // another rank's key (uniform per lane group): its gradient row, for the owner to apply
+    float* g = a.grows + (size_t)u * a.rstride;
+    if (sub == 0) {
+      pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
+      st4_nt(g, make_float4(gw, has_v ? 1.0f : 0.0f, 0.f, 0.f));
+    }
+    if (sub_ok && k > 0) st4_nt(g + 4 + sub * 4, has_v ? g4 : make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
   }
   if (sub == 0) {
     pen += a.p.l1 * fabsf(w_old) + 0.5f * a.p.l2 * w_old * w_old;
@@ -215,6 +231,31 @@ __device__ __forceinline__ void upd_load_row(const UpdArgs& a, uint32_t r, int s
   h0 = DFH_UPD_NT ? ld4_nt(reinterpret_cast<const float*>(a.hdr + r)) : ld4(reinterpret_cast<const float*>(a.hdr + r));
   vv = ld4_nt(va);
   ac = ld4_nt(va + kp);
+}
+
+// MIXED: the same for a key whose row word may name another rank's key (kRemoteRow: "row" = the key's rank u, in the
+// rows its owner sent).  The ADDRESSES are selected per lane group, the loads stay unconditional; a pulled row has no
+// accumulators (its V slice is read twice) and no count.
+__device__ __forceinline__ void upd_load_row_mixed(const UpdArgs& a, uint32_t rw, int sub, bool sub_ok, int kp, float4& h0, float4& vv,
+                                                   float4& ac, float& fc) {
+  const bool remote = (rw & kRemoteRow) != 0u;
+  const uint32_t r = rw & kRowMask;
+  const float* prow = a.rrows + (size_t)r * a.rstride;
+  const float* va = a.va + (size_t)r * (size_t)(2 * kp) + (sub_ok ? sub * 4 : 0);
+  const float* pv = remote ? prow + 4 + (sub_ok ? sub * 4 : 0) : va;
+  const float* pa = remote ? pv : va + kp;
+  const float* ph = remote ? prow : reinterpret_cast<const float*>(a.hdr + r);
+  const float* pc = remote ? prow + 2 : &a.hdr[r].fea_cnt;   // a pulled row holds 0 there
+  fc = *pc;
+  h0 = ld4(ph);
+  vv = ld4_nt(pv);
+  ac = ld4_nt(pa);
+}
+template <bool MIXED>
+__device__ __forceinline__ void upd_load(const UpdArgs& a, uint32_t rw, int sub, bool sub_ok, int kp, float4& h0, float4& vv, float4& ac,
+                                         float& fc) {
+  if (MIXED) upd_load_row_mixed(a, rw, sub, sub_ok, kp, h0, vv, ac, fc);
+  else upd_load_row(a, rw & kRowMask, sub, sub_ok, kp, h0, vv, ac, fc);
 }
 
 // 16 B from a batch-sized array: uniform base + 32-bit byte offset (one address register per load in flight)
@@ -288,7 +329,7 @@ __device__ __forceinline__ bool upd_team(uint32_t unit, uint32_t units, uint32_t
 }
 
 // ---- hot: one key per block and iteration
-template <int L, bool EXACT, int DB, bool HAS_VAL>
+template <int L, bool EXACT, int DB, bool HAS_VAL, bool MIXED>
 __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uint32_t nblk, float& pen) {
   __shared__ float part[UPD_NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
   const int lane = lane_id();
@@ -322,7 +363,7 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
       if (w == 0 && grp == 0) {
         float4 h0, vv, ac;
         float fc;
-        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
+        upd_load<MIXED>(a, rw, sub, sub_ok, kp, h0, vv, ac, fc);
         float gw = 0.f, xxp = 0.f;
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -334,14 +375,15 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
             g4.z += part[i][2 + sub * 4 + 2]; g4.w += part[i][2 + sub * 4 + 3];
           }
         }
-        upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)(end - beg), (rw & kCountLater) != 0u);
+        upd_apply<EXACT, MIXED>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)(end - beg), (rw & kCountLater) != 0u,
+                                (rw & kRemoteRow) != 0u);
       }
     }
   }
 }
 
 // ---- mid: one key per wave and iteration
-template <int L, bool EXACT, int DB, bool HAS_VAL>
+template <int L, bool EXACT, int DB, bool HAS_VAL, bool MIXED>
 __device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
   const int lane = lane_id();
   const int grp = lane / L, sub = lane % L;
@@ -366,16 +408,16 @@ __device__ __forceinline__ void upd_mid_role(const UpdArgs& a, uint32_t wave, ui
       if (grp == 0) {
         float4 h0, vv, ac;
         float fc;
-        upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
-        upd_apply<EXACT>(a, r, u, h0, vv, ac, s.gw, s.xxp, s.gv, sub, sub_ok, k, kp, pen, fc, (float)(end - beg),
-                         (rw & kCountLater) != 0u);
+        upd_load<MIXED>(a, rw, sub, sub_ok, kp, h0, vv, ac, fc);
+        upd_apply<EXACT, MIXED>(a, r, u, h0, vv, ac, s.gw, s.xxp, s.gv, sub, sub_ok, k, kp, pen, fc, (float)(end - beg),
+                                (rw & kCountLater) != 0u, (rw & kRemoteRow) != 0u);
       }
     }
   }
 }
 
 // ---- few: one L-lane group per key, occurrences in row order
-template <int L, bool EXACT, bool HAS_VAL>
+template <int L, bool EXACT, bool HAS_VAL, bool MIXED>
 __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
   constexpr int G = 64 / L;
   constexpr int FD = DFH_UPD_FEW_DEPTH;
@@ -404,11 +446,11 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
       // round trip 2: the row word — and, with it, the first occurrences (the segment is known already)
       const uint32_t rw = ld_rowword(a.uw + u);
       // a group without a key of its own (list exhausted, key of another rank) reads row 0 and drops it
-      const uint32_t r = (act && (rw & kRemoteRow) == 0u) ? (rw & kRowMask) : 0u;
+      const uint32_t r = (act && (MIXED || (rw & kRemoteRow) == 0u)) ? (rw & kRowMask) : 0u;
       // round trip 3: the model row (beside the slopes and XV rows of the first occurrences)
       float4 h0, vv, ac;
       float fc;
-      upd_load_row(a, r, sub, sub_ok, kp, h0, vv, ac, fc);
+      upd_load<MIXED>(a, act ? rw : 0u, sub, sub_ok, kp, h0, vv, ac, fc);
       float gw = 0.f, xxp = 0.f;
       float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (uint32_t j0 = 0; __ballot(j0 < len) != 0ull; j0 += FD) {
@@ -436,7 +478,8 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
           g4.z += (av[d].z * pp) * xx; g4.w += (av[d].w * pp) * xx;
         }
       }
-      if (act) upd_apply<EXACT>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)len_all, (rw & kCountLater) != 0u);
+      if (act) upd_apply<EXACT, MIXED>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)len_all, (rw & kCountLater) != 0u,
+                                       (rw & kRemoteRow) != 0u);
     }
   }
 }
@@ -445,12 +488,12 @@ __device__ __forceinline__ void upd_few_role(const UpdArgs& a, uint32_t wave, ui
 // one tile of <= 64 nonzeros of example i: lane l holds nonzero base + l (u = rank of its key, x its value, rw its row
 // word, valid = it exists); p = the example's slope, xvi = this lane's slice of XV_i.  Shared by the singles role of
 // k_update_fused (and, in the round-4 experiment noted at the end of this file, by the forward's epilogue).
-template <int L, bool EXACT, int RB>
+template <int L, bool EXACT, int RB, bool MIXED = false>
 __device__ __forceinline__ void upd_singles_tile(const UpdArgs& a, bool valid, uint32_t u, float x, uint32_t rw, float p, const float4 xvi,
                                                  int grp, int sub, bool sub_ok, int k, int kp, float& pen) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
-  const bool single = valid && (rw & (kSingleRow | kRemoteRow)) == kSingleRow && key_in(a.rg, u);
+  const bool single = valid && (MIXED ? (rw & kSingleRow) != 0u : (rw & (kSingleRow | kRemoteRow)) == kSingleRow) && key_in(a.rg, u);
   const unsigned long long mask = __ballot(single);
   const int n1 = __popcll(mask);
   if (n1 == 0) return;
@@ -458,7 +501,7 @@ __device__ __forceinline__ void upd_singles_tile(const UpdArgs& a, bool valid, u
   // others are packed behind them)
   const int rank = __popcll(mask & ((1ull << lane) - 1ull));
   const int dest = (single ? rank : n1 + (lane - rank)) * 4;
-  const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & (kRowMask | kCountLater)));
+  const uint32_t c_r = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(rw & (kRowMask | kCountLater | (MIXED ? kRemoteRow : 0u))));
   const uint32_t c_u = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)u);
   const float c_x = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(x)));
   for (int t0 = 0; t0 < n1; t0 += RB * G) {
@@ -471,7 +514,7 @@ __device__ __forceinline__ void upd_singles_tile(const UpdArgs& a, bool valid, u
       rr[q] = __shfl(c_r, t, 64);
       uu[q] = __shfl(c_u, t, 64);
       xs[q] = __shfl(c_x, t, 64);
-      upd_load_row(a, rr[q] & kRowMask, sub, sub_ok, kp, h0[q], vv[q], ac[q], fcs[q]);
+      upd_load<MIXED>(a, rr[q], sub, sub_ok, kp, h0[q], vv[q], ac[q], fcs[q]);
     }
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
@@ -480,14 +523,14 @@ __device__ __forceinline__ void upd_singles_tile(const UpdArgs& a, bool valid, u
         // one occurrence: the segmented sums of the other roles with a single term (0 + term)
         const float gw = p != 0.f ? p * xx : 0.f, xxp = p != 0.f ? p * (xx * xx) : 0.f;  // spmv.h:155
         const float4 g4 = make_float4((xvi.x * p) * xx, (xvi.y * p) * xx, (xvi.z * p) * xx, (xvi.w * p) * xx);
-        upd_apply<EXACT>(a, rr[q] & kRowMask, uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen, fcs[q], 1.0f,
-                         (rr[q] & kCountLater) != 0u);
+        upd_apply<EXACT, MIXED>(a, rr[q] & kRowMask, uu[q], h0[q], vv[q], ac[q], gw, xxp, g4, sub, sub_ok, k, kp, pen, fcs[q], 1.0f,
+                                (rr[q] & kCountLater) != 0u, (rr[q] & kRemoteRow) != 0u);
       }
     }
   }
 }
 
-template <int L, bool EXACT, int RB, bool HAS_VAL>
+template <int L, bool EXACT, int RB, bool HAS_VAL, bool MIXED>
 __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave, uint32_t nwaves, float& pen) {
   const int lane = lane_id();
   const int grp = lane / L, sub = lane % L;
@@ -505,7 +548,7 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
       const uint32_t u = ldu_s(a.index + j);
       const float x = HAS_VAL ? ldf_s(a.value + j) : 1.0f;
       const uint32_t rw = ld_rowword(a.uw + u);
-      upd_singles_tile<L, EXACT, RB>(a, valid, u, x, rw, p, xvi, grp, sub, sub_ok, k, kp, pen);
+      upd_singles_tile<L, EXACT, RB, MIXED>(a, valid, u, x, rw, p, xvi, grp, sub, sub_ok, k, kp, pen);
     }
   }
 }
@@ -526,7 +569,7 @@ __device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
   }
 }
 
-template <int L, bool EXACT, bool HAS_VAL>
+template <int L, bool EXACT, bool HAS_VAL, bool MIXED = false>
 __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
   if (blockIdx.x < a.nb_auc) {  // uniform per block; nb_auc is auc_units(nrows) rounded up to 8 (see the XCD note below)
     if (blockIdx.x < auc_units(a.nrows)) auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_part);
@@ -564,17 +607,17 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
   }
   if (!list_role) {
     if (DFH_UPD_ROLES & 8)
-    upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL>(a, bid * UPD_NW + w, nb_single * UPD_NW, pen);
+    upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL, MIXED>(a, bid * UPD_NW + w, nb_single * UPD_NW, pen);
   } else if (bid < a.nb_hot) {
     if (DFH_UPD_ROLES & 1)
-    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid, a.nb_hot, pen);
+    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen);
   } else if ((bid -= a.nb_hot) < a.nb_mid) {
     if (DFH_UPD_ROLES & 2)
-    upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);
+    upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);
   } else {
     bid -= a.nb_mid;
     if (DFH_UPD_ROLES & 4)
-    upd_few_role<L, EXACT, HAS_VAL>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
+    upd_few_role<L, EXACT, HAS_VAL, MIXED>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
   }
   upd_init_rows(a, L);
   upd_flush_penalty(a.prog, pen);

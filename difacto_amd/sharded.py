@@ -46,6 +46,56 @@ def balanced_splits(sample_keys, world):
     return s[q].astype(np.uint64)
 
 
+def blended_splits(id_sample, data_sample, world, alpha):
+    """first keys of shards 1 .. world-1 at the quantiles of the MIXTURE alpha * (keys the minibatches carry) + (1 - alpha) *
+    (keys of the id space).  alpha = 0 balances the rows every shard holds, alpha = 1 the keys every owner receives per step
+    (what dfh_shard_balanced_splits does with samples of the ranks' first minibatches, the C++ store's default).  The two
+    differ a lot on Criteo-shaped data: the slot id sits in the top bits of a reversed key (EncodeFeaGrpID + ReverseBytes,
+    base.h:39-63), the 13 integer slots hold 0.4 % of the ids and a third of a minibatch's keys, so ranges balanced on the
+    ids alone give one owner 2x the average traffic and another 0.13x (8 ranks); balanced on the traffic alone they give
+    one owner 30 % of the rows.  Identical on every rank when the samples are."""
+    if world == 1:
+        return np.zeros(0, np.uint64)
+    a = np.sort(np.asarray(id_sample, dtype=np.uint64))
+    b = np.sort(np.asarray(data_sample, dtype=np.uint64))
+    if alpha <= 0 or len(b) == 0:
+        return balanced_splits(a, world)
+    if alpha >= 1 or len(a) == 0:
+        return balanced_splits(b, world)
+    pts = np.concatenate([a, b])
+    wts = np.concatenate([np.full(len(a), (1.0 - alpha) / len(a)), np.full(len(b), alpha / len(b))])
+    o = np.argsort(pts, kind="stable")
+    pts, cw = pts[o], np.cumsum(wts[o])
+    return np.array([pts[min(int(np.searchsorted(cw, d / world)), len(pts) - 1)] for d in range(1, world)], dtype=np.uint64)
+
+
+def bench_splits(args, world, gen_factory, S):
+    """the key ranges of the N > 1 bench lines (identical on every rank: the workers' streams are seeded by rank, so every
+    rank can draw every worker's first minibatches itself).  --key-ranges data (default: balanced on the keys the minibatches
+    carry), ids (on the id space), blend (--blend-alpha between the two; what a model near the HBM capacity needs), uniform."""
+    from . import synth
+    mode = "uniform" if getattr(args, "uniform_ranges", False) else getattr(args, "key_ranges", "data")
+    if world == 1:
+        return None, mode
+    if mode == "uniform":
+        return uniform_splits(world), mode
+    alpha = {"data": 1.0, "ids": 0.0, "blend": float(getattr(args, "blend_alpha", 0.5))}[mode]
+    g = gen_factory()
+    ids = np.zeros(0, np.uint64)
+    if alpha < 1:
+        ids = np.concatenate([synth.reverse_bytes_np(g.ids_of(q, np.arange(0, int(g.vocab[q]), 61, dtype=np.uint64))) for q in range(S)])
+    data = np.zeros(0, np.uint64)
+    if alpha > 0:
+        parts = []
+        for p in range(world):
+            gp = gen_factory()
+            gp.rng = np.random.default_rng(5000 + p)   # not the timed streams: ranges come from a sample, as in production
+            for _ in range(2):
+                parts.append(np.unique(synth.reverse_bytes_np(gp.batch(args.rows)["index"])))
+        data = np.concatenate(parts)
+    return blended_splits(ids, data, world, alpha), mode
+
+
 def owner_of(keys, splits):
     """shard index of every (reversed) key"""
     return np.searchsorted(np.asarray(splits, dtype=np.uint64), np.asarray(keys, dtype=np.uint64), side="right")
@@ -100,14 +150,7 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
     comm_info = comm.info()
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
-    splits = None
-    if world > 1 and not args.uniform_ranges:
-        # balanced on the id space (= on the rows every shard holds): the split keys come out of the library
-        # (dfh_shard_balanced_splits: quantiles of the union of the ranks' samples); every rank samples other slots
-        sample = [synth.reverse_bytes_np(gen.all_ids(g))[::61] for g in range(S) if g % world == rank]
-        splits = comm.balanced_splits(np.concatenate(sample) if sample else np.zeros(0, np.uint64))
-    elif world > 1:
-        splits = uniform_splits(world)
+    splits, ranges_mode = bench_splits(args, world, lambda: synth.CriteoSynth(total_ids=args.ids, seed=42), S)
     owned = 0
     mine = []
     for g in range(S):
@@ -270,7 +313,7 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
                        "step": "device localize + key/row/gradient all-to-all-v + predict + calcgrad + in-place update (dfh_shard_step)",
                        "avg_unique_keys_per_batch": tot[2] / world, "prefilled": not args.no_prefill, "hyper": hyper,
                        "dry_run_shared_gpu": shared,
-                       "key_ranges": "uniform" if args.uniform_ranges else "balanced on the id space",
+                       "key_ranges": ranges_mode,
                        "exchange": ("overlap: two minibatches in flight inside dfh_shard_step (staleness <= 1 for rows of other "
                                     "owners, sgd_learner.cc:219-223), collectives on their own stream"
                                     if args.exchange == "overlap" else "sync: one minibatch at a time, zero staleness"),
@@ -336,11 +379,7 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
     all_keys = [synth.reverse_bytes_np(gen.all_ids(g)) for g in range(S)] if args.ids <= 40_000_000 else None
-    if all_keys is not None:
-        splits = balanced_splits(np.concatenate([a[::61] for a in all_keys]), W)
-    else:   # a sample of every slot's ids is enough for the quantiles
-        splits = balanced_splits(np.concatenate([synth.reverse_bytes_np(gen.ids_of(g, np.arange(0, int(gen.vocab[g]), 997, dtype=np.uint64)))
-                                                 for g in range(S)]), W)
+    splits, ranges_mode = bench_splits(args, W, lambda: synth.CriteoSynth(total_ids=args.ids, seed=42), S)
     # the W workers' streams (one generator object each: every worker draws its own data part, sgd_learner.cc:78-89).  Only the
     # emulated ranks' minibatches are kept as raw CSR; of the others only the localized key lists are needed.
     def stream(p):
@@ -379,7 +418,7 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
         "config": {"workload": "C4/C5 projection: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, model row-sharded by key range "
                                "over %d ranks, rank(s) %s emulated on 1 MI355X" % (args.ids, k, W, ranks),
                    "rows_per_step_per_gpu": B, "parallelism": "shard%d (emulated)" % W, "exchange": args.exchange, "hyper": hyper,
-                   "distinct_batches_per_rank": nd, "key_ranges": "balanced on the id space",
+                   "distinct_batches_per_rank": nd, "key_ranges": ranges_mode,
                    "transport": "loop-back (device copies of the exact message sizes; sends read once, receives copied from fed buffers)"},
         "ranks": results,
         "streams_seconds": t_streams,

@@ -116,14 +116,14 @@ class HipBackend:
     # ---- owner side: the keys received in a step (concatenated ascending lists, source s in
     # [seg[s], seg[s+1])) are resolved to rows once; every operation is one launch for all sources
     def owner_resolve(self, keys, seg, mslot=0):
-        rowid = torch.empty(keys.numel(), dtype=torch.int32, device=self.device)
+        rowid = torch.empty(2 * keys.numel(), dtype=torch.int32, device=self.device)   # row words + links
         if keys.numel():
             self.table.shard_resolve_multi(keys, seg, rowid, mslot)
         return rowid
 
     def owner_pull(self, rowid, keys, rows, seg):
         if keys.numel():
-            self.table.shard_pull_resolved(rowid, rowid.numel(), rows)
+            self.table.shard_pull_resolved(rowid, keys.numel(), rows)
 
     def owner_push_count(self, rowid, keys, cnt, seg, mslot=0):
         """Push(kFeaCount) of every source, applied in source order"""
@@ -138,7 +138,7 @@ class HipBackend:
     def owner_release(self, rowid, mslot=0):
         """ends a step that pushes no gradients (validation)"""
         if rowid.numel():
-            self.table.shard_release(rowid, rowid.numel(), mslot)
+            self.table.shard_release(rowid, rowid.numel() // 2, mslot)
 
     def sync(self):
         self.ctx.sync()

@@ -668,8 +668,8 @@ def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
 
 
 @pytest.mark.parametrize("V_dim", [0, 6, 64])
-@pytest.mark.parametrize("form", ["resolved", "multi"])
-def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
+@pytest.mark.parametrize("form,G", [("resolved", 4), ("multi", 4), ("multi", 8), ("multi", 11)])
+def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
     """keys arriving from several source ranks in one step (the same key under more than one
     source).  Two forms of the owner side must equal the per-source dfh_shard_* calls
     (parity-tested above) applied in source order:
@@ -684,7 +684,8 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
     ta = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # form under test
     tb = capi.Table(ctx, 1 << 14, V_dim=V_dim, **kw)  # per-source calls
     universe = np.unique(rng.integers(0, 2 ** 64 - 1, 3000, dtype=np.uint64))
-    G = 4
+    # G = 8: a key carried by every peer of a node fills the register list of k_push_grad_multi; G = 11: beyond it (the
+    # walk-per-entry path)
     for step in range(7):
         srcs = [np.sort(rng.choice(universe, size=int(rng.integers(0 if step == 3 else 200, 900)), replace=False))
                 for _ in range(G)]
@@ -697,7 +698,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
         train = step != 6          # the last step pushes no gradients (validation): release instead
         keys = torch.from_numpy(np.concatenate(srcs).view(np.int64)).to(dev)
         cnt = torch.from_numpy(rng.integers(1, 5, n).astype(np.float32)).to(dev)
-        rowid = torch.empty(n, dtype=torch.int32, device=dev)
+        rowid = torch.empty(2 * n, dtype=torch.int32, device=dev)   # row words + the links of resolve_multi
         rows_a = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         rows_b = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()  # the fixture's context runs on its own (non-blocking) stream
@@ -750,7 +751,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form):
     assert ta.size() == tb.size()
     if form == "multi":  # every source mask was cleared: a fresh multi step must see clean rows
         keys = torch.from_numpy(universe[:100].view(np.int64).copy()).to(dev)
-        rowid = torch.empty(100, dtype=torch.int32, device=dev)
+        rowid = torch.empty(200, dtype=torch.int32, device=dev)
         rows = torch.zeros((100, stride), dtype=torch.float32, device=dev)
         zeros = torch.zeros((100, stride), dtype=torch.float32, device=dev)
         zeros[:, 1] = 0

@@ -61,9 +61,10 @@ def subset_push(store, kind, keys, grads, lens, mask):
     store.push(keys[sel], kind, g, lens[sel])
 
 
-def emulate(oracle, batches, V_dim, hyper, splits):
+def emulate(oracle, batches, V_dim, hyper, splits, rec=None):
     """ONE store receiving the ranks' requests of every step: count pushes, pulls, then the gradient pushes —
-    per key the owner's own push first, then the other ranks' in ascending rank order"""
+    per key the owner's own push first, then the other ranks' in ascending rank order.  rec (a list): per step what every
+    rank localized, pulled and pushed (tests/test_loopback_emulation.py plays one rank's peers back from it)"""
     from oracle import bindings as ob
     from difacto_amd import sharded
     world = len(batches)
@@ -88,6 +89,8 @@ def emulate(oracle, batches, V_dim, hyper, splits):
             loss[r] += oracle.loss_evaluate(b["label"], p)
             grads[r] = oracle.fm_calcgrad(V_dim, loc["offset"], loc["index"], b["value"], b["label"], vals, p, wp, vp)
         owner = {r: sharded.owner_of(locs[r]["feaids"], splits) for r in act}
+        if rec is not None:
+            rec.append(dict(locs=locs, pulled=pulled, grads=grads))
         for r in act:   # every owner's own keys first
             subset_push(store, ob.GRADIENT, locs[r]["feaids"], grads[r], pulled[r][1], owner[r] == r)
         for r in act:   # then the keys other ranks own, source rank after source rank
@@ -116,7 +119,7 @@ def merge_ragged(mask_a, ra, rb):
     return vals, lens
 
 
-def emulate_overlap(oracle, batches, V_dim, hyper, splits):
+def emulate_overlap(oracle, batches, V_dim, hyper, splits, rec=None):
     """ONE store receiving the requests of the OVERLAPPED exchange (dfh_shard_set_exchange(s, 1), include/difacto_hip.h)
     in its documented order.  Per step t:  L(t): every rank count-pushes and reads the keys it owns itself (zero
     staleness);  [first step only: the other owners' keys are count-pushed and pulled now];  F(t);  the own keys'
@@ -161,6 +164,10 @@ def emulate_overlap(oracle, batches, V_dim, hyper, splits):
             loss[r] += oracle.loss_evaluate(b["label"], p)
             grads[r] = oracle.fm_calcgrad(V_dim, l["offset"], l["index"], b["value"], b["label"], vals, p, wp, vp)
             lens_of[r] = lens
+            if rec is not None:
+                if len(rec) <= i:
+                    rec.append(dict(locs=locs[i], pulled={}, grads=grads))
+                rec[i]["pulled"][r] = (vals, lens)
         for r in act:   # the own keys' update (fused, in place)
             subset_push(store, ob.GRADIENT, locs[i][r]["feaids"], grads[r], lens_of[r], mine[i][r])
         nxt = remote_pull(i + 1) if i + 1 < steps else None   # R(t+1) ahead of P(t)
