@@ -107,8 +107,9 @@ def parse_args():
                          "loop-back transport (peers' keys / counts / gradient rows synthesised from W - 1 other streams of the "
                          "generator restricted to the rank's key range; wires modelled) — every kernel of dfh_shard_step at N = W "
                          "at its real size on a quiet chip")
-    ap.add_argument("--emulate-rank", default="all", help="which rank(s) to emulate: an index, or `all` (one after the other; the "
-                                                          "projection takes the slowest, like a job's barrier would)")
+    ap.add_argument("--emulate-rank", default="auto",
+                    help="which rank(s) to emulate: an index, `auto` (the owner that receives the most keys per step: the job's "
+                         "slowest rank) or `all` (one after the other; the projection takes the slowest, like a job's barrier would)")
     ap.add_argument("--emulate-wire", choices=["off", "peak", "achievable"], default="achievable",
                     help="which wire model the projected `value` is quoted under (all three are in the line)")
     ap.add_argument("--force-sharded", action="store_true",

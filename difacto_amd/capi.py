@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdifacto_hip.so")
+# DIFACTO_HIP_LIB: another build of the same library (tools/var_<name>.so of a same-box A/B); it must exist
+LIB_PATH = os.environ.get("DIFACTO_HIP_LIB") or os.path.join(_HERE, "libdifacto_hip.so")
 
 FEA_COUNT, WEIGHT, GRADIENT = 1, 2, 3
 INIT_REFRAND, INIT_HASH = 0, 1
@@ -31,7 +32,7 @@ SYMBOLS = [
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
     "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
-    "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
+    "dfh_shard_multi_words", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
 ]
 XCHG_COUNTS, XCHG_KEYS, XCHG_CNT, XCHG_ROWS, XCHG_GRADS, XCHG_OTHER = range(6)
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
@@ -162,6 +163,8 @@ def lib():
     L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dfh_shard_release.argtypes = [vp, vp, sz, i32]
+    L.dfh_shard_multi_words.restype = sz
+    L.dfh_shard_multi_words.argtypes = [sz, i32]
     L.dfh_ctx_set_timing.argtypes = [vp, i32]
     L.dfh_ctx_set_timing_mask.argtypes = [vp, C.c_uint32]
     L.dfh_ctx_get_timing.argtypes = [vp, i32, vp, vp]
@@ -644,6 +647,11 @@ class DeviceBuffer:
 
 def row_stride(V_dim):
     return int(lib().dfh_row_stride(V_dim))
+
+
+def multi_words(n, nsrc):
+    """32-bit words of the row-word buffer dfh_shard_resolve_multi fills for n entries of nsrc sources"""
+    return int(lib().dfh_shard_multi_words(n, nsrc))
 
 
 class Comm:

@@ -1229,7 +1229,7 @@ int make_segoff(const size_t* seg, int nsrc, int mask_slot, SegOff* out) {
   out->slot = mask_slot;
   DFH_ARG(seg[0] == 0, "seg[0] must be 0");
   for (int s = 0; s <= nsrc; ++s) {
-    DFH_ARG(seg[s] < 0xFFFFFFF0ULL && (s == 0 || seg[s] >= seg[s - 1]), "seg must be ascending 32-bit offsets");
+    DFH_ARG(seg[s] < (1ULL << 27) - 1 && (s == 0 || seg[s] >= seg[s - 1]), "seg must be ascending offsets below 2^27");
     out->off[s] = (uint32_t)seg[s];
   }
   out->nsrc = nsrc;
@@ -1292,7 +1292,10 @@ int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint6
   const size_t stride = dfh_row_stride(t->v.k);
   rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
-    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);
+#ifndef DFH_PGM_BLOCKS_PER_CU
+#define DFH_PGM_BLOCKS_PER_CU 16
+#endif
+    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * DFH_PGM_BLOCKS_PER_CU);
     hipLaunchKernelGGL((k_push_grad_multi<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g,
                        d_grads, stride);
   });
@@ -1300,6 +1303,8 @@ int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint6
   DFH_HIP(hipGetLastError());
   return DFH_OK;
 }
+
+size_t dfh_shard_multi_words(size_t n, int nsrc) { return multi_words(n, nsrc < 1 ? 1 : nsrc); }
 
 int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_slot) {
   DFH_ARG(t && (n == 0 || d_rowid), "dfh_shard_release: NULL argument");

@@ -1516,35 +1516,49 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
 // ---------------------------------------------------------------------------
 // Owner side, one launch for ALL source ranks of a step.  The received keys are the
 // concatenation of nsrc ascending lists (SegOff).  k_resolve_multi resolves every entry to
-// its row and LINKS the entries that carry the same key: the row's list head (RowHdr::pad[slot])
-// is exchanged for entry + 1 and the previous head becomes the entry's link.  The entry that finds
-// the head empty — the first of its key to arrive — is the key's WORKER (bit 31 of its row word):
-// in the Push kernels it walks the list (at most nsrc - 1 dependent loads from an L2-resident
-// array; round 4 searched every later source's list by bisection, 14 dependent loads per source),
-// orders the entries by source — sources are concatenated in ascending order, so by entry index —
-// and applies their values one after the other in source order — exactly what per-source launches
-// would do — storing the row once.  Every other entry skips on its row word alone (no header
-// read).  The last Push of a step (or k_release_rows) clears the list head.
-// rowid holds 2 n words: [0, n) the row words, [n, 2 n) the links.
+// its row and elects ONE entry per key, the first to arrive, as the key's WORKER: it claims the
+// row's step word (RowHdr::pad[slot], 0 outside a step) with a compare-and-swap, leaving
+// (entry + 1) << 5 there; every later entry of the key bumps the word's low 5 bits (one
+// atomic add: the old value names the worker and the entry's place k) and writes its own index
+// into the worker's extras, extra[worker * XS + k].  In the Push kernels the worker — bit 31 of
+// its row word — has the number of the key's other entries with the header it reads anyway and
+// their indices in one 16 / 32 B read; it orders them by source (sources are concatenated in
+// ascending order: by entry index) and applies their values one after the other in source
+// order — exactly what per-source launches would do — storing the row once.  Every other entry
+// skips on its row word alone.  (Round 4 searched each later source's list by bisection, 14
+// dependent loads per source; a linked list through the entries, tried first in round 5, still
+// cost one dependent — and, written by another launch, cold — load per entry: 57 us for the
+// gradient push at C4 size against 25 us for the same rows without the multi-source keys.)
+// The last Push of a step (or k_release_rows) clears the step word.
+// rowid holds multi_words(n, nsrc) words: [0, n) the row words, from multi_extra_base(n) on
+// XS = multi_xs(nsrc) extras per entry.
 // ---------------------------------------------------------------------------
 struct SegOff {
   uint32_t off[33];  // entries of source s are [off[s], off[s+1])
   int nsrc;
-  int slot;          // which of the two per-row list heads (RowHdr::pad[0..1]) this step uses: two steps
+  int slot;          // which of the two per-row step words (RowHdr::pad[0..1]) this step uses: two steps
                      // may be in flight on an owner (one resolved and pulled, the other awaiting its gradients)
 };
 constexpr uint32_t ROW_ID_MASK = 0x1FFFFFFFu;  // a table holds fewer than 2^29 rows
 constexpr uint32_t ROW_WORKER = 0x80000000u;
-constexpr int MULTI_FAST = 8;                  // entries per key collected in registers (one node: 7 peers)
+constexpr int MULTI_FAST = 8;                  // entries per key ordered in registers (one node: 7 peers)
+__host__ __device__ __forceinline__ uint32_t multi_xs(int nsrc) { return (uint32_t)((nsrc - 1 + 3) / 4 * 4 > 0 ? (nsrc - 1 + 3) / 4 * 4 : 4); }
+__host__ __device__ __forceinline__ size_t multi_extra_base(size_t n) { return (n + 3) & ~(size_t)3; }
+__host__ __device__ __forceinline__ size_t multi_words(size_t n, int nsrc) { return multi_extra_base(n) + n * multi_xs(nsrc); }
 
 __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, SegOff g, uint32_t* __restrict__ rowid) {
   const uint32_t n = g.off[g.nsrc];
-  uint32_t* __restrict__ link = rowid + n;
+  const uint32_t XS = multi_xs(g.nsrc);
+  uint32_t* __restrict__ extra = rowid + multi_extra_base(n);
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const uint32_t r = find_or_insert(t, keys[e]);
-    const uint32_t prev = atomicExch(&t.hdr[r].pad[g.slot], e + 1);
-    link[e] = prev;
-    rowid[e] = r | (prev == 0 ? ROW_WORKER : 0u);
+    uint32_t* word = &t.hdr[r].pad[g.slot];
+    uint32_t old = atomicCAS(word, 0u, (e + 1) << 5);
+    if (old != 0u) {  // the key has its worker: take a place among its extras
+      old = atomicAdd(word, 1u);
+      extra[(size_t)((old >> 5) - 1u) * XS + (old & 31u)] = e;
+    }
+    rowid[e] = r | (old == 0u ? ROW_WORKER : 0u);
   }
 }
 
@@ -1555,45 +1569,6 @@ __global__ void k_release_rows(TableView t, const uint32_t* __restrict__ rowid, 
   }
 }
 
-// the entries of one key, ascending (= source order), from the list that starts at `head` (entry + 1; 0 ends it).
-// Up to MULTI_FAST entries are collected in registers and ordered by a small network; *more = 1 if the list is longer
-// (a job of more than 8 sources: the caller then walks the list once per entry, see multi_next_above).
-__device__ __forceinline__ int multi_collect(const uint32_t* __restrict__ link, uint32_t head, uint32_t (&ent)[MULTI_FAST], bool* more) {
-  int m = 0;
-  uint32_t p = head;
-#pragma unroll
-  for (int i = 0; i < MULTI_FAST; ++i) {
-    ent[i] = 0xFFFFFFFFu;
-    if (p) {
-      ent[i] = p - 1;
-      p = link[p - 1];
-      ++m;
-    }
-  }
-  *more = p != 0;
-  // odd-even transposition sort of 8 registers (unused slots hold ~0 and stay last)
-#pragma unroll
-  for (int pass = 0; pass < MULTI_FAST; ++pass) {
-#pragma unroll
-    for (int i = pass & 1; i + 1 < MULTI_FAST; i += 2) {
-      const uint32_t lo = min(ent[i], ent[i + 1]), hi = max(ent[i], ent[i + 1]);
-      ent[i] = lo;
-      ent[i + 1] = hi;
-    }
-  }
-  return m;
-}
-
-// the smallest entry of the list that is greater than `after` (or ~0): the slow path for more than MULTI_FAST sources
-__device__ __forceinline__ uint32_t multi_next_above(const uint32_t* __restrict__ link, uint32_t head, uint32_t after, bool first) {
-  uint32_t best = 0xFFFFFFFFu;
-  for (uint32_t p = head; p; p = link[p - 1]) {
-    const uint32_t e = p - 1;
-    if ((first || e > after) && e < best) best = e;
-  }
-  return best;
-}
-
 // Push(kFeaCount) of all sources: one thread per entry, the key's worker adds every source's count
 // (small integers: the sum is exact in any order) and then takes the InitV decision once —
 // w does not change during count pushes and fea_cnt only grows, so the outcome equals the
@@ -1601,14 +1576,16 @@ __device__ __forceinline__ uint32_t multi_next_above(const uint32_t* __restrict_
 __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ rowid, const uint64_t* __restrict__ keys,
                                    SegOff g, const float* __restrict__ cnt) {
   const uint32_t n = g.off[g.nsrc];
-  const uint32_t* __restrict__ link = rowid + n;
+  const uint32_t XS = multi_xs(g.nsrc);
+  const uint32_t* __restrict__ extra = rowid + multi_extra_base(n);
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const uint32_t rw = rowid[e];
     if (!(rw & ROW_WORKER)) continue;  // another entry of this key works for it
     const uint32_t r = rw & ROW_ID_MASK;
     RowHdr& h = t.hdr[r];
-    float fc = h.fea_cnt;
-    for (uint32_t p = h.pad[g.slot]; p; p = link[p - 1]) fc += cnt[p - 1];
+    float fc = h.fea_cnt + cnt[e];
+    const uint32_t m = h.pad[g.slot] & 31u;
+    for (uint32_t i = 0; i < m; ++i) fc += cnt[extra[(size_t)e * XS + i]];
     h.fea_cnt = fc;
     if (t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold) {
       init_v_hash_row(t, r, keys[e]);
@@ -1619,11 +1596,27 @@ __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ row
 
 // Push(kGradient) of all sources: L lanes per entry; the key's worker applies the sources' gradient rows
 // one after the other (FTRL on w with lazy InitV, AdaGrad on V iff the rows were pulled with V) on
-// registers and stores the row once; clears the row's list head.  The header, the worker's own gradient
-// row and the V / accumulator slices are requested together, before anything is known about the key
-// (80 % of the keys come from one source: their chain is row word -> {header, row, gradient} -> store).
+// registers and stores the row once; clears the row's step word.  The header, the worker's own gradient
+// row, the V / accumulator slices and the extras are requested together, before anything is known about
+// the key: a key of one source (80 %) is row word -> {header, row, gradient} -> store, a key of several
+// sources one round trip more (the other sources' gradient rows, four at a time).
+#ifndef DFH_PGM_NT
+#define DFH_PGM_NT 0
+#endif
+#ifndef DFH_PGM_BATCH
+#define DFH_PGM_BATCH 4
+#endif
+#ifndef DFH_PGM_WAVES
+#define DFH_PGM_WAVES 0
+#endif
+#if DFH_PGM_WAVES
+#define DFH_PGM_BOUNDS __launch_bounds__(256, DFH_PGM_WAVES)
+#else
+#define DFH_PGM_BOUNDS __launch_bounds__(256)
+#endif
+constexpr int PGM_BATCH = DFH_PGM_BATCH;
 template <int L>
-__global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
+__global__ void DFH_PGM_BOUNDS k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
                                                          const uint64_t* __restrict__ keys, SegOff g,
                                                          const float* __restrict__ grads, size_t stride) {
   constexpr int GPW = 64 / L;
@@ -1632,7 +1625,8 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   const uint32_t n = g.off[g.nsrc];
-  const uint32_t* __restrict__ link = rowid + n;
+  const uint32_t XS = multi_xs(g.nsrc);
+  const uint32_t* __restrict__ extra = rowid + multi_extra_base(n);
   const int d = sub * 4;
   const bool d_ok = d < t.kp;  // this lane's V slice (4 * L >= kp by dispatch: one float4 per lane covers the row)
   for (uint32_t e = group; e < n; e += ngroups) {
@@ -1645,14 +1639,17 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
     const int goff = d_ok ? 4 + d : 0;
     const float* vp = d_ok ? va + d : reinterpret_cast<const float*>(hp);
     const float* ap = d_ok ? va + t.kp + d : reinterpret_cast<const float*>(hp);
-    // one round trip: header (both halves), own gradient row, V and accumulator slices
+    // one round trip: header (both halves), own gradient row, V and accumulator slices, the extras
     const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
     const float fea_cnt = hp->fea_cnt;
-    const uint32_t head = hp->pad[g.slot];
+    const uint32_t word = hp->pad[g.slot];
     const float* g_own = grads + (size_t)e * stride;
     const float4 go0 = ld4(g_own);
     const float4 go_v = ld4(g_own + goff);
-    float4 v = ld4(vp), acc = ld4(ap);
+    float4 v = DFH_PGM_NT ? ld4_nt(vp) : ld4(vp), acc = DFH_PGM_NT ? ld4_nt(ap) : ld4(ap);
+    const uint32_t* xp = extra + (size_t)e * XS;
+    const uint4 x0 = *reinterpret_cast<const uint4*>(xp);
+    const uint4 x1 = *reinterpret_cast<const uint4*>(xp + (XS >= 8 ? 4 : 0));
     float w = h0.x, sqrt_g = h0.z, z = h0.w;
     uint32_t has_v = __float_as_uint(h0.y);
     const bool had_v = go0.y != 0.0f;  // every source pulled the same model version: one answer
@@ -1662,7 +1659,6 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
       continue;
     }
     if (!(had_v && d_ok)) v = acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint64_t key = keys[e];
     auto apply = [&](float gw, const float4& gv) {
       const float w_old = w;
       w = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
@@ -1670,7 +1666,7 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
       // gradient of this step touches the fresh values
       if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
         // every lane of the group reaches this with the same w: each writes its own 16 B of V and of the accumulators
-        if (d_ok) init_v_hash_slice(t, r, key, d);
+        if (d_ok) init_v_hash_slice(t, r, keys[e], d);
         has_v = 1;
       }
       if (had_v && d_ok) {
@@ -1680,32 +1676,55 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
         adagrad_update_v(gv.w, v.w, acc.w, t.p);
       }
     };
-    if (head == e + 1) {  // the usual case: one source carries the key (the worker arrived first AND last)
+    const uint32_t m = word & 31u;  // entries of this key besides the worker's own
+    if (m == 0) {                   // the usual case: one source carries the key
       apply(go0.x, go_v);
-    } else {
-      uint32_t ent[MULTI_FAST];
-      bool more;
-      const int m = multi_collect(link, head, ent, &more);
-      if (!more) {
-        // all gradient rows requested before the first is applied (unconditional loads on clamped entries)
-        float gws[MULTI_FAST];
-        float4 gvs[MULTI_FAST];
+    } else if (m < MULTI_FAST) {
+      // the worker's and the other sources' entries in ascending order: an odd-even transposition network on 8 registers
+      uint32_t ent[MULTI_FAST] = {e, x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z};
 #pragma unroll
-        for (int i = 0; i < MULTI_FAST; ++i) {
-          const float* gp = grads + (size_t)(i < m ? ent[i] : e) * stride;
+      for (int i = 1; i < MULTI_FAST; ++i)
+        if ((uint32_t)i > m) ent[i] = 0xFFFFFFFFu;
+#pragma unroll
+      for (int pass = 0; pass < MULTI_FAST; ++pass) {
+#pragma unroll
+        for (int i = pass & 1; i + 1 < MULTI_FAST; i += 2) {
+          const uint32_t lo = min(ent[i], ent[i + 1]), hi = max(ent[i], ent[i + 1]);
+          ent[i] = lo;
+          ent[i + 1] = hi;
+        }
+      }
+      // PGM_BATCH gradient rows per round trip (unconditional loads on clamped entries), applied in order
+#pragma unroll
+      for (int b0 = 0; b0 < MULTI_FAST; b0 += PGM_BATCH) {
+        if ((uint32_t)b0 > m) break;  // uniform per lane group
+        float gws[PGM_BATCH];
+        float4 gvs[PGM_BATCH];
+#pragma unroll
+        for (int i = 0; i < PGM_BATCH; ++i) {
+          const float* gp = grads + (size_t)((uint32_t)(b0 + i) <= m ? ent[b0 + i] : e) * stride;
           gws[i] = ld4(gp).x;
           gvs[i] = ld4(gp + goff);
         }
 #pragma unroll
-        for (int i = 0; i < MULTI_FAST; ++i)
-          if (i < m) apply(gws[i], gvs[i]);
-      } else {
-        uint32_t cur = multi_next_above(link, head, 0u, true);
-        while (cur != 0xFFFFFFFFu) {
-          const float* gp = grads + (size_t)cur * stride;
-          apply(ld4(gp).x, ld4(gp + goff));
-          cur = multi_next_above(link, head, cur, false);
+        for (int i = 0; i < PGM_BATCH; ++i)
+          if ((uint32_t)(b0 + i) <= m) apply(gws[i], gvs[i]);
+      }
+    } else {
+      // more than 8 sources carry the key (a job beyond one node): the next entry in ascending order is searched among
+      // the worker's own and its extras for every application
+      uint32_t cur = 0xFFFFFFFFu;
+      bool first = true;
+      for (uint32_t done = 0; done <= m; ++done) {
+        uint32_t best = (first || e > cur) ? e : 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < m; ++i) {
+          const uint32_t x = xp[i];
+          if ((first || x > cur) && x < best) best = x;
         }
+        const float* gp = grads + (size_t)best * stride;
+        apply(ld4(gp).x, ld4(gp + goff));
+        cur = best;
+        first = false;
       }
     }
     if (sub == 0) {
@@ -1717,8 +1736,13 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
       if (d + 1 >= t.k) { v.y = 0.f; acc.y = 0.f; }
       if (d + 2 >= t.k) { v.z = 0.f; acc.z = 0.f; }
       if (d + 3 >= t.k) { v.w = 0.f; acc.w = 0.f; }
-      st4(va + d, v);
-      st4(va + t.kp + d, acc);
+      if (DFH_PGM_NT) {
+        st4_nt(va + d, v);
+        st4_nt(va + t.kp + d, acc);
+      } else {
+        st4(va + d, v);
+        st4(va + t.kp + d, acc);
+      }
     }
   }
 }

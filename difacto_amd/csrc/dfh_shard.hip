@@ -862,7 +862,7 @@ int flight_bufs(dfh_shard* s, const dfh_shard::Flight& f, size_t stride) {
   }
   if (f.nrecv > s->r_cap[q]) {
     const size_t cap = f.nrecv + f.nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) || (rc = grow(&s->r_rowid[q], 2 * cap, st)) ||
+    if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) || (rc = grow(&s->r_rowid[q], multi_words(cap, s->c->world), st)) ||
         (rc = grow(&s->r_rows[q], cap * stride, st)))
       return rc;
     s->r_cap[q] = cap;
@@ -1106,7 +1106,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
   // ---- buffers
   if (nrecv > s->r_cap[0]) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], 2 * cap, st)) ||
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], multi_words(cap, s->c->world), st)) ||
         (rc = grow(&s->r_rows[0], cap * stride, st)))
       return rc;
     s->r_cap[0] = cap;
@@ -1516,7 +1516,7 @@ int host_call_bufs(dfh_shard* s, size_t nrecv, size_t n, size_t stride) {
   int rc;
   if (nrecv > s->r_cap[0]) {
     const size_t cap = nrecv + nrecv / 2 + 1024;
-    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], 2 * cap, st)) ||
+    if ((rc = grow(&s->r_keys[0], cap, st)) || (rc = grow(&s->r_cnt[0], cap, st)) || (rc = grow(&s->r_rowid[0], multi_words(cap, s->c->world), st)) ||
         (rc = grow(&s->r_rows[0], cap * stride, st)))
       return rc;
     s->r_cap[0] = cap;

@@ -81,19 +81,20 @@ def bench_splits(args, world, gen_factory, S):
         return uniform_splits(world), mode
     alpha = {"data": 1.0, "ids": 0.0, "blend": float(getattr(args, "blend_alpha", 0.5))}[mode]
     g = gen_factory()
-    ids = np.zeros(0, np.uint64)
-    if alpha < 1:
-        ids = np.concatenate([synth.reverse_bytes_np(g.ids_of(q, np.arange(0, int(g.vocab[q]), 61, dtype=np.uint64))) for q in range(S)])
-    data = np.zeros(0, np.uint64)
-    if alpha > 0:
-        parts = []
-        for p in range(world):
-            gp = gen_factory()
-            gp.rng = np.random.default_rng(5000 + p)   # not the timed streams: ranges come from a sample, as in production
-            for _ in range(2):
-                parts.append(np.unique(synth.reverse_bytes_np(gp.batch(args.rows)["index"])))
-        data = np.concatenate(parts)
-    return blended_splits(ids, data, world, alpha), mode
+    step = 61 if int(g.vocab.sum()) <= 100_000_000 else 997
+    ids = np.concatenate([synth.reverse_bytes_np(g.ids_of(q, np.arange(0, int(g.vocab[q]), step, dtype=np.uint64))) for q in range(S)])
+    parts = []
+    for p in range(world):
+        gp = gen_factory()
+        gp.rng = np.random.default_rng(5000 + p)   # not the timed streams: ranges come from a sample, as in production
+        for _ in range(2):
+            parts.append(np.unique(synth.reverse_bytes_np(gp.batch(args.rows)["index"])))
+    data = np.concatenate(parts)
+    splits = blended_splits(ids, data, world, alpha)
+    # what the ranges mean for every owner: its share of the model's rows and of the keys that arrive per step
+    args.range_shares = dict(rows=(np.bincount(owner_of(ids, splits), minlength=world) / max(len(ids), 1)).round(4).tolist(),
+                             traffic=(np.bincount(owner_of(data, splits), minlength=world) / max(len(data), 1)).round(4).tolist())
+    return splits, mode
 
 
 def owner_of(keys, splits):
@@ -346,6 +347,46 @@ XGMI_LINK_DIR_GBPS = XGMI_LINK_GBPS / 2   # one direction of one link
 WIRE_MODELS = (("off", 0.0, 0.0), ("peak", XGMI_LINK_DIR_GBPS, 10.0), ("achievable", 0.6 * XGMI_LINK_DIR_GBPS, 20.0))
 
 
+def _device_slot_keys(gen, g, r0, r1, device):
+    """reversed keys of ranks [r0, r1) of slot g, generated ON THE DEVICE with torch int64 arithmetic (wrap-around like
+    synth.splitmix64 / reverse_bytes_np; checked against them in tests/test_bench_contract.py): a 1e9-id space is too much
+    for numpy on the host.  -> int64 tensor holding the u64 bit patterns"""
+    def c(v):
+        return torch.tensor(v - (1 << 64) if v >= (1 << 63) else v, dtype=torch.int64, device=device)
+
+    def lsr(v, n):
+        return (v >> n) & ((1 << (64 - n)) - 1)
+    ranks = torch.arange(r0, r1, dtype=torch.int64, device=device)
+    x = c(int(gen.seed)) ^ c(g << 40) ^ ranks
+    x = x + c(0x9E3779B97F4A7C15)
+    z = (x ^ lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * c(0x94D049BB133111EB)
+    h = z ^ lsr(z, 31)
+    x = (h << 12) | g
+    x = (x << 32) | lsr(x, 32)
+    x = ((x & c(0x0000FFFF0000FFFF)) << 16) | lsr(x & c(0xFFFF0000FFFF0000), 16)
+    x = ((x & c(0x00FF00FF00FF00FF)) << 8) | lsr(x & c(0xFF00FF00FF00FF00), 8)
+    x = ((x & c(0x0F0F0F0F0F0F0F0F)) << 4) | lsr(x & c(0xF0F0F0F0F0F0F0F0), 4)
+    return x
+
+
+def _device_owned_keys(gen, lo, hi, device, chunk=1 << 25):
+    """yields int64 tensors (u64 bit patterns) of the reversed keys of the whole id space that fall into [lo, hi)"""
+    sign = 1 << 63
+    lo_s = torch.tensor((lo ^ sign) - (1 << 64) if (lo ^ sign) >= sign else (lo ^ sign), dtype=torch.int64, device=device)
+    hi1 = (hi - 1) ^ sign
+    hi_s = torch.tensor(hi1 - (1 << 64) if hi1 >= sign else hi1, dtype=torch.int64, device=device)
+    flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=device)
+    for g in range(len(gen.vocab)):
+        v = int(gen.vocab[g])
+        for r0 in range(0, v, chunk):
+            x = _device_slot_keys(gen, g, r0, min(v, r0 + chunk), device)
+            xs = x ^ flip    # unsigned order as signed order
+            sel = x[(xs >= lo_s) & (xs <= hi_s)]
+            if sel.numel():
+                yield sel
+
+
 def _localized_keys(hb):
     """(ascending unique reversed keys, occurrence counts f32) of a host minibatch: Localizer::Compact's feaids / feacnt
     (src/data/localizer.cc:11-50), in numpy — only to SYNTHESISE what peers would send; the emulated rank's own
@@ -371,7 +412,6 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
     build_hip()
     W = args.emulate_world
     B, k, S = args.rows, args.vdim, synth.NUM_SLOTS
-    ranks = list(range(W)) if args.emulate_rank == "all" else [int(args.emulate_rank)]
     hyper = dict(hyper)
     hyper["lr"] = hyper["lr"] / W
     hyper["V_lr"] = hyper["V_lr"] / W
@@ -380,6 +420,14 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
     t0 = time.time()
     all_keys = [synth.reverse_bytes_np(gen.all_ids(g)) for g in range(S)] if args.ids <= 40_000_000 else None
     splits, ranges_mode = bench_splits(args, W, lambda: synth.CriteoSynth(total_ids=args.ids, seed=42), S)
+    shares = getattr(args, "range_shares", None)
+    if args.emulate_rank == "all":
+        ranks = list(range(W))
+    elif args.emulate_rank == "auto":   # the owner that receives the most keys per step (ties: the most rows): the job's slowest rank
+        tr, rw = shares["traffic"], shares["rows"]
+        ranks = [max(range(W), key=lambda q: (round(tr[q], 3), rw[q]))]
+    else:
+        ranks = [int(args.emulate_rank)]
     # the W workers' streams (one generator object each: every worker draws its own data part, sgd_learner.cc:78-89).  Only the
     # emulated ranks' minibatches are kept as raw CSR; of the others only the localized key lists are needed.
     def stream(p):
@@ -418,7 +466,7 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
         "config": {"workload": "C4/C5 projection: Criteo-shaped synthetic, %d ids / 39 slots, V_dim=%d, model row-sharded by key range "
                                "over %d ranks, rank(s) %s emulated on 1 MI355X" % (args.ids, k, W, ranks),
                    "rows_per_step_per_gpu": B, "parallelism": "shard%d (emulated)" % W, "exchange": args.exchange, "hyper": hyper,
-                   "distinct_batches_per_rank": nd, "key_ranges": ranges_mode,
+                   "distinct_batches_per_rank": nd, "key_ranges": ranges_mode, "range_shares_per_owner": shares,
                    "transport": "loop-back (device copies of the exact message sizes; sends read once, receives copied from fed buffers)"},
         "ranks": results,
         "streams_seconds": t_streams,
@@ -438,21 +486,32 @@ def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride,
     # this rank's shard of the model, pre-filled (every id of its range present with V, like the N = 1 line)
     t0 = time.time()
     owned = 0
-    mine = []
-    for g in range(S):
-        keys = all_keys[g] if all_keys is not None else synth.reverse_bytes_np(gen.all_ids(g))
-        sel = keys[(keys >= np.uint64(lo)) & (keys <= np.uint64(hi - 1))]
-        mine.append(sel)
-        owned += len(sel)
-    table = capi.Table(ctx, int(owned * 1.05) + 8 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
-    for m in mine:
-        for o in range(0, len(m), 1 << 22):
-            part = np.ascontiguousarray(m[o:o + (1 << 22)])
-            db = capi.DeviceBuffer.from_numpy(ctx, part)
-            table.warm_start(db.ptr, len(part), w0=0.01, cnt0=100.0)
+    if all_keys is not None:
+        mine = []
+        for g in range(S):
+            keys = all_keys[g]
+            sel = keys[(keys >= np.uint64(lo)) & (keys <= np.uint64(hi - 1))]
+            mine.append(sel)
+            owned += len(sel)
+        table = capi.Table(ctx, int(owned * 1.05) + 8 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
+        for m in mine:
+            for o in range(0, len(m), 1 << 22):
+                part = np.ascontiguousarray(m[o:o + (1 << 22)])
+                db = capi.DeviceBuffer.from_numpy(ctx, part)
+                table.warm_start(db.ptr, len(part), w0=0.01, cnt0=100.0)
+                ctx.sync()
+                db.close()
+        del mine
+    else:   # an id space beyond the host's means (C5: 1e9 ids): the keys are generated on the device, twice (count, fill)
+        dev_t = torch.device("cuda", 0)
+        for sel in _device_owned_keys(gen, lo, hi, dev_t):
+            owned += int(sel.numel())
+        table = capi.Table(ctx, int(owned * 1.02) + 8 * B * S, V_dim=k, init_mode=capi.INIT_HASH, **hyper)
+        for sel in _device_owned_keys(gen, lo, hi, dev_t):
+            torch.cuda.synchronize()
+            table.warm_start(sel.data_ptr(), int(sel.numel()), w0=0.01, cnt0=100.0)
             ctx.sync()
-            db.close()
-    del mine
+        torch.cuda.empty_cache()
     t_prefill = time.time() - t0
     shard = capi.Shard(table, comm, splits)
     if args.exchange == "overlap":

@@ -55,6 +55,9 @@ def slot_vocab_sizes(total_ids=33_000_000):
     return v
 
 
+_CDF_CACHE = {}   # (total_ids, alpha) -> per-slot CDFs: generators of one id space share them (8 GB at 1e9 ids)
+
+
 class CriteoSynth:
     def __init__(self, total_ids=33_000_000, seed=42, alpha=ALPHA, pos_rate=0.25):
         self.vocab = slot_vocab_sizes(total_ids)
@@ -62,13 +65,15 @@ class CriteoSynth:
         self.alpha = alpha
         self.pos_rate = pos_rate
         self.rng = np.random.default_rng(seed)
-        self._cdf = [None] * NUM_SLOTS
+        self._cdf = _CDF_CACHE.setdefault((int(total_ids), float(alpha)), [None] * NUM_SLOTS)
 
     def _slot_cdf(self, g):
         if self._cdf[g] is None:
             r = np.arange(1, int(self.vocab[g]) + 1, dtype=np.float64)
-            c = np.cumsum(r ** (-self.alpha))
-            self._cdf[g] = c / c[-1]
+            np.power(r, -self.alpha, out=r)
+            np.cumsum(r, out=r)
+            r /= r[-1]
+            self._cdf[g] = r
         return self._cdf[g]
 
     def ids_of(self, g, ranks):

@@ -318,16 +318,18 @@ int dfh_shard_push_count_resolved(dfh_table* t, const uint32_t* d_rowid, const u
 int dfh_shard_push_grad_resolved(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, size_t n, const float* d_grads);
 /* The same for ALL source ranks of a step in one launch per operation.  d_keys is the
  * concatenation of nsrc ascending key lists, source s holding entries [seg[s], seg[s+1]) (seg:
- * HOST array of nsrc+1 offsets, nsrc <= 32; n = seg[nsrc] entries).  d_rowid holds 2 n words:
- * [0, n) the entries' row words (the row id in the low 29 bits — what dfh_shard_pull_resolved
- * reads), [n, 2 n) links between the entries that carry the same key (written by resolve_multi,
- * read by the Push calls).  In the two Push calls ONE entry per key (the first to be resolved)
- * applies every source's value in ascending source order (the result of nsrc per-source calls)
- * and stores the row once.  push_grad_multi ends the step for these rows; a step without it
- * (validation) ends with dfh_shard_release.  mask_slot (0 or 1) names which of two per-row list
- * heads the step uses: an owner may hold two steps at once — one resolved and pulled, the other
- * still awaiting its gradients (the reference keeps two minibatches in flight,
- * sgd_learner.cc:219-223) — and they must use different slots. */
+ * HOST array of nsrc+1 offsets, nsrc <= 32; n = seg[nsrc] < 2^27 entries).  d_rowid holds
+ * dfh_shard_multi_words(n, nsrc) words: [0, n) the entries' row words (the row id in the low 29
+ * bits — what dfh_shard_pull_resolved reads), behind them, per entry, the indices of the other
+ * entries that carry the same key (written by resolve_multi for ONE entry per key, the first to
+ * be resolved; read by the Push calls).  In the two Push calls that entry applies every
+ * source's value in ascending source order (the result of nsrc per-source calls) and stores the
+ * row once.  push_grad_multi ends the step for these rows; a step without it (validation) ends
+ * with dfh_shard_release.  mask_slot (0 or 1) names which of two per-row step words the step
+ * uses: an owner may hold two steps at once — one resolved and pulled, the other still awaiting
+ * its gradients (the reference keeps two minibatches in flight, sgd_learner.cc:219-223) — and
+ * they must use different slots. */
+size_t dfh_shard_multi_words(size_t n, int nsrc);
 int dfh_shard_resolve_multi(dfh_table* t, const uint64_t* d_keys, const size_t* seg, int nsrc, int mask_slot,
                             uint32_t* d_rowid);
 int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,

@@ -116,7 +116,10 @@ class HipBackend:
     # ---- owner side: the keys received in a step (concatenated ascending lists, source s in
     # [seg[s], seg[s+1])) are resolved to rows once; every operation is one launch for all sources
     def owner_resolve(self, keys, seg, mslot=0):
-        rowid = torch.empty(2 * keys.numel(), dtype=torch.int32, device=self.device)   # row words + links
+        if not hasattr(self, "_n_entries"):
+            self._n_entries = {}
+        self._n_entries[mslot] = keys.numel()
+        rowid = torch.empty(max(self.capi.multi_words(keys.numel(), len(seg) - 1), 1), dtype=torch.int32, device=self.device)   # row words + extras
         if keys.numel():
             self.table.shard_resolve_multi(keys, seg, rowid, mslot)
         return rowid
@@ -138,7 +141,7 @@ class HipBackend:
     def owner_release(self, rowid, mslot=0):
         """ends a step that pushes no gradients (validation)"""
         if rowid.numel():
-            self.table.shard_release(rowid, rowid.numel() // 2, mslot)
+            self.table.shard_release(rowid, self._n_entries[mslot], mslot)
 
     def sync(self):
         self.ctx.sync()

@@ -62,3 +62,37 @@ def test_committed_sharded_line_has_the_same_shape():
     assert x["bound"] == "xgmi" and abs(x["peak"] - 7 * 153.6) < 1e-9
     assert "rccl" in d["config"]["transport_bound"] and d["config"]["auc_every_minibatch"] is True
     assert set(d["stage_ms_per_step"]) == {"counts", "L", "K", "R", "RW", "F", "G", "P"}
+
+
+def test_device_id_generation_matches_the_host_generator():
+    """bench.py --emulate-world on a 1e9-id space (C5) fills the emulated rank's shard from ids generated with torch int64
+    arithmetic on the device; the same code on the CPU must give the host generator's reversed keys, range filter included"""
+    import numpy as np
+    import torch
+    from difacto_amd import sharded, synth
+    g = synth.CriteoSynth(total_ids=300_000, seed=42)
+    allk = np.concatenate([synth.reverse_bytes_np(g.all_ids(q)) for q in range(synth.NUM_SLOTS)])
+    for lo, hi in ((0, 1 << 64), (3 << 60, 9 << 60), (9 << 60, 1 << 64)):
+        want = np.sort(allk[(allk >= np.uint64(lo)) & (allk <= np.uint64(hi - 1))])
+        got = np.sort(np.concatenate([t.numpy().view(np.uint64) for t in
+                                      sharded._device_owned_keys(g, lo, hi, torch.device("cpu"), chunk=1 << 14)] + [np.zeros(0, np.uint64)]))
+        assert np.array_equal(want, got)
+
+
+def test_blended_key_ranges():
+    """the three kinds of key ranges of the N > 1 bench: shares of rows and of per-step traffic per owner"""
+    import numpy as np
+    from difacto_amd import sharded, synth
+
+    class A:
+        rows, blend_alpha = 2000, 0.5
+    out = {}
+    for mode in ("ids", "data", "blend"):
+        a = A()
+        a.key_ranges = mode
+        splits, m = sharded.bench_splits(a, 8, lambda: synth.CriteoSynth(total_ids=2_000_000, seed=42), synth.NUM_SLOTS)
+        assert m == mode and len(splits) == 7 and np.all(splits[1:] >= splits[:-1])
+        out[mode] = a.range_shares
+    assert max(out["ids"]["rows"]) < 0.14 and max(out["data"]["traffic"]) < 0.14      # each balances what it is named after
+    assert max(out["ids"]["traffic"]) > 0.18 and max(out["data"]["rows"]) > 0.18      # ... and not the other
+    assert max(out["blend"]["rows"]) < max(out["data"]["rows"]) and max(out["blend"]["traffic"]) < max(out["ids"]["traffic"])

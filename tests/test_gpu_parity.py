@@ -698,7 +698,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         train = step != 6          # the last step pushes no gradients (validation): release instead
         keys = torch.from_numpy(np.concatenate(srcs).view(np.int64)).to(dev)
         cnt = torch.from_numpy(rng.integers(1, 5, n).astype(np.float32)).to(dev)
-        rowid = torch.empty(2 * n, dtype=torch.int32, device=dev)   # row words + the links of resolve_multi
+        rowid = torch.empty(max(capi.multi_words(n, G), 1), dtype=torch.int32, device=dev)   # row words + the extras of resolve_multi
         rows_a = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         rows_b = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()  # the fixture's context runs on its own (non-blocking) stream
@@ -751,7 +751,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
     assert ta.size() == tb.size()
     if form == "multi":  # every source mask was cleared: a fresh multi step must see clean rows
         keys = torch.from_numpy(universe[:100].view(np.int64).copy()).to(dev)
-        rowid = torch.empty(200, dtype=torch.int32, device=dev)
+        rowid = torch.empty(capi.multi_words(100, 2), dtype=torch.int32, device=dev)
         rows = torch.zeros((100, stride), dtype=torch.float32, device=dev)
         zeros = torch.zeros((100, stride), dtype=torch.float32, device=dev)
         zeros[:, 1] = 0
