@@ -32,7 +32,7 @@ SYMBOLS = [
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
     "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
-    "dfh_shard_multi_words", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
+    "dfh_shard_multi_words", "dfh_shard_reserve", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
 ]
 XCHG_COUNTS, XCHG_KEYS, XCHG_CNT, XCHG_ROWS, XCHG_GRADS, XCHG_OTHER = range(6)
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
@@ -193,6 +193,7 @@ def lib():
     L.dfh_comm_selfcheck.argtypes = [vp, C.c_double]
     L.dfh_shard_balanced_splits.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfh_shard_set_exchange.argtypes = [vp, i32]
+    L.dfh_shard_reserve.argtypes = [vp, sz, sz]
     L.dfh_comm_create_loopback.argtypes = [vp, i32, i32, PP(vp)]
     L.dfh_comm_loopback_feed.argtypes = [vp, i32, vp, i32]
     L.dfh_comm_loopback_wire.argtypes = [vp, C.c_double, C.c_double]
@@ -796,6 +797,10 @@ class Shard:
     def set_exchange(self, mode):
         """"sync" (one minibatch at a time, zero staleness) or "overlap" (two in flight, staleness <= 1); between epochs"""
         _ck(lib().dfh_shard_set_exchange(self.h, {"sync": 0, "overlap": 1}[mode]))
+
+    def reserve(self, batch_keys, recv_keys):
+        """exchange buffers for these sizes now, so that no step re-allocates (after set_exchange)"""
+        _ck(lib().dfh_shard_reserve(self.h, int(batch_keys), int(recv_keys)))
 
     def set_timing(self, on):
         _ck(lib().dfh_shard_set_timing(self.h, 1 if on else 0))

@@ -1005,6 +1005,40 @@ int dfh_shard_set_exchange(dfh_shard* s, int mode) {
   return DFH_OK;
 }
 
+int dfh_shard_reserve(dfh_shard* s, size_t batch_keys, size_t recv_keys) {
+  DFH_ARG(s, "dfh_shard_reserve: NULL shard");
+  if (s->fl[0].pulled || s->fl[1].pulled || s->counts_ready) {
+    set_error("dfh_shard_reserve: a minibatch is under way (call it before the first step or between epochs)");
+    return DFH_ERR_STATE;
+  }
+  dfh_ctx* ctx = s->t->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  if (s->cs) DFH_HIP(hipStreamSynchronize(s->cs));
+  int rc = sync_all(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  const size_t stride = dfh_row_stride(s->t->v.k);
+  const int nslots = s->exchange == 1 ? 2 : 1;
+  for (int q = 0; q < nslots; ++q) {
+    if (recv_keys > s->r_cap[q]) {
+      const size_t cap = recv_keys;
+      if ((rc = grow(&s->r_keys[q], cap, st)) || (rc = grow(&s->r_cnt[q], cap, st)) ||
+          (rc = grow(&s->r_rowid[q], multi_words(cap, s->c->world), st)) || (rc = grow(&s->r_rows[q], cap * stride, st)))
+        return rc;
+      s->r_cap[q] = cap;
+    }
+    if (s->c->world > 1 && batch_keys > s->w_cap[q]) {
+      if ((rc = grow(&s->w_rows[q], batch_keys * stride, st))) return rc;
+      s->w_cap[q] = batch_keys;
+    }
+    if (s->c->world > 1 && batch_keys > s->g_cap[q]) {
+      if ((rc = grow(&s->w_grads[q], batch_keys * stride, st))) return rc;
+      s->g_cap[q] = batch_keys;
+    }
+  }
+  return DFH_OK;
+}
+
 int dfh_shard_set_timing(dfh_shard* s, int enable) {
   DFH_ARG(s, "dfh_shard_set_timing: NULL shard");
   s->timing = enable != 0;

@@ -355,6 +355,10 @@ class CriteoChunkParser : public ChunkParser {
             nnl = nl_head = 0;   // (none left: that is why we are here)
           }
           if (npos > kWin) break;   // a line of > 16 K fields: not ours
+          // ParseRow (a short row) and the skip over blank lines read the text themselves and may have left p BEYOND what
+          // was scanned: delimiters before p must never enter pos[] — they would be counted into the next row's `ntab`
+          // (a short row ending at a window boundary made the next row's d[] point before its first field)
+          if (scanned < p) scanned = p;
           const char* stop = static_cast<size_t>(end - scanned) > kWin ? scanned + kWin : end;
           cr = ScanDelims(base, scanned, stop, pos, &npos, nlq, &nnl);
           scanned = stop;

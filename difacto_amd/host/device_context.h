@@ -6,8 +6,17 @@
 #ifndef DIFACTO_HOST_DEVICE_CONTEXT_H_
 #define DIFACTO_HOST_DEVICE_CONTEXT_H_
 #include <cstdlib>
+#include "difacto/base.h"
 #include "difacto_hip.h"
 #include "dmlc/logging.h"
+
+// The device Localizer (dfh_localize) always sorts by ReverseBytes(id) and the sharded store's key ranges rely on it
+// (include/difacto/base.h:29-51).  A host built with the reference's NO_REVERSE_ID=1 (Makefile:15-17: REVERSE_FEATURE_ID=0)
+// would hand the device ids the host headers no longer reverse: refused here, at compile time, instead of training on a
+// differently ordered model (SURVEY 8a trap 11).
+#if !REVERSE_FEATURE_ID
+#error "the device path needs REVERSE_FEATURE_ID=1: build the host without NO_REVERSE_ID (the device Localizer reverses ids itself)"
+#endif
 
 namespace difacto {
 

@@ -62,6 +62,9 @@ KWArgs SGDLearner::Init(const KWArgs& kwargs) {
         for (size_t i = blk.offset[0]; i < blk.offset[blk.size]; ++i) sample.push_back(ReverseBytes(blk.index[i]));
       }
     }
+    // exchange buffers for this job's minibatches up front (batch_size x feed_ids_per_row keys): nothing is re-allocated
+    // inside a step unless the data has more ids per row than announced
+    ss->set_reserve_keys(static_cast<size_t>(param_.batch_size) * static_cast<size_t>(GetUpdater()->device_param().feed_ids_per_row));
     ss->CreateShard(sample);
   }
   if (param_.model_in.size()) LoadModel();
@@ -297,7 +300,19 @@ struct DeviceFeed {
         }
       }
     }
-    if (!rb) {   // none fits: a new one (too small ones stay spare and are freed with the feed)
+    if (!rb) {   // none fits: a new one, in place of a spare that has proved too small (such buffers — ~58 MB and
+                 // a stream each — used to stay until the feed was destroyed)
+      dfh_rowbuf* small = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!spare.empty()) {
+          small = spare.back();
+          spare.pop_back();
+          all.erase(std::remove(all.begin(), all.end(), small), all.end());
+          cap.erase(small);
+        }
+      }
+      if (small) DFH_CALL(dfh_rowbuf_destroy(small));   // waits for the gathers queued out of it, nothing else
       const size_t rows = std::max<size_t>(nrows, 1), nz = std::max<size_t>(nnz + nnz / 4, 1);
       DFH_CALL(dfh_rowbuf_create(ctx, rows, nz, &rb));
       std::lock_guard<std::mutex> lk(mu);
@@ -368,8 +383,9 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   feed.ctx = ctx;
   const bool device_feed = train && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
   BatchReader::SliceFn upload;
-  // (48 ids per row: the criteo rows of the reference's example have 39)
-  if (device_feed) feed.Start(static_cast<size_t>(param_.batch_size) * param_.shuffle, static_cast<size_t>(param_.batch_size) * param_.shuffle * 48);
+  // (feed_ids_per_row, default 48: the criteo rows of the reference's example have 39)
+  const size_t ids_per_row = static_cast<size_t>(GetUpdater()->device_param().feed_ids_per_row);
+  if (device_feed) feed.Start(static_cast<size_t>(param_.batch_size) * param_.shuffle, static_cast<size_t>(param_.batch_size) * param_.shuffle * ids_per_row);
   if (device_feed)
     upload = [&feed](const dmlc::RowBlock<feaid_t>& blk, const std::vector<BufSlice>& slices, uint64_t serial) {
       feed.Upload(blk, slices, serial);
@@ -381,9 +397,12 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   if (device_feed) batch_reader->DescribeSlices(nullptr);
   // described minibatches are ~120 KB each: a deeper queue lets the loop ride out the reader's pause at a buffer boundary
   PrefetchSource reader(batch_reader, device_feed ? kFusedBatches : 2);
+  // objects in rotation: a dozen only where a dozen steps can be queued (the device feed's bursts); validation, prediction
+  // and host-feed jobs have a prefetch depth of 2 and rotate three (six times the HBM and creation time for nothing)
+  const int nrot = device_feed ? kFusedBatches : 3;
   auto all_there = [&] {
-    for (auto* b : batch_)
-      if (!b) return false;
+    for (int q = 0; q < nrot; ++q)
+      if (!batch_[q]) return false;
     return true;
   };
   auto ensure = [&](size_t rows, size_t nnz) {
@@ -398,9 +417,9 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     }
     batch_rows_ = std::max(rows, batch_rows_);
     batch_nnz_ = std::max(nnz * 2, batch_nnz_);
-    for (auto& b : batch_) {
-      DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &b));
-      DFH_CALL(dfh_batch_set_option(b, "compute_auc", 1));  // sgd_learner.cc:153-155
+    for (int q = 0; q < nrot; ++q) {
+      DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &batch_[q]));
+      DFH_CALL(dfh_batch_set_option(batch_[q], "compute_auc", 1));  // sgd_learner.cc:153-155
     }
   };
   const bool split_prep = getenv("DIFACTO_SPLIT_PREP") != nullptr;
@@ -478,14 +497,14 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   // the batch objects while the reader parses its first chunks (sizes: this job's batch_size at 48 ids per row, or what an
   // earlier job left; a bigger minibatch re-creates them, as before)
   if (device_feed && !all_there() && !(getenv("DIFACTO_FEED_PRECREATE") && atoi(getenv("DIFACTO_FEED_PRECREATE")) == 0))
-    ensure(param_.batch_size, static_cast<size_t>(param_.batch_size) * 48);
+    ensure(param_.batch_size, static_cast<size_t>(param_.batch_size) * ids_per_row);
   bool have = reader.Next();
   if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
   int i = 0;
   if (have) prepare(0);
   if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
   while (have) {
-    const int cur = i % kFusedBatches, nxt = (i + 1) % kFusedBatches;
+    const int cur = i % nrot, nxt = (i + 1) % nrot;
     const bool have_next = reader.Next();
     if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
     bool stepped = false;

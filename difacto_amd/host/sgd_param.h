@@ -89,7 +89,11 @@ struct DeviceParam : public dmlc::Parameter<DeviceParam> {
   /*! \brief sharded store: "overlap" keeps two minibatches in flight like the reference's batch tracker
    *  (sgd_learner.cc:219-223; rows pulled from other owners are at most one minibatch stale), "sync" one (zero staleness) */
   std::string shard_exchange;
+  /*! \brief ids per row the device feed's row buffers and batch objects are first sized for (the criteo rows of the
+   *  reference's example have 39); data with more ids per row re-creates them at the size it needs */
+  int feed_ids_per_row;
   DMLC_DECLARE_PARAMETER(DeviceParam) {
+    DMLC_DECLARE_FIELD(feed_ids_per_row).set_range(1, 1 << 20).set_default(48);
     DMLC_DECLARE_FIELD(shard_ranges).set_default("balanced");
     DMLC_DECLARE_FIELD(shard_exchange).set_default("overlap");
     DMLC_DECLARE_FIELD(table_capacity).set_default(0);

@@ -157,6 +157,7 @@ class ShardedDeviceStore : public Store {
     if (balanced) DFH_CALL(dfh_shard_balanced_splits(comm_, sample.data(), sample.size(), splits.data()));
     DFH_CALL(dfh_shard_create(up->table(), comm_, balanced ? splits.data() : nullptr, &shard_));
     if (dp.shard_exchange == "overlap") DFH_CALL(dfh_shard_set_exchange(shard_, 1));
+    if (reserve_keys_) DFH_CALL(dfh_shard_reserve(shard_, reserve_keys_, 2 * reserve_keys_));  // no re-allocation inside a step
     uint64_t lo = 0, hi = 0;
     DFH_CALL(dfh_shard_owned_range(shard_, balanced ? splits.data() : nullptr, &lo, &hi));
     LOG(INFO) << "sharded store: rank " << rank_ << " owns the reversed keys [" << lo << ", " << (hi ? std::to_string(hi) : "2^64")
@@ -196,6 +197,9 @@ class ShardedDeviceStore : public Store {
   int NumServers() override { return world_; }
 
   dfh_shard* shard() { return shard_; }
+  /*! \brief unique keys of the largest minibatch to expect (batch_size x ids per row): the exchange buffers are sized for it
+   *  when the shard is created; 0: they grow when a step first meets a size */
+  void set_reserve_keys(size_t n) { reserve_keys_ = n; }
   dfh_comm* comm() { return comm_; }
 
  private:
@@ -203,6 +207,7 @@ class ShardedDeviceStore : public Store {
   int time_ = 0;
   dfh_comm* comm_ = nullptr;
   dfh_shard* shard_ = nullptr;
+  size_t reserve_keys_ = 0;
   std::unique_ptr<FileExchange> files_;
 };
 

@@ -172,6 +172,7 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
     shard = capi.Shard(table, comm, splits)
     if args.exchange == "overlap":
         shard.set_exchange("overlap")
+    shard.reserve(B * S, 2 * B * S)   # no buffer grows (stream drain + re-allocation) inside a step
     gen.rng = np.random.default_rng(1000 + rank)   # every rank draws its own stream (different data parts, sgd_learner.cc:78-89)
     nd = max(1, args.distinct)
     dev = []
@@ -516,6 +517,7 @@ def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride,
     shard = capi.Shard(table, comm, splits)
     if args.exchange == "overlap":
         shard.set_exchange("overlap")
+    shard.reserve(B * S, 2 * B * S)   # no buffer grows (stream drain + re-allocation) inside a step
     raw, own_loc = streams[r]
     # per minibatch: what the W - 1 peers send this owner (their keys inside [lo, hi), ascending per peer, peer order)
     feeds = []

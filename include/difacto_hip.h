@@ -443,6 +443,12 @@ int dfh_shard_prefetch_counts(dfh_shard* s, dfh_batch* b_next);
  * job (src/sgd/sgd_learner.cc:201-202), keep it constant from one announcement to the step.  Call between steps only
  * (no minibatch under way); COLLECTIVE in effect: every rank must use the same mode. */
 int dfh_shard_set_exchange(dfh_shard* s, int mode);
+/* Exchange buffers for minibatches of up to batch_keys unique keys and up to recv_keys keys received from the other
+ * ranks per step, allocated NOW (after dfh_shard_set_exchange: the overlapped exchange keeps two sets).  Optional: without
+ * it — and for a minibatch beyond these sizes — dfh_shard_step grows the buffers when it first meets the size, which
+ * drains the streams and re-allocates in the middle of a step (the reference's store has no counterpart: ps-lite
+ * allocates per message).  With key ranges balanced on the data, recv_keys ~ batch_keys; 2 x is generous. */
+int dfh_shard_reserve(dfh_shard* s, size_t batch_keys, size_t recv_keys);
 /* Per-stage device time of the steps since the last reset (HIP events around every stage; they cost the streams a
  * few microseconds each: for a diagnostic pass, not for the timed run).  ms[DFH_SHARD_STAGES]: counts, L (own keys'
  * lookup), K, R, RW, F (forward + backward / own update), G, P; *steps = steps covered. */

@@ -721,3 +721,39 @@ def test_criteo_fast_parser_equals_the_plain_loop(ing):
         b = _parse_criteo_mode(ing, text, True, 1)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), t_i
         assert len(a[1]) == text.count(b"\n") + (0 if text.endswith(b"\n") else 1)
+    # (iv) ADVICE r4: a short row or a run of blank lines whose end falls ON a scan-window boundary (multiples of 16 384
+    # bytes from the chunk's start, and from wherever a scan resumed), followed by a row with an empty 13th integer field:
+    # the stale delimiters before p once made the next row look regular with its fields in the wrong place (criteo_test:
+    # a wild CityHash64 length)
+    kwin = 1 << 14
+
+    empty13 = lambda train: b"\t".join(([b"1"] if train else []) + [b"%d" % (i * 5) for i in range(12)] + [b""] +
+                                         [b"%08x" % (0x1234567 * (i + 3) & 0xffffffff) for i in range(26)]) + b"\n"
+    nwin = 0
+
+    def short_cats(train, gap):
+        """a row with all integer fields and only 5 categorical ones, `gap` bytes long (one integer token stretched)"""
+        f = ([b"1"] if train else []) + [b"%d" % (i * 3) for i in range(13)] + [b"%08x" % (77 * (i + 1)) for i in range(5)]
+        fixed = len(b"\t".join(f)) + 1
+        f[4] = f[4] + b"7" * (gap - fixed)
+        return b"\t".join(f) + b"\n"
+    for train in (True, False):
+        for mult in (1, 2, 3):
+            for shape in range(3):
+                if shape == 0:    # a short row `x...x\n` whose '\n' is the last byte of the window (it swallows the next row's
+                    filler = lambda gap: b"x" * (gap - 1) + b"\n"                      # first field, as in the reference)
+                elif shape == 1:  # blank lines up to the boundary
+                    filler = lambda gap: b"\n" * gap
+                else:             # a row short of categorical fields ending on the boundary
+                    filler = lambda gap: short_cats(train, gap)
+                text = row(train) * 2
+                while len(text) + len(row(train)) <= mult * kwin - 200:
+                    text += row(train)
+                text += filler(mult * kwin - len(text))
+                assert len(text) == mult * kwin
+                text += empty13(train) + row(train) * 3 + empty13(train) + row(train)
+                a = _parse_criteo_mode(ing, text, train, 0)
+                b = _parse_criteo_mode(ing, text, train, 1)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (train, mult, shape)
+                nwin += 1
+    assert nwin == 18

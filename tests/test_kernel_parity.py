@@ -88,7 +88,7 @@ CASES = ["c2_rcv1_k8", "ragged_k0", "ragged_k4", "ragged_k5", "ragged_k64", "rag
 
 # The tolerance of every comparison here is rtol 1e-5 |ref| + the summation-noise floor of oracle/tolerance.py; the
 # backstop is the fraction of elements inside the PURE rtol 1e-5 (no floor).  PURE_MIN holds, per case and quantity, the
-# fraction measured on MI355X (profiles/r03_parity.json) minus 0.01: a kernel change that pushes more elements onto the
+# fraction measured on MI355X (profiles/r04zz_parity.json, C_SIGMA = 1; newer records: profiles/r05*_parity.json) minus 0.01: a kernel change that pushes more elements onto the
 # floor fails here even while every element is still inside the model's tolerance.  DFH_PARITY_RECORD=<file> re-records.
 PURE_MIN = {
     'fused/adversarial_k16/l1=0': {'logits': 0.971},
