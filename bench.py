@@ -153,29 +153,86 @@ def pmc_traffic(kernels, preset):
     return None, None
 
 
+def requests_profile(pipelined):
+    """(memory-side requests per step, source file) from the newest committed counter pass of the default step
+    (profiles/rNN_requests_{pipelined,serial}.json: rocprofv3 --pmc TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum, tools/requests_table.py),
+    and the request-rate ceiling of the access pattern (tools/fresh_bench.hip, the newest profiles/rNN_fresh_rows_bench.txt: the
+    best of random 256 B row gathers [2 line reads per row] and 512 B row read-modify-writes with their 16 B header [5 line
+    reads + 9 writes per row] on rows that are NOT in the memory-side cache).  Counters of committed profiles, NOT of this run."""
+    import re
+    req = src = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_requests_%s.json" % ("pipelined" if pipelined else "serial"))), reverse=True):
+        try:
+            req, src = json.load(open(path))["requests_per_step"], os.path.relpath(path, ROOT)
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    ceil = csrc = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fresh_rows_bench.txt")), reverse=True):
+        try:
+            best = 0.0
+            for line in open(path):
+                if line.startswith("nsets 1 "):
+                    break   # (the second half repeats ONE index set: cached rows, not the ceiling)
+                m = re.match(r"(gather256|rmw\+hdr)\s+blocks\s+\d+\s*:\s*([0-9.]+) us", line)
+                if m:
+                    n = 390000 * 2 if m.group(1) == "gather256" else 147000 * 14
+                    best = max(best, n / (float(m.group(2)) * 1e-6))
+            if best:
+                ceil, csrc = best, os.path.relpath(path, ROOT)
+                break
+        except (OSError, ValueError):
+            continue
+    return req, src, ceil, csrc
+
+
 def secondary_lines(args):
     """the other single-GPU lines of SURVEY 8(d), each by a child process of this same file (own table, own
     measurement, own roofline blocks): c3 with the reference's default hyper-parameters and one GPU's share of C5
     (V_dim 128).  Run after the headline measurement has released its 21 GB; a failure is reported, not fatal."""
     import subprocess
     out = {}
-    for preset in ("c3-refdefaults", "c5-slice"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--preset", preset, "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--min-time", str(args.secondary_min_time), "--cpu-batches", "0", "--no-secondary"]
+    # (name, arguments): c3-cold = the FIRST 256 steps on an empty table (a real first epoch: index insert + zero row + lazy
+    # InitV land in a key's first step; VERDICT r4); c2 = the reference's quick-start shape with its own CPU baseline
+    runs = [("c3-refdefaults", ["--preset", "c3-refdefaults", "--cpu-batches", "0"]),
+            ("c5-slice", ["--preset", "c5-slice", "--cpu-batches", "0"]),
+            ("c3-cold", ["--preset", "c3", "--no-prefill", "--steps", "256", "--warmup", "0", "--max-reps", "1", "--min-time", "0",
+                         "--cpu-batches", "0", "--distinct", "256"]),
+            ("c2", ["--preset", "c2", "--cpu-batches", "100"])]
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--min-time", str(args.secondary_min_time), "--no-secondary"] + extra   # (later flags win: c3-cold sets its own steps)
         t0 = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             keep = ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repetitions", "timed_region_s_total",
-                    "dominant_kernel", "roofline", "roofline_backward", "roofline_step", "kernel_ms_per_step")
+                    "dominant_kernel", "roofline", "roofline_backward", "roofline_step", "kernel_ms_per_step", "steps", "warmup")
             e = {k: d.get(k) for k in keep}
+            if name == "c2":
+                e["cpu_baseline"] = d.get("cpu_baseline")
             e["config"] = {k: d["config"].get(k) for k in ("workload", "rows_per_step", "unique_keys_per_batch", "model_keys",
-                                                           "table_bytes", "hyper")}
+                                                           "table_bytes", "hyper", "prefilled")}
             e["wall_seconds"] = time.time() - t0
-            out[preset] = e
+            out[name] = e
         except Exception as ex:  # noqa: BLE001 — the headline line must survive anything here
-            out[preset] = dict(error=repr(ex)[:300], wall_seconds=time.time() - t0)
+            out[name] = dict(error=repr(ex)[:300], wall_seconds=time.time() - t0)
     return out
+
+
+def roofline_requests(args, s_per_step):
+    """the step against the rate at which the chip serves random memory-side requests (every random read is a
+    128 B line whatever it uses, writes are 32 / 64 B requests; the update's mix of the two is served at ~44 G requests/s)"""
+    if args.preset not in ("c3", "c3-refdefaults") or args.no_relocalize:
+        return None
+    req, src, ceil, csrc = requests_profile(not args.no_pipeline)
+    if not req or not ceil:
+        return None
+    per_s = req / s_per_step
+    return dict(bound="memory-side requests", per_step=req, per_s=per_s, ceiling_per_s=ceil, frac=per_s / ceil,
+                per_step_source=src, ceiling_source=csrc,
+                note="requests of a committed counter pass of this step (not of this run) over this run's step time; ceiling = best "
+                     "request rate of tools/fresh_bench.hip's patterns on fresh rows")
 
 
 def host_info():
@@ -553,6 +610,7 @@ def main():
         "roofline_step": dict(bound="hbm", bytes_per_example=r_step, achieved=ex_per_s * r_step / 1e9, peak=HBM_PEAK_GBPS,
                               unit="GB/s", frac=ex_per_s * r_step / 1e9 / HBM_PEAK_GBPS,
                               note="SURVEY 8d R_step = s(1+k)4 + s k 4 + u(3+2k)8 with the measured u = U/B"),
+        "roofline_requests": roofline_requests(args, dt / args.steps),
         "cpu_baseline": cpu,
         "secondary": secondary,
         "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,

@@ -530,6 +530,7 @@ int dispatch_L(int kp, F&& f) {
 }
 
 constexpr KeyRange kAllKeys{0u, 0xFFFFFFFFu, 0u};
+constexpr size_t kSmallBatchPairs = 16384;  // at or below: no probe ahead on the preparation stream (launch-bound sizes)
 
 int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr, const MixSrc* mix = nullptr) {
   BatchView bv = batch_view(b);
@@ -2624,7 +2625,7 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   b->defer_ready = true;
   rc = localize_impl(b, max_index, nullptr);
   lap(4);  // Localizer queued
-  if (!rc && nnz) {
+  if (!rc && nnz > kSmallBatchPairs) {   // (a small minibatch: the step's own pass probes, see dfh_batch_lookup)
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
     if (hipGetLastError() != hipSuccess) rc = DFH_ERR_HIP;
@@ -2681,6 +2682,10 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   }
   dfh_ctx* c = b->ctx;
   if (b->nnz == 0) return DFH_OK;
+  // A small minibatch is bound by the number of launches, not by what they move (C2, 7 500 pairs: the worker loop's step
+  // takes exactly as long as the host needs to queue it): the step's own lookup pass probes in the launch it makes anyway.
+  // 50.9 -> 44.8 us per step on the rcv1 shape (profiles/r05b_c2_launch_bound.txt).
+  if (b->nnz <= kSmallBatchPairs) return DFH_OK;
   DFH_HIP(hipSetDevice(c->device));
   int rc = table_reserve(t, b->nnz);  // U <= nnz keys may be new
   if (rc) return rc;

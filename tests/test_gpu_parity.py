@@ -7,6 +7,7 @@ because two fp32 evaluations that sum in different orders can only agree to
 eps * sum|terms|); feature-id hashing / indexing bit-exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -371,9 +372,91 @@ def test_table_save_load_files(capi, ctx, oracle, tmp_path):
 
 
 # ------------------------------------------------------------------ the fused step
+_RECORD = {}
+
+
+def _record_parity(case, d):
+    _RECORD[case] = {k: (float(v) if isinstance(v, (np.floating, float)) else int(v)) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_record():
+    """DFH_PARITY_RECORD_STEPS=<file>: worst error / tolerance of every step-by-step comparison of this module"""
+    yield
+    path = os.environ.get("DFH_PARITY_RECORD_STEPS")
+    if path and _RECORD:
+        import json
+        json.dump(_RECORD, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _export_index(tb):
+    """the device table as arrays sorted by key: (keys, scal[n, 4] = {fea_cnt, w, sqrt_g, z}, has_V, V[n, 2k] or None)"""
+    e = tb.export()
+    o = np.argsort(e["keys"])
+    return e["keys"][o], e["scal"][o], e["has_V"][o], (e["V"][o] if e["V"] is not None else None)
+
+
+def _resync_oracle(so, exp, keys):
+    """the oracle store takes the DEVICE's state of `keys` (every SGDEntry field, sgd_updater.h:19-29): the step that follows is
+    compared from identical state on both sides, so that no difference of an earlier step is carried along"""
+    ek, scal, has, V = exp
+    pos = np.searchsorted(ek, keys)
+    for key, p in zip(keys, pos):
+        if p < len(ek) and ek[p] == key:
+            so.poke(int(key), *scal[p], (V[p] if (V is not None and has[p]) else None))
+
+
+def _check_step_state(so, exp1, keys, kw, V_dim, gtol_w, gtol_V, what):
+    """the model after ONE step from identical state: the device's entries of the step's keys against the oracle's.  The update
+    arithmetic is the reference's operation for operation (dfh_kernels.hip ftrl_update_w / adagrad_update_v), so the two sides
+    can differ only by what the gradient tolerance gtol (rtol 1e-5 |g| + the summation floor of oracle/tolerance.py + the
+    logit tolerance carried through the slope) lets through, times the sensitivity of each field to the gradient
+    (sgd_updater.cc:104-138):  d sqrt_g <= dg;  dz <= (1 + |w| / lr) dg;  dw <= (lr + |w| + |w'|) / (lr_beta + sqrt_g') dg;
+    d acc <= dg;  dV <= 2 V_lr / V_lr_beta dg — doubled, plus rtol 1e-5 of the terms each field is summed from."""
+    from oracle import tolerance as T
+    ek, scal, has, V = exp1
+    pos = np.searchsorted(ek, keys)
+    R = T.RTOL
+    lr, lrb = kw.get("lr", 0.01), kw.get("lr_beta", 1.0)
+    vlr, vlrb = kw.get("V_lr", 0.01), kw.get("V_lr_beta", 1.0)
+    worst = 0.0
+    for u, (key, p) in enumerate(zip(keys, pos)):
+        assert p < len(ek) and ek[p] == key, "%s: key %d missing on the device" % (what, key)
+        o = so.peek(int(key))
+        assert o is not None
+        fc, w, sg, z = (float(x) for x in scal[p])
+        assert fc == float(o["fea_cnt"]), (what, key)
+        dg = float(gtol_w[u])
+        w0 = abs(float(o["w"])) + abs(w)
+        tol_sg = R * abs(o["sqrt_g"]) + 2 * dg
+        tol_z = R * (abs(o["z"]) + abs(o["sqrt_g"]) * (1 + w0 / lr)) + 2 * (1 + w0 / lr) * dg
+        tol_w = R * abs(o["w"]) + (lr / (lrb + abs(o["sqrt_g"]))) * tol_z + 2 * w0 * dg / (lrb + abs(o["sqrt_g"]))
+        for name, got, want, tol in (("sqrt_g", sg, o["sqrt_g"], tol_sg), ("z", z, o["z"], tol_z), ("w", w, o["w"], tol_w)):
+            err = abs(got - float(want))
+            assert err <= tol + 1e-30, "%s: key %d %s got %r want %r (|diff| %.3g > tol %.3g, gradient tol %.3g)" % (
+                what, key, name, got, float(want), err, tol, dg)
+            worst = max(worst, err / (tol + 1e-30))
+        assert bool(has[p]) == (o["V"] is not None), "%s: key %d has_V %d vs oracle %r" % (what, key, has[p], o["V"] is not None)
+        if V_dim and has[p]:
+            gv, ov = V[p].astype(np.float64), o["V"].astype(np.float64)
+            dgv = gtol_V[u]
+            tol_acc = R * np.abs(ov[V_dim:]) + 2 * dgv
+            tol_v = R * np.abs(ov[:V_dim]) + 2 * (vlr / vlrb) * (R * np.abs(ov[V_dim:]) + 2 * dgv)
+            ev, ea = np.abs(gv[:V_dim] - ov[:V_dim]), np.abs(gv[V_dim:2 * V_dim] - ov[V_dim:])
+            assert np.all(ea <= tol_acc + 1e-30), "%s: key %d accumulators off by up to %.3g (tol %.3g)" % (what, key, ea.max(), tol_acc[ea.argmax()])
+            assert np.all(ev <= tol_v + 1e-30), "%s: key %d V off by up to %.3g (tol %.3g)" % (what, key, ev.max(), tol_v[ev.argmax()])
+            worst = max(worst, float((ev / (tol_v + 1e-30)).max()), float((ea / (tol_acc + 1e-30)).max()))
+    return worst
+
+
 def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, device_localize=True, capacity=1 << 16,
-                         table=None):
-    from oracle import bindings as ob
+                         table=None, count_push_every_step=False):
+    """dfh_sgd_step against the oracle's worker loop, STEP BY STEP FROM IDENTICAL STATE (round 5; VERDICT r4: the fixed
+    rtol 5e-5 on logits / 2e-4 on the final weights of rounds 1-4 let a defect of 4 x rtol through): before every step the
+    oracle store takes the device's state of the step's keys, then both sides run the step and are compared with the
+    tolerance north_star states — logits at rtol 1e-5 + the summation floor, every field of every touched SGDEntry at
+    the gradient tolerance times the field's sensitivity (_check_step_state)."""
+    from oracle import bindings as ob, tolerance as T
     om = ob.INIT_HASH if mode == "hash" else ob.INIT_REFRAND
     dm = capi.INIT_HASH if mode == "hash" else capi.INIT_REFRAND
     so = oracle.store_create(init_mode=om, V_dim=V_dim, **kw)
@@ -382,51 +465,62 @@ def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, de
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     bt = capi.Batch(ctx, max_rows, max(max_nnz, 1))
     locs = [oracle.localize(b["offset"], b["index"]) for b in batches]
+    designs = [T.design(l["offset"], l["index"], b["value"], l["U"]) for b, l in zip(batches, locs)]
+    worst_pred = worst_state = 0.0
     for epoch in range(epochs):
-        for b, loc in zip(batches, locs):
+        push_cnt = epoch == 0 or count_push_every_step
+        for b, loc, D in zip(batches, locs, designs):
+            if not (epoch == 0 and b is batches[0] and table is None):
+                _resync_oracle(so, _export_index(tb), loc["feaids"])
             if device_localize:
                 bt.load_host(b["offset"], b["index"], b["value"], b["label"])
                 bt.localize()
             else:
                 bt.load_localized_host(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"],
-                                       loc["feacnt"] if epoch == 0 else None)
-            bt.sgd_step(tb, is_train=True, push_cnt=(epoch == 0))
+                                       loc["feacnt"] if push_cnt else None)
+            bt.sgd_step(tb, is_train=True, push_cnt=push_cnt)
             pg = bt.pred()
             prog_g = bt.progress(reset=True)
-            if epoch == 0:  # the step's own count push precedes its pull (sgd_learner.cc:214-217)
+            if push_cnt:  # the step's own count push precedes its pull (sgd_learner.cc:214-217)
                 so.push(loc["feaids"], ob.FEA_COUNT, loc["feacnt"])
-            pv, pl = so.pull(loc["feaids"])  # the weights this step will see, for an fp64 penalty
+            pv, pl = so.pull(loc["feaids"])  # the weights this step sees
             po, prog_o = so.sgd_step(loc["offset"], loc["index"], b["value"], b["label"], loc["feaids"],
                                      feacnt=None, is_train=True)
-            assert_close(pg, po, rtol=5e-5, what="pred epoch %d" % epoch)
+            w64, V64, has = T.dense_rows(pv, pl, V_dim)
+            _, floor_p = T.predict_bound(D, w64, V64)
+            worst_pred = max(worst_pred, T.check(pg, po, floor_p, "logits, epoch %d" % epoch))
+            # the gradient tolerance: rtol |g| + the sums' floor + what the logit tolerance lets through the slope (|dp/dpred| <= 1/4)
+            gw, gV, fl_w, fl_V = T.calcgrad_bound(D, b["label"], po, w64, V64, has)
+            dp = 0.25 * (T.RTOL * np.abs(po.astype(np.float64)) + floor_p)
+            gtol_w = T.RTOL * np.abs(gw) + fl_w + D.AT @ dp
+            gtol_V = None
+            if V_dim:
+                XV = np.abs(D.X @ V64)
+                gtol_V = T.RTOL * np.abs(gV) + fl_V + D.AT @ (XV * dp[:, None]) + np.abs(V64) * (D.X2T @ dp)[:, None]
+            worst_state = max(worst_state, _check_step_state(so, _export_index(tb), loc["feaids"], kw, V_dim, gtol_w, gtol_V,
+                                                             "model after the step, epoch %d" % epoch))
             # Loss::Evaluate sums n terms in fp32 (loss.h:57-66), the device in fp64: allow the
             # reference its own rounding, ~n * eps / 6 (observed 2.6e-5 at n = 10 000)
             assert prog_g.loss == pytest.approx(prog_o.loss, rel=2e-5 + 1e-8 * len(b["label"]))
             # EvaluatePenalty (sgd_learner.cc:249-273) adds U*(1+V_dim) small terms into one fp32
             # scalar; at 9.5 M terms whole addends fall below half an ulp of the running sum and the
             # reference comes out 1 % low.  The device keeps fp64 partials: check it against the
-            # exact value, and the reference within its own rounding.
-            if V_dim == 0:  # lens is empty: one value per key
-                w64, v64 = pv.astype(np.float64), np.zeros(0)
-            else:
-                starts = np.concatenate([[0], np.cumsum(pl)[:-1]]).astype(np.int64)
-                w64 = pv[starts].astype(np.float64)
-                is_w = np.zeros(len(pv), bool)
-                is_w[starts] = True
-                v64 = pv[~is_w].astype(np.float64)
+            # exact value, and the reference within its own rounding (n terms: ~sqrt(n) eps relative, the drift of a
+            # running fp32 sum of positive terms ~n eps / 2 at worst).
             exact = kw.get("l1", 0.0) * np.abs(w64).sum() + 0.5 * kw.get("l2", 0.0) * (w64 ** 2).sum() \
-                + 0.5 * kw.get("V_l2", 0.0) * (v64 ** 2).sum()
+                + 0.5 * kw.get("V_l2", 0.0) * (V64 ** 2).sum()
             assert prog_g.penalty == pytest.approx(exact, rel=2e-5, abs=1e-6)
             nterms = loc["U"] * (1 + V_dim)
-            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=1e-4 if nterms < 1e5 else 0.05, abs=1e-6)
+            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=max(1e-4, 0.5 * nterms * 2.0 ** -24), abs=1e-6)
             assert prog_g.nrows == prog_o.nrows
-    # final model state, key by key
+    # final model state, key by key: one step apart from identical state, so the last step's tolerance class
     allkeys = np.unique(np.concatenate([l["feaids"] for l in locs]))
     vg, lg = tb.pull(allkeys)
     vo, lo = so.pull(allkeys)
     assert np.array_equal(lg, lo)
-    assert_close(vg, vo, rtol=2e-4, what="final weights")
     n_with_v = int(np.sum(lo > 1)) if V_dim else 0
+    _record_parity("fused_stepwise/k%d/%s/%d_batches_x_%d" % (V_dim, mode, len(batches), epochs),
+                   dict(worst_logit_err_over_tol=worst_pred, worst_state_err_over_tol=worst_state, steps=epochs * len(batches)))
     if table is None:
         tb.close()
     bt.close()
@@ -441,6 +535,18 @@ def test_fused_step_vs_oracle(capi, ctx, oracle, V_dim, mode):
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=1, V_init_scale=0.2, seed=9)
     n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, 3, kw)
     assert (n_with_v > 0) == (V_dim > 0)
+
+
+def test_fused_steps_c5_shape(capi, ctx, oracle):
+    """BASELINE.json's C5 shape on one rank: V_dim = 128, the reference's default l1 = 1 and V_threshold = 10
+    (sgd_param.h:95-105), Criteo-shaped rows, feature counts pushed in every step (epoch 0): three minibatches, twice —
+    keys cross V_threshold and get their V lazily while w sits at 0 under l1 for most of them"""
+    from difacto_amd import synth
+    gen = synth.CriteoSynth(total_ids=200_000, seed=7)
+    batches = [gen.batch(1500) for _ in range(3)]
+    kw = dict(l1=1.0, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=10, V_init_scale=0.05, seed=3)
+    n_with_v = _run_fused_vs_oracle(capi, ctx, oracle, 128, "hash", batches, 2, kw, capacity=1 << 18, count_push_every_step=True)
+    assert n_with_v > 10
 
 
 def test_full_size_c3_minibatches(capi, ctx, oracle):

@@ -15,7 +15,9 @@ restatement: the same finite / non-finite pattern, and rtol 1e-5 (+ floor) where
 distinguish +-Inf from NaN in a sum that is non-finite on both sides (padding lanes multiply by 0), and it has one
 documented deviation: four consecutive V coordinates (one lane's 16 B slice) that are all exactly 0.0 inside an
 ALLOCATED row are treated like a key without V (dfh_kernels.hip k_forward) — NaN in the reference,
-neutral here; not constructed below.
+neutral here.  Observable only when the WHOLE allocated row is zero (any nonzero slice meets the same value and makes
+Inf - Inf = NaN on both sides): constructed in test_allocated_all_zero_V_row_times_nonfinite_value, which asserts the
+documented outcome on both sides.
 """
 import numpy as np
 import pytest
@@ -231,6 +233,64 @@ def test_hip_fused_step_on_nonfinite_values(capi, ctx, oracle, k):
     assert np.isfinite(vo).sum() > 0.3 * len(vo)
     tb.close()
     bt.close()
+
+
+def _zero_row_scenario(k):
+    """3 examples x 3 keys; the key of rank 1 has an ALLOCATED V row that is exactly zero and w = 0; example 1 carries it with x = Inf,
+    example 2 with x = NaN, example 0 with a finite value"""
+    off = np.array([0, 3, 6, 9], np.uint64)
+    idx = np.array([0, 1, 2] * 3, np.uint32)   # localized: ranks of the three keys
+    val = np.array([0.5, 1.0, -1.0, 0.25, np.inf, 2.0, 1.5, np.nan, 0.5], np.float32)
+    lab = np.array([1, -1, 1], np.float32)
+    rng = np.random.default_rng(5)
+    rows = [np.concatenate([[0.3], rng.normal(size=k) * 0.1]), np.concatenate([[0.0], np.zeros(k)]),
+            np.concatenate([[-0.2], rng.normal(size=k) * 0.1])]
+    W = np.concatenate(rows).astype(np.float32)
+    lens = np.full(3, 1 + k, np.int32)
+    return off, idx, val, lab, W, lens
+
+
+@pytest.mark.parametrize("k", [4, 64])
+def test_allocated_all_zero_V_row_times_nonfinite_value_reference_side(oracle, ref, k):
+    """the reference's side of the one documented deviation: SpMM has no zero skip (spmm.h:108-118 tests V_pos only), so an
+    allocated row of zeros times Inf / NaN is NaN, and so is the logit (fm_loss.h:118 clamps +-Inf, never NaN)"""
+    off, idx, val, lab, W, lens = _zero_row_scenario(k)
+    wp, vp = oracle.get_pos(lens)
+    po = oracle.fm_predict(k, off, idx, val, W, wp, vp)
+    pr = ref.fm_predict(k, off, idx, val, W, wp, vp)
+    assert np.isfinite(po[0]) and np.isnan(po[1]) and np.isnan(po[2])
+    assert np.array_equal(np.isnan(pr), np.isnan(po)) and pr[0] == po[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 64])
+def test_allocated_all_zero_V_row_times_nonfinite_value(capi, ctx, oracle, k):
+    """... and the device's: k_forward loads V rows speculatively and takes a 16 B slice that is all zero for "no V" (the
+    per-coordinate test costs the forward 1.4 of 20 us), so the all-zero ALLOCATED row is neutral: the logit of the two
+    poisoned examples is what it would be without that key (its w is 0: SpMV skips it on both sides, spmv.h:125).  A model
+    reaches this state only by import / load: InitV draws from +-V_init_scale / 2 and AdaGrad steps do not return a whole
+    row to exact zero."""
+    from oracle import tolerance as T
+    off, idx, val, lab, W, lens = _zero_row_scenario(k)
+    wp, vp = oracle.get_pos(lens)
+    # what the logits are WITHOUT key 1 (drop its nonzeros): the device's answer for all three examples
+    keep = idx != 1
+    off2 = np.array([0, 2, 4, 6], np.uint64)
+    po_without = oracle.fm_predict(k, off2, idx[keep], val[keep], W, wp, vp)
+    stride = capi.row_stride(k)
+    rows = T.packed_rows(W, lens, k, stride)
+    bt = capi.Batch(ctx, 3, 9)
+    raw = np.array([5, 9, 12], np.uint64)   # any three distinct ids; ranks follow the reversed order
+    order = np.argsort(np.array([capi.reverse_bytes(int(x)) for x in raw], dtype=np.uint64))
+    bt.load_host(off, raw[order][idx], val, lab)   # raw[order][r]: the raw id whose reversed key has rank r
+    bt.localize()
+    d_rows = capi.DeviceBuffer.from_numpy(ctx, rows)
+    bt.forward(k, d_rows.ptr)
+    pg = bt.pred()
+    assert np.all(np.isfinite(pg)), pg
+    np.testing.assert_allclose(pg[1:], po_without[1:], rtol=1e-5, atol=1e-6)
+    for o in (bt, d_rows):
+        o.close()
 
 
 @pytest.mark.gpu
