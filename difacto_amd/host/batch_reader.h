@@ -120,7 +120,12 @@ class TextChunks {
     out->data = nullptr;
     out->size = 0;
     if (pos_ >= end_) return false;
-    size_t stop = std::min(pos_ + chunk_bytes_, end_);
+    // the first chunks are small: a job's first shuffle buffer (batch_size x shuffle rows, ~23 MB of criteo text) used to lie
+    // in two 16 MB chunks, i.e. was parsed by two threads while the others idled and the device waited (~15 ms of a job's
+    // ~65 ms start-up); sixteenths of a chunk for the first 64 let the whole pool work on it
+    const size_t want = nchunks_ < 64 ? std::max<size_t>(chunk_bytes_ / 16, 64) : chunk_bytes_;
+    ++nchunks_;
+    size_t stop = std::min(pos_ + want, end_);
     if (base_[stop - 1] != '\n') {  // finish the line that crosses the chunk (or the part) border
       const char* nl = static_cast<const char*>(memchr(base_ + stop, '\n', size_ - stop));
       stop = nl ? static_cast<size_t>(nl - base_) + 1 : size_;
@@ -143,6 +148,7 @@ class TextChunks {
   const char* base_ = nullptr;
   size_t size_ = 0, pos_ = 0, end_ = 0;
   size_t chunk_bytes_;
+  size_t nchunks_ = 0;
 };
 
 /*! \brief "label idx[:val] idx[:val] ..." per line; '#' starts a comment line */

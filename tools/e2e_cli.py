@@ -33,7 +33,8 @@ for a in range(0, rows, 10000):
     recs.append(oi.write_crb_record(off[a:b + 1] - off[a], labf[a:b], idx[int(off[a]):int(off[b])]))
 open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
 sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
-common = ["task=train", "learner=sgd", "batch_size=10000", "max_num_epochs=1", "V_dim=64", "V_threshold=0", "l1=0", "lr=.01",
+common = ["task=train", "learner=sgd", "batch_size=" + os.environ.get("E2E_BATCH_SIZE", "10000"), "max_num_epochs=1",
+          "V_dim=" + os.environ.get("E2E_VDIM", "64"), "V_threshold=0", "l1=0", "lr=.01",
           "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
 EXES = os.environ.get("E2E_EXES", "difacto").split(",")   # A/B: several binaries under build/ on the same files
 # A/B of environment switches on the same files: E2E_VARIANTS="name:KEY=VAL+KEY=VAL,name2:" (an entry of EXES may be
