@@ -120,12 +120,10 @@ class TextChunks {
     out->data = nullptr;
     out->size = 0;
     if (pos_ >= end_) return false;
-    // the first chunks are small: a job's first shuffle buffer (batch_size x shuffle rows, ~23 MB of criteo text) used to lie
-    // in two 16 MB chunks, i.e. was parsed by two threads while the others idled and the device waited (~15 ms of a job's
-    // ~65 ms start-up); sixteenths of a chunk for the first 64 let the whole pool work on it
-    const size_t want = nchunks_ < 64 ? std::max<size_t>(chunk_bytes_ / 16, 64) : chunk_bytes_;
-    ++nchunks_;
-    size_t stop = std::min(pos_ + want, end_);
+    // (Measured dead end, round 5: sixteenths of a chunk for a job's first 64 chunks, so that the whole parser pool works on
+    // the first shuffle buffer — start-up 77 -> 64 ms, but the pool of chunk containers then recycles 64 small containers
+    // for ever and the steady state fell 70 -> 54-62 M rows/s on criteo text; profiles/r05d_e2e_chunk_ramp_ab.txt.)
+    size_t stop = std::min(pos_ + chunk_bytes_, end_);
     if (base_[stop - 1] != '\n') {  // finish the line that crosses the chunk (or the part) border
       const char* nl = static_cast<const char*>(memchr(base_ + stop, '\n', size_ - stop));
       stop = nl ? static_cast<size_t>(nl - base_) + 1 : size_;
@@ -148,7 +146,6 @@ class TextChunks {
   const char* base_ = nullptr;
   size_t size_ = 0, pos_ = 0, end_ = 0;
   size_t chunk_bytes_;
-  size_t nchunks_ = 0;
 };
 
 /*! \brief "label idx[:val] idx[:val] ..." per line; '#' starts a comment line */
