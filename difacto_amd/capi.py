@@ -32,7 +32,7 @@ SYMBOLS = [
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
     "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
-    "dfh_shard_multi_words", "dfh_shard_reserve", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
+    "dfh_batch_create_many", "dfh_shard_multi_words", "dfh_shard_reserve", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
 ]
 XCHG_COUNTS, XCHG_KEYS, XCHG_CNT, XCHG_ROWS, XCHG_GRADS, XCHG_OTHER = range(6)
 SHARD_STAGES = ("counts", "L", "K", "R", "RW", "F", "G", "P")
@@ -118,6 +118,7 @@ def lib():
     L.dfh_auc_times_n.argtypes = [vp, vp, vp, sz, PP(f32)]
     L.dfh_batch_create.argtypes = [vp, sz, sz, PP(vp)]
     L.dfh_batch_destroy.argtypes = [vp]
+    L.dfh_batch_create_many.argtypes = [vp, i32, sz, sz, PP(vp)]
     L.dfh_batch_load_host.argtypes = [vp, sz, vp, vp, vp, vp]
     L.dfh_batch_load_device.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.dfh_batch_attach_device.argtypes = [vp, sz, sz, vp, vp, vp, vp]
@@ -483,6 +484,18 @@ class RowBuf:
         if self.h:
             lib().dfh_rowbuf_destroy(self.h)
             self.h = None
+
+
+def create_batches(ctx, n, max_rows, max_nnz):
+    """n Batch objects carved from one device allocation (dfh_batch_create_many)"""
+    hs = (C.c_void_p * n)()
+    _ck(lib().dfh_batch_create_many(ctx.h, n, max_rows, max_nnz, hs))
+    out = []
+    for i in range(n):
+        b = Batch.__new__(Batch)
+        b.ctx, b.h = ctx, C.c_void_p(hs[i])
+        out.append(b)
+    return out
 
 
 class Batch:

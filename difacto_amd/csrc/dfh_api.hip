@@ -5,6 +5,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
@@ -55,6 +56,11 @@ struct dfh_ctx {
   // consumer of these events is a stream of this device
   int event_flags = 1;
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
+  // The library's code object (8 MB, a few hundred kernel instantiations) is loaded by the runtime on the FIRST launch of any
+  // of its kernels: 30-40 ms that used to fall into a job's first minibatch (build/difacto: the first dfh_batch_prepare_rows
+  // took 32-42 ms, profiles/r05e_e2e_startup.txt).  A helper thread makes that first launch while the caller goes on to
+  // allocate its model table; joined when the context is destroyed.
+  std::thread warm;
 
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
@@ -128,6 +134,9 @@ struct dfh_batch {
   uint32_t* d_offset = nullptr;
   float* d_value = nullptr;
   float* d_label = nullptr;
+  void* arena = nullptr;     // the one device allocation the object's arrays are carved from (dfh_batch_create)
+  void* shared_arena = nullptr;  // SharedArena*: dfh_batch_create_many
+  size_t arena_bytes = 0;
   uint64_t* o_raw = nullptr;
   uint32_t* o_offset = nullptr;
   float* o_value = nullptr;
@@ -834,12 +843,27 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  if (!(getenv("DFH_WARM_LOAD") && atoi(getenv("DFH_WARM_LOAD")) == 0)) {   // (0: A/B)
+    c->warm = std::thread([device] {
+      if (hipSetDevice(device) != hipSuccess) return;
+      hipStream_t s = nullptr;
+      uint32_t* d = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&d), 256) == hipSuccess) {
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, d, 0u);
+        (void)hipStreamSynchronize(s);
+      }
+      (void)hipGetLastError();
+      if (d) (void)hipFree(d);
+      if (s) (void)hipStreamDestroy(s);
+    });
+  }
   *out = c;
   return DFH_OK;
 }
 
 int dfh_ctx_destroy(dfh_ctx* c) {
   if (!c) return DFH_OK;
+  if (c->warm.joinable()) c->warm.join();
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->scratch) hipFree(c->scratch);
@@ -1810,8 +1834,18 @@ int dfh_loss_evaluate(dfh_ctx* c, const float* label, const float* pred, size_t 
 }
 
 // ------------------------------------------------------------------ batches
-int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** out) {
-  DFH_ARG(c && out && max_rows >= 1 && max_nnz >= 1, "dfh_batch_create: bad argument");
+namespace {
+// several batch objects carved from ONE device allocation (dfh_batch_create_many): the last one destroyed frees it
+struct SharedArena {
+  void* base = nullptr;
+  int refs = 0;
+};
+}  // namespace
+
+// shared != NULL: the object's arrays are carved at shared->base + at (sized by a first call with size_only = true)
+static int batch_create_impl(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** out, SharedArena* shared, size_t at,
+                             size_t* size_only, bool sync) {
+  DFH_ARG(c && (out || size_only) && max_rows >= 1 && max_nnz >= 1, "dfh_batch_create: bad argument");
   DFH_ARG(max_nnz < 0xFFFFFFF0ULL && max_rows < 0xFFFFFFF0ULL, "batch too large for 32-bit positions");
   DFH_HIP(hipSetDevice(c->device));
   dfh_batch* b = new (std::nothrow) dfh_batch();
@@ -1828,15 +1862,44 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   rocprim::radix_sort_pairs(nullptr, auc_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, B, 0, 32, c->stream);
   b->temp_bytes = std::max(std::max(sort_bytes, scan_bytes), auc_bytes) + 256;
+  // ONE device allocation per batch object, carved below (256 B aligned pieces).  Until round 5 every array was its own
+  // hipMalloc — 61 of them, ~40 us each: the worker loop's twelve objects cost a job ~35 ms of its ~65 ms start-up.  Two passes
+  // over the same list: the first adds the sizes up, the second hands the pieces out.
+  char* arena_at = nullptr;
+  size_t arena_need = 0;
+  bool sizing = true;
 #define DFH_ALLOC(ptr, count, type)                                                        \
   do {                                                                                     \
-    hipError_t e__ = hipMalloc(reinterpret_cast<void**>(&(ptr)), (count) * sizeof(type));  \
-    if (e__ != hipSuccess) {                                                               \
-      set_error(std::string("dfh_batch_create: hipMalloc: ") + hipGetErrorString(e__));    \
-      dfh_batch_destroy(b);                                                                \
-      return DFH_ERR_HIP;                                                                  \
+    const size_t bytes__ = (((size_t)(count) * sizeof(type)) + 255) & ~(size_t)255;        \
+    if (sizing) {                                                                          \
+      arena_need += bytes__;                                                               \
+    } else {                                                                               \
+      (ptr) = reinterpret_cast<type*>(arena_at);                                           \
+      arena_at += bytes__;                                                                 \
     }                                                                                      \
   } while (0)
+  for (int pass = 0; pass < 2; ++pass) {
+  sizing = pass == 0;
+  if (!sizing) {
+    if (size_only) {   // the caller only asked how much one object takes
+      *size_only = arena_need;
+      delete b;
+      return DFH_OK;
+    }
+    if (shared) {
+      b->shared_arena = shared;
+      ++shared->refs;
+      arena_at = static_cast<char*>(shared->base) + at;
+    } else {
+      hipError_t e__ = hipMalloc(reinterpret_cast<void**>(&b->arena), arena_need);
+      if (e__ != hipSuccess) {
+        set_error(std::string("dfh_batch_create: hipMalloc: ") + hipGetErrorString(e__));
+        dfh_batch_destroy(b);
+        return DFH_ERR_HIP;
+      }
+      arena_at = static_cast<char*>(b->arena);
+    }
+  }
   DFH_ALLOC(b->o_raw, N, uint64_t);
   DFH_ALLOC(b->o_offset, B + 1, uint32_t);
   DFH_ALLOC(b->o_value, N, float);
@@ -1893,7 +1956,9 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   DFH_ALLOC(b->d_auc_lab, B, uint32_t);
   DFH_ALLOC(b->d_auc_slab, B, uint32_t);
   DFH_ALLOC(b->d_auc_part, AUC_PART_WORDS, uint32_t);
+  }  // sizing pass, carving pass
 #undef DFH_ALLOC
+  b->arena_bytes = arena_need;
   b->d_total = b->d_U + 1;
   // ev_ready / ev_free order streams of ONE device: no system-scope fence (cache write-back + invalidate) at the record
   const unsigned evf = hipEventDisableTiming | (c->event_flags ? hipEventDisableSystemFence : 0u);
@@ -1906,8 +1971,45 @@ int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** ou
   // all-ones makes a stray use fault at once instead of reading some row
   DFH_HIP(hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream));
   DFH_HIP(hipMemsetAsync(b->d_uw, 0xFF, N * sizeof(uint2), c->stream));
-  DFH_HIP(hipStreamSynchronize(c->stream));
+  if (sync) DFH_HIP(hipStreamSynchronize(c->stream));
   *out = b;
+  return DFH_OK;
+}
+
+int dfh_batch_create(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_batch** out) {
+  return batch_create_impl(c, max_rows, max_nnz, out, nullptr, 0, nullptr, true);
+}
+
+int dfh_batch_create_many(dfh_ctx* c, int n, size_t max_rows, size_t max_nnz, dfh_batch** out) {
+  DFH_ARG(c && out && n >= 1 && n <= 64, "dfh_batch_create_many: 1 <= n <= 64 objects");
+  size_t each = 0;
+  int rc = batch_create_impl(c, max_rows, max_nnz, nullptr, nullptr, 0, &each, false);
+  if (rc) return rc;
+  each = (each + 4095) & ~(size_t)4095;
+  SharedArena* sa = new (std::nothrow) SharedArena();
+  DFH_ARG(sa != nullptr, "out of host memory");
+  DFH_HIP(hipSetDevice(c->device));
+  if (hipMalloc(&sa->base, each * (size_t)n) != hipSuccess) {
+    delete sa;
+    set_error("dfh_batch_create_many: hipMalloc failed");
+    return DFH_ERR_HIP;
+  }
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  for (int i = 0; i < n; ++i) {
+    rc = batch_create_impl(c, max_rows, max_nnz, &out[i], sa, each * (size_t)i, nullptr, false);
+    if (rc) {
+      for (int j = 0; j < i; ++j) {
+        dfh_batch_destroy(out[j]);
+        out[j] = nullptr;
+      }
+      if (sa->refs == 0) {
+        hipFree(sa->base);
+        delete sa;
+      }
+      return rc;
+    }
+  }
+  DFH_HIP(hipStreamSynchronize(c->stream));   // the objects' memsets
   return DFH_OK;
 }
 
@@ -1922,15 +2024,15 @@ int dfh_batch_destroy(dfh_batch* b) {
   if (b->ev_free) hipEventDestroy(b->ev_free);
   if (b->ev_staged) hipEventDestroy(b->ev_staged);
   if (b->h_stage) hipHostFree(b->h_stage);
-  void* ptrs[] = {b->o_raw,    b->o_offset,  b->o_value,    b->o_label,    b->d_keys,     b->d_skeys,     b->d_pos,     b->d_spos,
-                  b->d_bpos,   b->d_head,    b->d_uid,      b->d_temp,     b->d_feaids,   b->d_feacnt,    b->d_col_ptr, b->d_index,
-                  b->d_s_row,  b->d_s_val,   b->d_U,        b->d_urow,     b->d_need,     b->d_rank,      b->d_pred,    b->d_slope,
-                  b->d_xv,     b->d_prog,    b->d_smp_key,  b->d_smp_pos,  b->d_smp_rank, b->d_spl_key,   b->d_spl_pos, b->d_first_key,
-                  b->d_last_key, b->d_packed, b->d_run_off, b->d_bstart,   b->d_btotal,   b->d_nheads,    b->d_lh,      b->d_auc_keys,
-                  b->d_auc_skeys, b->d_auc_lab, b->d_auc_slab, b->d_mid, b->d_mid_ent, b->d_hot, b->d_hot_ent, b->d_uw,
-                  b->d_auc_part, b->d_few, b->d_few_ent};
-  for (void* p : ptrs)
-    if (p) hipFree(p);
+  if (b->d_xv) hipFree(b->d_xv);      // (grows with V_dim: its own allocation, ensure_xv)
+  if (b->arena) hipFree(b->arena);   // every other device array of the object
+  if (b->shared_arena) {             // ... or its share of an allocation made for several objects
+    SharedArena* sa = static_cast<SharedArena*>(b->shared_arena);
+    if (--sa->refs == 0) {
+      hipFree(sa->base);
+      delete sa;
+    }
+  }
   delete b;
   return DFH_OK;
 }

@@ -417,10 +417,10 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     }
     batch_rows_ = std::max(rows, batch_rows_);
     batch_nnz_ = std::max(nnz * 2, batch_nnz_);
-    for (int q = 0; q < nrot; ++q) {
-      DFH_CALL(dfh_batch_create(ctx, batch_rows_, std::max<size_t>(batch_nnz_, 1), &batch_[q]));
-      DFH_CALL(dfh_batch_set_option(batch_[q], "compute_auc", 1));  // sgd_learner.cc:153-155
-    }
+    // one device allocation for all of them (dfh_batch_create_many): twelve objects used to be 12 x 61 hipMallocs, ~35 ms of
+    // a job's start-up
+    DFH_CALL(dfh_batch_create_many(ctx, nrot, batch_rows_, std::max<size_t>(batch_nnz_, 1), batch_));
+    for (int q = 0; q < nrot; ++q) DFH_CALL(dfh_batch_set_option(batch_[q], "compute_auc", 1));  // sgd_learner.cc:153-155
   };
   const bool split_prep = getenv("DIFACTO_SPLIT_PREP") != nullptr;
   std::vector<dfh_rowbuf*> bufs;
@@ -498,11 +498,19 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   // earlier job left; a bigger minibatch re-creates them, as before)
   if (device_feed && !all_there() && !(getenv("DIFACTO_FEED_PRECREATE") && atoi(getenv("DIFACTO_FEED_PRECREATE")) == 0))
     ensure(param_.batch_size, static_cast<size_t>(param_.batch_size) * ids_per_row);
+  const double t_created = prof ? now() : 0;
   bool have = reader.Next();
+  const double t_first = prof ? now() : 0;
   if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
   int i = 0;
   if (have) prepare(0);
-  if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
+  if (prof) {
+    const double t1 = now();
+    LOG(INFO) << "start-up: batch objects " << t_created - (t_first - t_read) << " s, first minibatch from the reader after "
+              << t_first - t_created << " s more, its preparation queued in " << t1 - t_first << " s";
+    t_prep += t1 - t0;
+    t0 = t1;
+  }
   while (have) {
     const int cur = i % nrot, nxt = (i + 1) % nrot;
     const bool have_next = reader.Next();

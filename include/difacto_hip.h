@@ -190,6 +190,9 @@ int dfh_auc_times_n(dfh_ctx* ctx, const float* label, const float* pred, size_t 
 
 /* ------------------------------------------------- device-resident batches */
 int dfh_batch_create(dfh_ctx* ctx, size_t max_rows, size_t max_nnz, dfh_batch** out);
+/* n batch objects of one size out of ONE device allocation (freed with the last of them): what a worker loop that rotates a
+ * dozen objects creates at the start of a job — one allocation instead of n (a job's start-up) */
+int dfh_batch_create_many(dfh_ctx* ctx, int n, size_t max_rows, size_t max_nnz, dfh_batch** out);
 int dfh_batch_destroy(dfh_batch* b);
 
 /* raw minibatch = what Reader::Value() hands the worker (dmlc::RowBlock<feaid_t>,
