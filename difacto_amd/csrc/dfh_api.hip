@@ -1317,10 +1317,7 @@ int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint6
   const size_t stride = dfh_row_stride(t->v.k);
   rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
-#ifndef DFH_PGM_BLOCKS_PER_CU
-#define DFH_PGM_BLOCKS_PER_CU 16
-#endif
-    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * DFH_PGM_BLOCKS_PER_CU);
+    const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);   // (8 / 32 per CU: 61.0 / 58.6 against 57.4 us)
     hipLaunchKernelGGL((k_push_grad_multi<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g,
                        d_grads, stride);
   });

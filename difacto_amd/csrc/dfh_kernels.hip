@@ -1600,23 +1600,18 @@ __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ row
 // row, the V / accumulator slices and the extras are requested together, before anything is known about
 // the key: a key of one source (80 %) is row word -> {header, row, gradient} -> store, a key of several
 // sources one round trip more (the other sources' gradient rows, four at a time).
+// measurement switches (tools/owner_bench.py at N = 8 size, profiles/r05a_*): streaming hints on the row loads / stores change
+// nothing (58.1 against 57.4 us), nor does the number of gradient rows requested per round trip (1 / 2 / 8: 51.1 / 46.6 / 50.5
+// against 47.4 us for 4) or the waves per SIMD those leave room for
 #ifndef DFH_PGM_NT
 #define DFH_PGM_NT 0
 #endif
 #ifndef DFH_PGM_BATCH
 #define DFH_PGM_BATCH 4
 #endif
-#ifndef DFH_PGM_WAVES
-#define DFH_PGM_WAVES 0
-#endif
-#if DFH_PGM_WAVES
-#define DFH_PGM_BOUNDS __launch_bounds__(256, DFH_PGM_WAVES)
-#else
-#define DFH_PGM_BOUNDS __launch_bounds__(256)
-#endif
 constexpr int PGM_BATCH = DFH_PGM_BATCH;
 template <int L>
-__global__ void DFH_PGM_BOUNDS k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
+__global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint32_t* __restrict__ rowid,
                                                          const uint64_t* __restrict__ keys, SegOff g,
                                                          const float* __restrict__ grads, size_t stride) {
   constexpr int GPW = 64 / L;
