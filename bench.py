@@ -112,6 +112,9 @@ def parse_args():
                          "slowest rank) or `all` (one after the other; the projection takes the slowest, like a job's barrier would)")
     ap.add_argument("--emulate-wire", choices=["off", "peak", "achievable"], default="achievable",
                     help="which wire model the projected `value` is quoted under (all three are in the line)")
+    ap.add_argument("--shard-prep-ahead", type=int, default=2,
+                    help="N>1: minibatches are localized this many steps before they train (2: the keys of minibatch t+1 are ready "
+                         "when step t starts and travel at once; 1: round 4's loop)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (key-range shards + RCCL all_to_all_v) even with one rank")
     args = ap.parse_args()

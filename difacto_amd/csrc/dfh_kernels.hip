@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256) k_auc_finalize(AucFin f) { auc_finalize_b
 // Push(kFeaCount): fea_cnt += cnt, maybe InitV (sgd_updater.cc:62-73).
 // cnt_from_ptr: counts are the segment lengths of the localized batch.
 // ---------------------------------------------------------------------------
-__global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+__device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
                          int rows_known, uint2* __restrict__ uw, AucFin fin) {
@@ -481,17 +481,43 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
   }
 }
 
+__global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                         uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
+                         const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
+                         int rows_known, uint2* __restrict__ uw, AucFin fin) {
+  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin);
+}
+
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
 // the pulled-rows buffer belongs to key u; the slots of this rank's own keys [lo, hi) are unused)
+struct UwRemote {
+  const float* rows;
+  size_t stride;
+  const uint32_t* d_U;
+  uint32_t lo, hi;
+  uint2* uw;                 // the whole minibatch's array (the lookup's `uw` starts at the rank's own keys)
+  const uint32_t* col_ptr;   // likewise
+};
+__device__ __forceinline__ void uw_remote_body(const UwRemote& m) {
+  const uint32_t U = *m.d_U;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
+    if (u - m.lo < m.hi - m.lo) continue;
+    // (bit 30: the key occurs once in the minibatch — the singles role of the mixed update launch takes it)
+    const uint32_t single = (m.col_ptr && m.col_ptr[u + 1] - m.col_ptr[u] == 1u) ? kSingleRow : 0u;
+    m.uw[u] = make_uint2(u | kRemoteRow | single, __float_as_uint(m.rows[(size_t)u * m.stride]));
+  }
+}
 __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,
                             uint32_t hi, uint2* __restrict__ uw, const uint32_t* __restrict__ col_ptr) {
-  const uint32_t U = *d_U;
-  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
-    if (u - lo < hi - lo) continue;
-    // (bit 30: the key occurs once in the minibatch — the singles role of the mixed update launch takes it)
-    const uint32_t single = (col_ptr && col_ptr[u + 1] - col_ptr[u] == 1u) ? kSingleRow : 0u;
-    uw[u] = make_uint2(u | kRemoteRow | single, __float_as_uint(rows[(size_t)u * stride]));
-  }
+  uw_remote_body(UwRemote{rows, stride, d_U, lo, hi, uw, col_ptr});
+}
+// the own keys' lookup and the others' row words in ONE launch (overlapped exchange: the rows of the other owners arrived
+// during the previous step; one launch boundary less on the main stream of the sharded step)
+__global__ void k_lookup_uw_remote(TableView t, const uint64_t* __restrict__ keys, uint32_t n_static, uint32_t* __restrict__ urow,
+                                   const float* __restrict__ cnt, const uint32_t* __restrict__ col_ptr, int push_cnt,
+                                   uint2* __restrict__ uw, AucFin fin, UwRemote m) {
+  lookup_body(t, keys, nullptr, n_static, urow, cnt, col_ptr, push_cnt, nullptr, 0, uw, fin);
+  uw_remote_body(m);
 }
 
 // ---------------------------------------------------------------------------

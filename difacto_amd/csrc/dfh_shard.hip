@@ -1369,14 +1369,25 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
   // ---- L: this rank's own keys: rows + Push(kFeaCount) on its own table, {row, w} per key for the forward.  Runs
   // after everything the previous step applied: own keys are read with zero staleness.
   const uint32_t n_own = cur.own_hi - cur.own_lo;
+  // the row words of the others' keys ride in this launch when their rows are already on their way (every step but an
+  // epoch's first): one launch boundary less on the main stream
+  const bool uw_folded = cur.any_own && cur.pulled && cur.any_remote && b != nullptr;
   if (cur.any_own) {
     if (int rcr = table_reserve(t, n_own)) return rcr;
     StageScope ts(s, DFH_SHARD_STAGE_L, st);
     const bool counts = push_cnt != 0;
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
-                       (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo,
-                       (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr, b->d_col_ptr + cur.own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + cur.own_lo, auc_pending(b));
+    const float* cntp = (counts && b->has_cnt) ? b->d_feacnt + cur.own_lo : (const float*)nullptr;
+    const int mode = counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0;
+    if (uw_folded) {
+      DFH_HIP(hipStreamWaitEvent(st, s->ev_rw[cur.slot], 0));  // the rows of the other owners have arrived
+      const UwRemote m{s->w_rows[cur.slot], stride, b->d_U, cur.own_lo, cur.own_hi, b->d_uw, b->d_col_ptr};
+      hipLaunchKernelGGL(k_lookup_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo, n_own,
+                         b->d_urow + cur.own_lo, cntp, b->d_col_ptr + cur.own_lo, mode, b->d_uw + cur.own_lo, auc_pending(b), m);
+    } else {
+      hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
+                         (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo, cntp, b->d_col_ptr + cur.own_lo, mode, (uint32_t*)nullptr,
+                         0, b->d_uw + cur.own_lo, auc_pending(b));
+    }
     b->auc_pending_n = 0;
     DFH_HIP(hipGetLastError());
   }
@@ -1405,9 +1416,9 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     StageScope ts(s, DFH_SHARD_STAGE_F, st);
     rc = ensure_xv(b, kp);
     if (rc) return rc;
-    DFH_HIP(hipStreamWaitEvent(st, s->ev_rw[q], 0));  // the rows of the other owners have arrived
+    if (!uw_folded) DFH_HIP(hipStreamWaitEvent(st, s->ev_rw[q], 0));  // the rows of the other owners have arrived
     const RowSrc tsrc = table_src(t, b->d_urow);
-    if (cur.any_remote) {
+    if (cur.any_remote && !uw_folded) {
       hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, s->w_rows[q], stride, b->d_U, cur.own_lo,
                          cur.own_hi, b->d_uw, b->d_col_ptr);
       DFH_HIP(hipGetLastError());

@@ -183,7 +183,11 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
             host_sample.append(hb)
         dev.append((capi.DeviceBuffer.from_numpy(ctx, hb["offset"].astype(np.uint32)), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
                     capi.DeviceBuffer.from_numpy(ctx, hb["label"])))
-    bts = [capi.Batch(ctx, B, B * S) for _ in range(3)]
+    # minibatches are localized `ahead` steps before they train (--shard-prep-ahead, default 2): the overlapped exchange
+    # sends the keys of minibatch t+1 during step t, so its Localizer has to be through when step t STARTS — localized only
+    # one ahead (round 4) it ran beside step t's forward and the owners' pull for t+1 waited for it
+    ahead = max(1, int(getattr(args, "shard_prep_ahead", 2)))
+    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + 2)]
     if not getattr(args, "no_auc", False):
         for b_ in bts:
             b_.set_option("compute_auc", 1)   # BinClassMetric::AUC of every minibatch (sgd_learner.cc:153-155)
@@ -192,14 +196,15 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
         o, x, l = dev[i % nd]
         b = bts[i % len(bts)]
         b.attach_device(B, B * S, o.ptr, x.ptr, None, l.ptr)
-        b.localize()   # on the preparation stream, while the previous step's exchange runs
+        b.localize()   # on the preparation stream, while earlier steps' exchanges run
 
     def step(i):
-        prep(i + 1)
+        prep(i + ahead)
         shard.prefetch_counts(bts[(i + 1) % len(bts)])   # the next step will not wait for its counts mid-way
         shard.step(bts[i % len(bts)], is_train=True, push_cnt=True)
 
-    prep(0)
+    for j in range(ahead):
+        prep(j)
     done = 0
     for _ in range(args.warmup):
         step(done)
@@ -447,6 +452,8 @@ def bench_main_emulated(args, hyper, cpu_baseline_fn=None):
     results = []
     for r in ranks:
         results.append(_emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride, nd))
+    if args.emulate_wire not in results[0]["models"]:   # DFH_EMUL_MODELS left it out
+        args.emulate_wire = next(iter(results[0]["models"]))
     worst = max(results, key=lambda x: x["models"][args.emulate_wire]["ms_per_step"])
     headline = worst["models"][args.emulate_wire]
     proj = {m: W * B / (max(x["models"][m]["ms_per_step"] for x in results) * 1e-3) for m in worst["models"]}
@@ -561,7 +568,8 @@ def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride,
     comm.feed(capi.XCHG_GRADS, grads_shadow.ptr, sticky=True)
     dev = [(capi.DeviceBuffer.from_numpy(ctx, hb["offset"].astype(np.uint32)), capi.DeviceBuffer.from_numpy(ctx, hb["index"]),
             capi.DeviceBuffer.from_numpy(ctx, hb["label"])) for hb in raw]
-    bts = [capi.Batch(ctx, B, B * S) for _ in range(3)]
+    ahead = max(1, int(getattr(args, "shard_prep_ahead", 2)))   # (see bench_main_native)
+    bts = [capi.Batch(ctx, B, B * S) for _ in range(ahead + 2)]
     if not getattr(args, "no_auc", False):
         for b_ in bts:
             b_.set_option("compute_auc", 1)
@@ -580,11 +588,12 @@ def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride,
         fed[0] += 1
 
     def step(i):
-        prep(i + 1)
+        prep(i + ahead)
         shard.prefetch_counts(bts[(i + 1) % len(bts)])
         shard.step(bts[i % len(bts)], is_train=True, push_cnt=True)
 
-    prep(0)
+    for j in range(ahead):
+        prep(j)
     done = 0
     for _ in range(args.warmup):
         step(done)
@@ -595,7 +604,10 @@ def _emulate_one_rank(args, r, W, splits, streams, all_keys, gen, hyper, stride,
     models = {}
     min_time = max(0.3, args.min_time / 3)
     stage = {}
+    only = os.environ.get("DFH_EMUL_MODELS")   # e.g. "off": one wire model only (a kernel trace of just that case)
     for name, gbps, lat in WIRE_MODELS:
+        if only and name not in only.split(","):
+            continue
         comm.wire(gbps, lat)
         for _ in range(8):
             step(done)
