@@ -537,6 +537,38 @@ def test_fused_step_vs_oracle(capi, ctx, oracle, V_dim, mode):
     assert (n_with_v > 0) == (V_dim > 0)
 
 
+def test_batch_objects_out_of_one_allocation(capi, ctx, oracle):
+    """dfh_batch_create_many: n batch objects carved from ONE device allocation (the worker loop's dozen: a job's start-up) behave
+    like n objects of their own — the same step on each gives bit-identical logits — and the allocation survives until the LAST
+    of them is destroyed, whatever the order"""
+    rng = np.random.default_rng(31)
+    b = random_batch(rng, 200, 3000, 20, binary=False)
+    kw = dict(l1=0.01, l2=0.0, lr=0.1, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=1)
+    nnz = int(b["offset"][-1])
+    many = capi.create_batches(ctx, 5, 200, nnz)
+    own = capi.Batch(ctx, 200, nnz)
+    preds = []
+    for bt in many + [own]:
+        tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_HASH, **kw)
+        for _ in range(2):
+            bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+            bt.localize()
+            bt.sgd_step(tb, is_train=True, push_cnt=True)
+        preds.append(bt.pred().copy())
+        tb.close()
+    assert all(np.array_equal(p, preds[-1]) for p in preds)
+    for i in (3, 0, 4):          # out of order; the survivors keep working on the shared allocation
+        many[i].close()
+    tb = capi.Table(ctx, 1 << 14, V_dim=8, init_mode=capi.INIT_HASH, **kw)
+    for bt in (many[1], many[2]):
+        bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+        bt.localize()
+        bt.sgd_step(tb, is_train=False)
+        assert np.all(np.isfinite(bt.pred()))
+    for o in (many[1], many[2], own, tb):
+        o.close()
+
+
 def test_fused_steps_c5_shape(capi, ctx, oracle):
     """BASELINE.json's C5 shape on one rank: V_dim = 128, the reference's default l1 = 1 and V_threshold = 10
     (sgd_param.h:95-105), Criteo-shaped rows, feature counts pushed in every step (epoch 0): three minibatches, twice —

@@ -207,6 +207,8 @@ def _worker(rank, world, port, out_dir, balanced, prefetch, mode="sync"):
     if mode == "overlap":
         sh.set_exchange("overlap")   # two minibatches in flight: needs the next one announced (prefetch)
         sh.set_timing(True)
+    if balanced:   # exchange buffers up front (dfh_shard_reserve: no re-allocation inside a step); the other cases let them grow
+        sh.reserve(ROWS * 30, 2 * ROWS * 30 * world)
     batches = make_batches(rank)
     max_nnz = max(int(b["offset"][-1]) for b in batches)
     bts = [capi.Batch(ctx, ROWS, max_nnz) for _ in range(2)]
