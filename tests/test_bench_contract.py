@@ -96,3 +96,37 @@ def test_blended_key_ranges():
     assert max(out["ids"]["rows"]) < 0.14 and max(out["data"]["traffic"]) < 0.14      # each balances what it is named after
     assert max(out["ids"]["traffic"]) > 0.18 and max(out["data"]["rows"]) > 0.18      # ... and not the other
     assert max(out["blend"]["rows"]) < max(out["data"]["rows"]) and max(out["blend"]["traffic"]) < max(out["ids"]["traffic"])
+
+
+def test_committed_projection_line_says_what_it_is():
+    """bench.py --emulate-world: a projection must never read like a measurement of N GPUs — it is marked, says
+    which ranks were emulated on how many GPUs, carries all three wire models with their assumptions, and per rank the
+    stage times, the bytes per GPU-step and the key counts the projection rests on"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_emul_c4_w8*.json")))
+    assert paths
+    d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    assert d["projection"] is True and d["n_gpus"] == 1 and d["emulated_world"] == 8 and d["vs_baseline"] is None
+    assert "PROJECTED" in d["metric"] and "NOT a measurement" in d["value_note"]
+    assert set(d["projected_examples_per_sec"]) <= {"off", "peak", "achievable"} and d["projected_examples_per_sec"]
+    assert d["wire_models"]["peak"]["link_gbps_per_direction"] == 76.8 and "assumed" in d["wire_model_note"]
+    for r in d["ranks"]:
+        assert r["keys_in_per_batch"] > 0 and r["remote_keys_out_per_batch"] > 0 and r["owned_keys"] > 0
+        assert set(r["bytes_per_gpu_step"]) == {"K_out", "K_in", "RW_out", "RW_in", "G_out", "G_in"}
+        for m in r["models"].values():
+            assert m["ms_per_step"] > 0 and m["bytes_sent_per_step"] > 0 and m["bytes_recv_per_step"] > 0
+    assert d["value"] == d["projected_examples_per_sec"][[m for m in ("achievable", "peak", "off") if m in d["projected_examples_per_sec"]][0]] \
+        or d["value"] in d["projected_examples_per_sec"].values()
+
+
+def test_committed_default_line_carries_the_request_ceiling():
+    """round 5: `roofline_requests` (the step against the chip's rate for random memory-side requests) and the two new
+    `secondary` entries (first epoch on an empty table; the reference's quick-start shape with ITS CPU baseline)"""
+    d = json.loads(open(newest("r0[5-9]*_bench_c3.json", "r05z_bench_c3.json")).read().strip().splitlines()[-1])
+    q = d["roofline_requests"]
+    assert q["per_step"] > 3e6 and 0.3 < q["frac"] < 1.0 and abs(q["frac"] - q["per_s"] / q["ceiling_per_s"]) < 1e-9
+    assert q["per_step_source"].startswith("profiles/") and q["ceiling_source"].startswith("profiles/")
+    sec = d["secondary"]
+    assert sec["c3-cold"]["config"]["prefilled"] is False and sec["c3-cold"]["steps"] == 256 and sec["c3-cold"]["warmup"] == 0
+    c2 = sec["c2"]
+    assert c2["cpu_baseline"]["kind"] in ("reference", "port") and c2["value"] > 5 * c2["cpu_baseline"]["value"]
