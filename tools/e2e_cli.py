@@ -35,7 +35,7 @@ open(os.path.join(d, "train.rec"), "wb").write(oi.write_recordio(recs))
 sys.stderr.write("files written in %.1f s\n" % (time.time() - t0))
 common = ["task=train", "learner=sgd", "batch_size=" + os.environ.get("E2E_BATCH_SIZE", "10000"), "max_num_epochs=1",
           "V_dim=" + os.environ.get("E2E_VDIM", "64"), "V_threshold=0", "l1=0", "lr=.01",
-          "V_lr=.01", "V_init=hash", "table_capacity=8388608", "stop_rel_objv=0", "num_jobs_per_epoch=1"]
+          "V_lr=.01", "V_init=hash", "table_capacity=" + os.environ.get("E2E_TABLE_CAPACITY", "8388608"), "stop_rel_objv=0", "num_jobs_per_epoch=1"]
 EXES = os.environ.get("E2E_EXES", "difacto").split(",")   # A/B: several binaries under build/ on the same files
 # A/B of environment switches on the same files: E2E_VARIANTS="name:KEY=VAL+KEY=VAL,name2:" (an entry of EXES may be
 # "binary@name" to run that binary under the named variant's environment)
@@ -54,7 +54,7 @@ def run(path, fmt):
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
     loop_s = None
     for l in r.stderr.splitlines():
-        if "host loop over" in l or "reader: " in l or "batch reader" in l or "start-up:" in l:   # DIFACTO_PROFILE=1
+        if "host loop over" in l or "reader: " in l or "batch reader" in l or "start-up:" in l or "dfh_table:" in l:   # DIFACTO_PROFILE=1
             sys.stderr.write(fmt + " " + exe + ": " + l.split("INFO")[-1].strip() + "\n")
         m = re.search(r"host loop over (\d+) minibatches: reader ([0-9.e+-]+) s, stage \+ localize \+ lookup ([0-9.e+-]+) s.*step ([0-9.e+-]+) s", l)
         if m:   # the worker loop's own clock: process start, HIP initialisation and the table allocation are outside it
