@@ -550,10 +550,12 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
 
 // ---- the sharded worker loop: sgd_learner.cc:129-227 with Store::Pull / Push turned into the exchange of
 // dfh_shard_step.  The ranks step together; a rank whose part of the data is exhausted keeps serving
-// its shard (b = NULL) until nobody has a minibatch left.  Two batch objects: while one minibatch steps,
-// the next is copied in and localized on the preparation stream, and its per-owner key counts travel
-// inside the running step (dfh_shard_prefetch_counts) — the two minibatches the reference's batch
-// tracker keeps in flight (sgd_learner.cc:219-223), without its staleness.
+// its shard (b = NULL) until nobody has a minibatch left.  Four batch objects in rotation: while minibatch t steps,
+// minibatch t+1 — copied in and localized one step EARLIER — has its per-owner key counts (and, overlapped, its keys
+// and rows) exchanged inside the running step (dfh_shard_prefetch_counts), and minibatch t+2 is copied in and localized
+// on the preparation stream: the keys of t+1 are ready when step t starts (round 5: localized only one ahead, the
+// Localizer of t+1 ran beside step t's forward and the exchange waited for it).  The two minibatches the
+// reference's batch tracker keeps in flight (sgd_learner.cc:219-223), without its staleness in sync mode.
 void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress) {
   const bool train = job.type == sgd::Job::kTraining;
   const bool predict = job.type == sgd::Job::kPrediction;
@@ -572,14 +574,16 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
     q.loss = p.loss; q.penalty = p.penalty; q.auc = p.auc; q.nrows = p.nrows;
     progress->Merge(q);
   };
-  for (int q = 2; q < kFusedBatches; ++q) {  // the fused loop's further objects: this loop rotates two
+  constexpr int kSlots = 4;
+  static_assert(kSlots <= kFusedBatches, "the sharded loop's objects are the first of the fused loop's");
+  for (int q = kSlots; q < kFusedBatches; ++q) {  // the fused loop's further objects: this loop rotates four
     if (!batch_[q]) continue;
     drain(batch_[q]);
     dfh_batch_destroy(batch_[q]);
     batch_[q] = nullptr;
   }
-  size_t cap_rows[2] = {0, 0}, cap_nnz[2] = {0, 0};
-  for (int q = 0; q < 2; ++q) {  // objects left by an earlier job keep their size
+  size_t cap_rows[kSlots] = {0}, cap_nnz[kSlots] = {0};
+  for (int q = 0; q < kSlots; ++q) {  // objects left by an earlier job keep their size
     if (batch_[q]) {
       cap_rows[q] = batch_rows_;
       cap_nnz[q] = batch_nnz_;
@@ -607,28 +611,39 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
     return b;
   };
   dfh_batch* cur = prepare(0);
+  dfh_batch* nxt = prepare(1);   // localized a step before it is announced
   int active = 1;
   for (int i = 0; active; ++i) {
-    dfh_batch* nxt = prepare((i + 1) & 1);
+    dfh_batch* ahead = prepare((i + 2) % kSlots);   // (its slot's previous minibatch, i - 2, has been stepped)
     DFH_CALL(dfh_shard_prefetch_counts(ss->shard(), nxt));
     if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step: batch " << (cur ? "yes" : "none");
     DFH_CALL(dfh_shard_step(ss->shard(), cur, train ? 1 : 0, push_cnt ? 1 : 0, &active));
     if (predict && cur) WritePredictions(cur);
     if (getenv("DIFACTO_TRACE")) LOG(INFO) << "shard step done: active " << active;
     cur = nxt;
+    nxt = ahead;
   }
-  for (int q = 0; q < 2; ++q) {
+  size_t max_rows = 0, max_nnz = 0;
+  for (int q = 0; q < kSlots; ++q) {
+    max_rows = std::max(max_rows, cap_rows[q]);
+    max_nnz = std::max(max_nnz, cap_nnz[q]);
+  }
+  for (int q = 0; q < kSlots; ++q) {
     if (!batch_[q]) continue;
     drain(batch_[q]);
-    // the fused loop sizes both objects alike: keep that invariant for whichever job runs next
-    if (cap_rows[q] != std::max(cap_rows[0], cap_rows[1]) || cap_nnz[q] != std::max(cap_nnz[0], cap_nnz[1])) {
+    // the fused loop sizes its objects alike: keep that invariant for whichever job runs next
+    if (cap_rows[q] != max_rows || cap_nnz[q] != max_nnz) {
       dfh_batch_destroy(batch_[q]);
       batch_[q] = nullptr;
     }
   }
-  batch_rows_ = std::max(cap_rows[0], cap_rows[1]);
-  batch_nnz_ = std::max(cap_nnz[0], cap_nnz[1]);
-  if (!batch_[0] && batch_[1]) std::swap(batch_[0], batch_[1]);
+  batch_rows_ = max_rows;
+  batch_nnz_ = max_nnz;
+  for (int q = 0, w = 0; q < kSlots; ++q)   // the survivors to the front
+    if (batch_[q]) {
+      if (q != w) std::swap(batch_[q], batch_[w]);
+      ++w;
+    }
   uint64_t nkeys;
   DFH_CALL(dfh_table_size(GetUpdater()->table(), &nkeys));  // surfaces a full shard as an error
 }
