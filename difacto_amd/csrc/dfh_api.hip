@@ -303,6 +303,10 @@ int check_table_err(dfh_table* t) {
     set_error("model table is full (capacity_rows exceeded)");
     return DFH_ERR_CAPACITY;
   }
+  if (e & 2u) {
+    set_error("a source's key list repeats a key (dfh_shard_resolve_multi: the lists must be unique, as a Localizer emits them)");
+    return DFH_ERR_ARG;
+  }
   if (e & 4u) {
     set_error("gradient carries V for a key whose V is not allocated (reference CHECK(e.V != nullptr))");
     return DFH_ERR_ARG;

@@ -48,7 +48,7 @@ struct TableView {
   RowHdr* hdr;
   float* va;
   uint32_t* nrows;     // device counter of allocated rows
-  uint32_t* err;       // device error word (bit0: capacity, bit2: gradient with V for a row without V, bit3: key-index wait gave up)
+  uint32_t* err;       // device error word (bit0: capacity, bit1: a repeated key inside one source's list (k_resolve_multi), bit2: gradient with V for a row without V, bit3: key-index wait gave up)
   uint32_t* rng_state; // REFRAND: the mutated rand_r seed (sgd_updater.cc:144)
   uint32_t capacity;
   int k;   // V_dim

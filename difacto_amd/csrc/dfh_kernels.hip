@@ -1582,7 +1582,10 @@ __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, 
     uint32_t old = atomicCAS(word, 0u, (e + 1) << 5);
     if (old != 0u) {  // the key has its worker: take a place among its extras
       old = atomicAdd(word, 1u);
-      extra[(size_t)((old >> 5) - 1u) * XS + (old & 31u)] = e;
+      // (a source's list is unique, so a key has at most nsrc - 1 <= XS extras; a list with a repeated key is a caller's
+      // error: flagged like a duplicate key instead of writing past the worker's extras)
+      if ((old & 31u) < XS) extra[(size_t)((old >> 5) - 1u) * XS + (old & 31u)] = e;
+      else atomicOr(t.err, 2u);
     }
     rowid[e] = r | (old == 0u ? ROW_WORKER : 0u);
   }

@@ -911,6 +911,25 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         o.close()
 
 
+def test_resolve_multi_refuses_a_repeated_key_inside_one_source(capi, ctx):
+    """the owner-side election (k_resolve_multi) gives a key's worker room for one entry per OTHER source: a source list that
+    repeats a key is a caller's error and is reported (DFH_ERR_ARG through dfh_table_check), never written past the extras"""
+    import torch
+    dev = torch.device("cuda", 0)
+    kw = dict(l1=0.0, l2=0.0, lr=0.1, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=1)
+    tb = capi.Table(ctx, 1 << 12, V_dim=4, **kw)
+    keys = np.array([5, 9, 9, 9, 9, 9, 9, 12], np.uint64)   # ONE source, key 9 six times: more extras than its worker has room for
+    d_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+    rowid = torch.empty(capi.multi_words(len(keys), 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    tb.shard_resolve_multi(d_keys, np.array([0, len(keys)]), rowid)
+    ctx.sync()
+    with pytest.raises(capi.DfhError) as ei:
+        tb.check()
+    assert "repeats a key" in str(ei.value)
+    tb.close()
+
+
 @pytest.mark.parametrize("streams", [0, 1])
 def test_device_row_gather_matches_host_load(capi, oracle, streams):
     """the device feed (dfh_rowbuf_load_host + dfh_batch_gather_rows, or dfh_batch_prepare_rows = gather + Localizer + lookup
