@@ -505,13 +505,13 @@ def _run_fused_vs_oracle(capi, ctx, oracle, V_dim, mode, batches, epochs, kw, de
             # EvaluatePenalty (sgd_learner.cc:249-273) adds U*(1+V_dim) small terms into one fp32
             # scalar; at 9.5 M terms whole addends fall below half an ulp of the running sum and the
             # reference comes out 1 % low.  The device keeps fp64 partials: check it against the
-            # exact value, and the reference within its own rounding (n terms: ~sqrt(n) eps relative, the drift of a
-            # running fp32 sum of positive terms ~n eps / 2 at worst).
+            # exact value, and the reference within its own rounding (the drift of a running fp32 sum of n positive terms:
+            # n eps / 2 at worst, 1 % observed at 9.5 M terms; capped at 5 %).
             exact = kw.get("l1", 0.0) * np.abs(w64).sum() + 0.5 * kw.get("l2", 0.0) * (w64 ** 2).sum() \
                 + 0.5 * kw.get("V_l2", 0.0) * (V64 ** 2).sum()
             assert prog_g.penalty == pytest.approx(exact, rel=2e-5, abs=1e-6)
             nterms = loc["U"] * (1 + V_dim)
-            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=max(1e-4, 0.5 * nterms * 2.0 ** -24), abs=1e-6)
+            assert prog_g.penalty == pytest.approx(prog_o.penalty, rel=max(1e-4, min(0.05, 0.5 * nterms * 2.0 ** -24)), abs=1e-6)
             assert prog_g.nrows == prog_o.nrows
     # final model state, key by key: one step apart from identical state, so the last step's tolerance class
     allkeys = np.unique(np.concatenate([l["feaids"] for l in locs]))
