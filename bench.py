@@ -603,7 +603,8 @@ def main():
                    "distinct_batches": nd,
                    "distinct_batches_note": "SURVEY 8d asks for a stream of 1 000; 256 x 390 000 ids is a 2 GB working set against a 256 MB "
                                             "memory-side cache (a batch recurs every ~30 ms of device time) and 64 / 256 distinct batches "
-                                            "measured the same rate (85.55 / 85.54 M, round 4); --distinct 1000 adds ~40 s of host-side generation",
+                                            "measured the same rate (85.55 / 85.54 M, round 4) and so do 256 / 1 000 (84.43 / 84.41 M, profiles/r05w_*); "
+                                            "--distinct 1000 adds ~28 s of host-side generation",
                    "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
                    "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
