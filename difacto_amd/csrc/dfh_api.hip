@@ -2472,7 +2472,13 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   } else {
     // the small size class (<= 1024 buckets, up to 700 pairs each) as long as it holds the minibatch, then the large one
     // (<= 4096 buckets: 2.9 M pairs); beyond that the library sort
-    const size_t P_want = (N + LOC_AVG_BUCKET - 1) / LOC_AVG_BUCKET;
+    // small minibatches (the reference's batch-of-100 quick start) are a chain of launch latencies, not of bandwidth: half-size
+    // buckets are one 64-run per wave and one merge round less in k_loc_sort (round 5, profiles/r05v_*)
+#ifndef DFH_LOC_SMALL_AVG
+#define DFH_LOC_SMALL_AVG 192
+#endif
+    const size_t avg_bucket = N <= 65536u ? (size_t)DFH_LOC_SMALL_AVG : (size_t)LOC_AVG_BUCKET;
+    const size_t P_want = (N + avg_bucket - 1) / avg_bucket;
     if (P_want <= (size_t)LOC_MAX_BUCKETS) P = (int)std::max<size_t>(1, P_want);
     else if (N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
     else if (P_want <= (size_t)LOC_BIG_BUCKETS) P = (int)P_want;

@@ -399,46 +399,81 @@ __device__ __forceinline__ bool loc_sort_bucket(const LocView& v, uint32_t beg, 
   uint64_t* sk = bk;  // where the sorted bucket ends up (LDS path)
   uint32_t* sp = bp;
   if (in_lds) {
-    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
-      ak[t] = gk[t];
-      ap[t] = gp[t];
-    }
-    __syncthreads();
-    // runs of 64: rank every element inside its 64-chunk (LDS broadcast reads, no barriers)
+    // runs of 64: a wave ranks its 64 pairs against each other in registers — lane j's pair is broadcast with v_readlane, 64
+    // unrolled compares, no LDS round trip per compare (round 5: the LDS form waited out one ds_read latency per compare,
+    // 3.5 us per run) — and writes the sorted run to LDS
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += LOC_SORT_THREADS) {
+    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < n; c0 += LOC_SORT_THREADS) {  // wave-uniform: every lane is active below
       const uint32_t idx = c0 + lane;
       const bool valid = idx < n;
-      const uint64_t mk = valid ? ak[idx] : ~0ULL;
-      const uint32_t mp = valid ? ap[idx] : ~0u;
-      const uint32_t lim = min(64u, n - c0);
+      const uint64_t mk = valid ? gk[idx] : ~0ULL;  // the padding pair is less than nothing
+      const uint32_t mp = valid ? gp[idx] : ~0u;
+      const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < lim; ++j) rank += comp_less(ak[c0 + j], ap[c0 + j], mk, mp) ? 1u : 0u;
+#pragma unroll 8  // (fully unrolled, the compiler reads all 192 words first and spills them)
+      for (int j = 0; j < 64; ++j) {
+        const uint64_t ok = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(khi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(klo, j);
+        const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)mp, j);
+        rank += comp_less(ok, op, mk, mp) ? 1u : 0u;
+      }
       if (valid) {
         bk[c0 + rank] = mk;
         bp[c0 + rank] = mp;
       }
     }
     __syncthreads();
-    // merge rounds: element's slot = its offset in its run + (# smaller elements in the sibling run)
+    // merge rounds: element's slot = its offset in its run + (# smaller elements in the sibling run).  A thread carries its
+    // (up to) LOC_LDS_CAP / LOC_SORT_THREADS elements through the search together: one LDS latency per step, not one per
+    // element and step.  The count is built from descending powers of two (the sibling run has at most L elements).
+    constexpr int E = LOC_LDS_CAP / LOC_SORT_THREADS;
+    static_assert(E * LOC_SORT_THREADS == LOC_LDS_CAP && LOC_SORT_THREADS % 64 == 0, "a thread carries E elements of a full bucket");
     uint64_t* dk = ak;
     uint32_t* dp = ap;
-    for (uint32_t L = 64; L < n; L <<= 1) {
-      for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
-        const uint64_t mk = sk[idx];
-        const uint32_t mp = sp[idx];
-        const uint32_t r = idx / L;
-        const uint32_t pair_base = (r & ~1u) * L;
-        const uint32_t sib = (r ^ 1u) * L;
-        uint32_t lo = min(sib, n), hi = min(sib + L, n);
-        const uint32_t sib_beg = lo;
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (comp_less(sk[mid], sp[mid], mk, mp)) lo = mid + 1; else hi = mid;
+    uint32_t sh = 6;
+    for (uint32_t L = 64; L < n; L <<= 1, ++sh) {
+      uint64_t mk[E];
+      uint32_t mp[E], cnt[E], sb[E], len[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t idx = threadIdx.x + e * LOC_SORT_THREADS;
+        const bool valid = idx < n;
+        len[e] = 0;
+        cnt[e] = 0;
+        if (e * LOC_SORT_THREADS >= n) continue;  // block-uniform: a bucket of n <= 256 e costs e elements' work
+        mk[e] = valid ? sk[idx] : 0ULL;
+        mp[e] = valid ? sp[idx] : 0u;
+        const uint32_t sib = ((idx >> sh) ^ 1u) << sh;
+        sb[e] = min(sib, n);
+        len[e] = valid ? min(sib + L, n) - sb[e] : 0u;
+        cnt[e] = 0;
+      }
+      for (uint32_t step = L; step; step >>= 1) {
+        uint64_t ok[E];
+        uint32_t op[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (e * LOC_SORT_THREADS >= n) continue;
+          const uint32_t t = cnt[e] + step;
+          const uint32_t at = t <= len[e] ? sb[e] + t - 1u : 0u;  // slot 0 when there is nothing to test: always readable
+          ok[e] = sk[at];
+          op[e] = sp[at];
         }
-        const uint32_t dst = pair_base + (idx - r * L) + (lo - sib_beg);
-        dk[dst] = mk;
-        dp[dst] = mp;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (e * LOC_SORT_THREADS >= n) continue;
+          const uint32_t t = cnt[e] + step;
+          if (t <= len[e] && comp_less(ok[e], op[e], mk[e], mp[e])) cnt[e] = t;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t idx = threadIdx.x + e * LOC_SORT_THREADS;
+        if (idx < n) {
+          const uint32_t r = idx >> sh;
+          const uint32_t dst = ((r & ~1u) << sh) + (idx - (r << sh)) + cnt[e];
+          dk[dst] = mk[e];
+          dp[dst] = mp[e];
+        }
       }
       __syncthreads();
       uint64_t* tk = sk; sk = dk; dk = tk;
