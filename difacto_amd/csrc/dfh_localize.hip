@@ -18,8 +18,8 @@
 //                  pair back from the tag and the CSR offsets instead of gathering it from a 1.5 MB array (LocView::tb).
 //                  A bucket's area is filled XCD group by XCD group (LocView::btotal), so that the short runs of the
 //                  tiles running on one XCD merge into whole lines in that XCD's L2.
-//   k_loc_sort     one block per bucket: merge sort in LDS by (key, pos) (64-wide runs by ranking,
-//                  then log2(n/64) rounds of merge-by-binary-search); bucket summary
+//   k_loc_sort     one block per bucket: merge sort by (key, pos) (64-wide runs ranked in registers with v_readlane
+//                  broadcasts, then log2(n/64) rounds of merge-by-binary-search in LDS); bucket summary
 //   k_loc_emit     one block per bucket: unique ids before the bucket from the summaries, then the
 //                  Localizer's outputs (dictionary, segment starts, compact index per nnz), the
 //                  key-ordered (row, value) view for the backward pass, the long-segment lists of
