@@ -76,6 +76,14 @@ def parse_args():
     ap.add_argument("--prep-streams", type=int, default=1,
                     help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
                          "keeps 2 in flight)")
+    ap.add_argument("--single-queue", dest="single_queue", action="store_true", default=False,
+                    help="the single-queue step (csrc/dfh_riders.hip): no preparation stream; the Localizer's stages of the next "
+                         "minibatches ride as extra blocks of this step's own three launches")
+    ap.add_argument("--two-queues", dest="single_queue", action="store_false",
+                    help="rounds 2-5: Localizer + probe of minibatch t+1 on a low-priority preparation stream")
+    ap.add_argument("--ahead", type=int, default=0,
+                    help="single-queue step: minibatches prepared (noted) ahead of the one training (default 2: count(t+2) rides "
+                         "in the update launch of step t)")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
     ap.add_argument("--fused-probe", action="store_true",
@@ -437,13 +445,17 @@ def main():
                     len(hb["label"]), int(hb["offset"][-1])))
     # depth+1 batch objects: batches t+1 .. t+depth are localized on the preparation streams while
     # batch t trains on the main stream (updates are still applied strictly in batch order)
-    depth = 0 if args.no_pipeline else max(1, min(args.prep_streams, 4))
+    sq = args.single_queue and not args.no_pipeline
+    depth = 0 if (args.no_pipeline or sq) else max(1, min(args.prep_streams, 4))
     for kv in args.ctx_option:
         name, val = kv.split("=", 1)
         ctx.set_option(name, int(val))
     ctx.set_pipeline(depth)
-    ahead = max(depth, 1)
+    if sq:
+        ctx.set_option("single_queue", 1)
+    ahead = (args.ahead or 2) if sq else max(depth, 1)
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
+    # (single queue: everything is ordered by the one stream, ahead + 1 objects rotate)
     bts = [capi.Batch(ctx, B, max_nnz) for _ in range(ahead + (2 if depth else 1))]
     bt = bts[0]
     if not args.no_auc:
@@ -605,7 +617,8 @@ def main():
                                             "memory-side cache (a batch recurs every ~30 ms of device time) and 64 / 256 distinct batches "
                                             "measured the same rate (85.55 / 85.54 M, round 4) and so do 256 / 1 000 (84.43 / 84.41 M, profiles/r05w_*); "
                                             "--distinct 1000 adds ~28 s of host-side generation",
-                   "pipelined_prep": not args.no_pipeline, "prep_streams": depth,
+                   "pipelined_prep": not args.no_pipeline, "prep_streams": depth, "single_queue": bool(sq),
+                   "minibatches_prepared_ahead": ahead,
                    "feature_counts_pushed_every_step": not args.later_epoch},
         "repetitions": len(reps), "timed_region_s_total": t_all,
         "ms_per_step_min": float(min(reps)) / args.steps * 1e3, "ms_per_step_max": float(max(reps)) / args.steps * 1e3,

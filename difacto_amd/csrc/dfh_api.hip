@@ -13,6 +13,7 @@
 #include "dfh_kernels.hip"
 #include "dfh_localize.hip"
 #include "dfh_update.hip"
+#include "dfh_riders.hip"
 
 using namespace dfh;
 
@@ -56,6 +57,16 @@ struct dfh_ctx {
   // consumer of these events is a stream of this device
   int event_flags = 1;
   int prep_priority = -1;      // preparation streams: -1 lowest, 0 default, 1 highest stream priority
+  // The single-queue step (dfh_riders.hip): no preparation stream.  dfh_localize on a batch object only NOTES the work
+  // (pend, in call order); the stages of the sample sort then ride, one per launch and minibatch, as extra blocks of the
+  // launches later steps make on the main stream — stage s in the launch of kind rider_slot[s] (0 = the step's lookup pass,
+  // 1 = forward, 2 = update); rider_alone[s]: as a launch of its own just before that launch instead (A/B).  A consumer that
+  // needs a minibatch before its stages have all found a carrier runs the rest as plain launches (flush_pending).
+  int single_queue = 0;
+  int rider_slot[4] = {2, 0, 1, 2};     // count, scatter, sort, emit
+  int rider_alone[4] = {0, 0, 0, 0};
+  int rider_period[3] = {3, 3, 4};      // L, F, U: one group of 8 rider blocks every n groups of 8 blocks (1: riders first)
+  std::vector<dfh_batch*> pend;
   // The library's code object (8 MB, a few hundred kernel instantiations) is loaded by the runtime on the FIRST launch of any
   // of its kernels: 30-40 ms that used to fall into a job's first minibatch (build/difacto: the first dfh_batch_prepare_rows
   // took 32-42 ms, profiles/r05e_e2e_startup.txt).  A helper thread makes that first launch while the caller goes on to
@@ -191,9 +202,18 @@ struct dfh_batch {
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
   bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
+  // single-queue step: the sample sort of the loaded minibatch as noted by dfh_localize (arguments of its four stages) and the
+  // first stage that has not been queued yet (RID_STAGES: nothing pending)
+  LocView loc_v{};
+  EmitOut loc_o{};
+  uint32_t loc_gsort = 0;
+  bool loc_big = false;
+  int pend_stage = RID_STAGES;
 };
 
 namespace {
+int flush_pending(dfh_batch* b);  // single-queue step: queue what is left of the batch's noted Localizer as plain launches
+void pend_remove(dfh_ctx* c, dfh_batch* b);
 // stream of the batch's current preparation phase
 inline hipStream_t prep_of(const dfh_batch* b) {
   const dfh_ctx* c = b->ctx;
@@ -202,6 +222,9 @@ inline hipStream_t prep_of(const dfh_batch* b) {
 // a new phase (a load / attach call) takes the next preparation stream
 void phase_begin(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
+  // a new minibatch is loaded into an object whose noted Localizer has not been queued completely: finish it first (its
+  // stages leave per-object state behind — bucket totals reset by the sort, the next call's splitters written by emit)
+  if (b->pend_stage < RID_STAGES) (void)flush_pending(b);
   hipStream_t next = c->pipeline ? c->preps[c->next_prep++ % c->nprep] : nullptr;
   if (next && b->prep && next != b->prep && b->ready_pending) {
     // the previous phase's output was never consumed by a step: keep the two phases ordered
@@ -229,6 +252,10 @@ int prep_end(dfh_batch* b) {
 }
 int main_begin(dfh_batch* b) {
   dfh_ctx* c = b->ctx;
+  if (b->pend_stage < RID_STAGES) {  // consumed before every stage found a carrier launch (the first steps of a loop)
+    int rc = flush_pending(b);
+    if (rc) return rc;
+  }
   if (b->ready_pending) {
     DFH_HIP(hipStreamWaitEvent(c->stream, b->ev_ready, 0));
     b->ready_pending = false;
@@ -545,7 +572,11 @@ int dispatch_L(int kp, F&& f) {
 constexpr KeyRange kAllKeys{0u, 0xFFFFFFFFu, 0u};
 constexpr size_t kSmallBatchPairs = 16384;  // at or below: no probe ahead on the preparation stream (launch-bound sizes)
 
-int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr, const MixSrc* mix = nullptr) {
+// (forward declared: the rider helpers live next to the Localizer's host code further down)
+void collect_riders(dfh_ctx* c, int slot, bool can_ride, uint32_t main_groups, RiderSet* rs);
+
+int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* uw = nullptr, const MixSrc* mix = nullptr,
+                   bool riders = false) {
   BatchView bv = batch_view(b);
   bv.uw = uw;
   // one wave per example, all resident at once where possible: the kernel is
@@ -565,6 +596,23 @@ int launch_forward(dfh_batch* b, const RowSrc& src, int k, int kp, const uint2* 
   }
   MixSrc mx{nullptr, 0};
   if (mix) mx = *mix;
+  // single-queue step: the stages of later minibatches' Localizer that belong into a forward launch ride in this one
+  RiderSet rs;
+  rs.n = 0;
+  if (riders && c->single_queue) collect_riders(c, 1, !mix && fwd_depth == 5, ((uint32_t)grid + 7u) / 8u, &rs);
+  if (rs.n) {
+    const dim3 rgrid((((unsigned)grid + 7u) / 8u + rs.ngroups) * 8u);
+    const size_t shm = std::max<size_t>(rider_smem(rs), 4 * sizeof(double));
+    int rcr = dispatch_L(kp, [&](auto Lc) {
+      constexpr int L = decltype(Lc)::value;
+      if (ea && eb) hipExtLaunchKernelGGL((k_forward_riders<L, 5>), rgrid, dim3(256), shm, s, ea, eb, 0, bv, src, k, kp, (uint32_t)grid, rs);
+      else hipLaunchKernelGGL((k_forward_riders<L, 5>), rgrid, dim3(256), shm, s, bv, src, k, kp, (uint32_t)grid, rs);
+    });
+    if (ea && eb) c->spans.push_back({DFH_K_FORWARD, ea, eb});
+    if (rcr) return rcr;
+    DFH_HIP(hipGetLastError());
+    return DFH_OK;
+  }
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int L = decltype(Lc)::value;
 #define DFH_FWD1(D, M)                                                                                                       \
@@ -670,7 +718,8 @@ UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* nee
 // rrows / grows (sharded store): the keys of other ranks (kRemoteRow in uw) read the rows their owners sent and leave
 // gradient rows, in the same launch that updates this rank's own keys in place (k_update_fused<..., MIXED>)
 int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* need, const uint2* uw, KeyRange rg, bool add_cnt,
-                        bool with_auc = false, const float* rrows = nullptr, float* grows = nullptr, size_t rstride = 0) {
+                        bool with_auc = false, const float* rrows = nullptr, float* grows = nullptr, size_t rstride = 0,
+                        bool riders = false) {
   dfh_ctx* c = b->ctx;
   hipStream_t s = c->stream;
   const int L = lanes_for(kp);
@@ -705,6 +754,30 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
     eb = TimeScope::get(c);
   }
   const dim3 grid((unsigned)(a.nb_auc + a.nb_hot + a.nb_mid + a.nb_few + nb_single)), block(UPD_THREADS);
+  // single-queue step: the stages of later minibatches' Localizer that belong into an update launch ride in this one
+  RiderSet rs;
+  rs.n = 0;
+  if (riders && c->single_queue) collect_riders(c, 2, !mixed && UPD_THREADS == RID_THREADS, (grid.x + 7u) / 8u, &rs);
+  if (rs.n) {
+    const dim3 rgrid(((grid.x + 7u) / 8u + rs.ngroups) * 8u);
+    const size_t shm = std::max<size_t>(rider_smem(rs), UPD_SMEM);
+    int rcr = dispatch_L(kp, [&](auto Lc) {
+      constexpr int LL = decltype(Lc)::value;
+#define DFH_UPDR(EXACT, HV)                                                                                                 \
+  if (ea && eb) hipExtLaunchKernelGGL((k_update_fused_riders<LL, EXACT, HV>), rgrid, block, shm, s, ea, eb, 0, a, grid.x, rs); \
+  else hipLaunchKernelGGL((k_update_fused_riders<LL, EXACT, HV>), rgrid, block, shm, s, a, grid.x, rs)
+      if (kp == 4 * LL) {
+        if (b->has_value) { DFH_UPDR(true, true); } else { DFH_UPDR(true, false); }
+      } else {
+        if (b->has_value) { DFH_UPDR(false, true); } else { DFH_UPDR(false, false); }
+      }
+#undef DFH_UPDR
+    });
+    if (ea && eb) c->spans.push_back({DFH_K_BACKWARD, ea, eb});
+    if (rcr) return rcr;
+    DFH_HIP(hipGetLastError());
+    return DFH_OK;
+  }
   int rc = dispatch_L(kp, [&](auto Lc) {
     constexpr int LL = decltype(Lc)::value;
 #define DFH_UPD(EXACT, HV)                                                                                         \
@@ -730,14 +803,19 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
 
 template <bool FUSED>
 int launch_backward(dfh_batch* b, const RowSrc& src, const TableView& tv, float* grads, size_t gstride, int k, int kp,
-                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr, bool add_cnt = false, bool* auc_rides = nullptr) {
+                    uint32_t* need, KeyRange rg = kAllKeys, const uint2* uw = nullptr, bool add_cnt = false, bool* auc_rides = nullptr,
+                    bool riders = false) {
   if (FUSED && src.urow && uw && b->ctx->upd_kernel) {
     // auc_rides: in: the caller wants the minibatch's AUC; out: this launch computed it
     const bool with_auc = auc_rides && *auc_rides && b->nrows <= AUC_PAIRS_MAX_N && UPD_THREADS == 256;
     if (auc_rides) *auc_rides = with_auc;
-    return launch_update_fused(b, tv, k, kp, need, uw, rg, add_cnt, with_auc);
+    return launch_update_fused(b, tv, k, kp, need, uw, rg, add_cnt, with_auc, nullptr, nullptr, 0, riders);
   }
   if (auc_rides) *auc_rides = false;
+  if (riders) {  // no rider form of k_backward_all: the stages due in an update launch run alone
+    RiderSet none;
+    collect_riders(b->ctx, 2, false, 0, &none);
+  }
   BatchView bv = batch_view(b);
   hipStream_t s = b->ctx->stream;
   const int L = lanes_for(kp);
@@ -893,6 +971,9 @@ int dfh_ctx_sync(dfh_ctx* c) {
 int dfh_ctx_set_pipeline(dfh_ctx* c, int enable) {
   DFH_ARG(c, "ctx is NULL");
   DFH_ARG(enable >= 0 && enable <= 4, "dfh_ctx_set_pipeline: 0 (off) .. 4 preparation streams");
+  if (c->single_queue && enable) {  // the single-queue step has no preparation stream; minibatches are still prepared ahead
+    return DFH_OK;
+  }
   int rc = sync_all(c);
   if (rc) return rc;
   while ((int)c->preps.size() < enable) {
@@ -945,6 +1026,31 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "event_flags") {
     DFH_ARG(value == 0 || value == 1, "event_flags must be 0 (default events) or 1 (no system-scope fence); set before batches are created");
     c->event_flags = value;
+  } else if (n == "single_queue") {
+    DFH_ARG(value == 0 || value == 1, "single_queue must be 0 (preparation streams) or 1 (the Localizer's stages ride in the step's launches)");
+    if (value != c->single_queue) {
+      for (dfh_batch* p : std::vector<dfh_batch*>(c->pend)) {
+        int rcf = flush_pending(p);
+        if (rcf) return rcf;
+      }
+      int rcs = sync_all(c);
+      if (rcs) return rcs;
+      if (value) {  // one queue: no preparation streams
+        c->nprep = 0;
+        c->next_prep = 0;
+        c->pipeline = false;
+      }
+      c->single_queue = value;
+    }
+  } else if (n == "rider_slot_count" || n == "rider_slot_scatter" || n == "rider_slot_sort" || n == "rider_slot_emit") {
+    // which launch of a step carries the stage: 0 lookup, 1 forward, 2 update; + 4: as a launch of its own just before it
+    DFH_ARG(value >= 0 && value <= 6 && (value & 3) <= 2, "rider_slot_*: 0 lookup, 1 forward, 2 update (+ 4: alone, before that launch)");
+    const int st = n == "rider_slot_count" ? 0 : n == "rider_slot_scatter" ? 1 : n == "rider_slot_sort" ? 2 : 3;
+    c->rider_slot[st] = value & 3;
+    c->rider_alone[st] = (value >> 2) & 1;
+  } else if (n == "rider_period_lookup" || n == "rider_period_forward" || n == "rider_period_update") {
+    DFH_ARG(value >= 1 && value <= 4096, "rider_period_*: one group of 8 rider blocks every n groups (1: riders first)");
+    c->rider_period[n == "rider_period_lookup" ? 0 : n == "rider_period_forward" ? 1 : 2] = value;
   } else if (n == "prep_priority") {
     DFH_ARG(value >= -1 && value <= 1, "prep_priority must be -1 (lowest), 0 (default) or 1 (highest)");
     DFH_ARG(c->preps.empty(), "prep_priority must be set before dfh_ctx_set_pipeline creates the streams");
@@ -2020,6 +2126,7 @@ int dfh_batch_destroy(dfh_batch* b) {
             (unsigned long long)b->n_prof, b->t_prof[0], b->t_prof[1], b->t_prof[2], b->t_prof[3], b->t_prof[4], b->t_prof[5]);
   if (!b) return DFH_OK;
   hipSetDevice(b->ctx->device);
+  pend_remove(b->ctx, b);  // stages noted but never queued die with the object
   sync_all(b->ctx);
   if (b->ev_ready) hipEventDestroy(b->ev_ready);
   if (b->ev_free) hipEventDestroy(b->ev_free);
@@ -2436,6 +2543,100 @@ int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, cons
 }
 
 namespace {
+// one stage (RiderKind) of the noted sample sort of b's minibatch as a launch of its own on stream s
+void launch_loc_stage(dfh_batch* b, int stage, hipStream_t s, dfh_table* probe = nullptr) {
+  const LocView& v = b->loc_v;
+  switch (stage) {
+    case RID_COUNT:
+      if (b->loc_big) hipLaunchKernelGGL(k_loc_count<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      else hipLaunchKernelGGL(k_loc_count<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      break;
+    case RID_SCATTER:
+      if (b->loc_big) hipLaunchKernelGGL(k_loc_scatter<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      else hipLaunchKernelGGL(k_loc_scatter<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      break;
+    case RID_SORT:
+      hipLaunchKernelGGL(k_loc_sort, dim3(b->loc_gsort), dim3(LOC_SORT_THREADS), 0, s, v);
+      break;
+    default:
+      if (probe) hipLaunchKernelGGL(k_loc_emit<true>, dim3(b->loc_gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->loc_o, probe->v, b->d_urow);
+      else hipLaunchKernelGGL(k_loc_emit<false>, dim3(b->loc_gsort), dim3(LOC_EMIT_THREADS), 0, s, v, b->loc_o, TableView{}, (uint32_t*)nullptr);
+      break;
+  }
+}
+
+void pend_remove(dfh_ctx* c, dfh_batch* b) {
+  auto it = std::find(c->pend.begin(), c->pend.end(), b);
+  if (it != c->pend.end()) c->pend.erase(it);
+}
+
+int flush_pending(dfh_batch* b) {
+  dfh_ctx* c = b->ctx;
+  if (b->pend_stage >= RID_STAGES) return DFH_OK;
+  {
+    TimeScope ts(c, DFH_K_LOCALIZE);
+    for (int st = b->pend_stage; st < RID_STAGES; ++st) launch_loc_stage(b, st, c->stream);
+  }
+  b->pend_stage = RID_STAGES;
+  pend_remove(c, b);
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+// the riders of the next launch of kind `slot` (0 lookup, 1 forward, 2 update): for every minibatch with noted stages, in the
+// order they were noted, its next stage if that stage belongs into this kind of launch.  A stage configured to run alone, or
+// one too many for the launch (can_ride false: the launch has no rider form), is queued here as a launch of its own — just
+// before the carrier — and the minibatch's following stage is considered at once.  main_groups: the carrier's own blocks / 8.
+void collect_riders(dfh_ctx* c, int slot, bool can_ride, uint32_t main_groups, RiderSet* rs) {
+  rs->n = 0;
+  rs->ngroups = 0;
+  rs->period = 1;
+  rs->first[0] = 0;
+  if (!c->single_queue || c->pend.empty()) return;
+  for (size_t i = 0; i < c->pend.size(); ++i) {
+    dfh_batch* p = c->pend[i];
+    while (p->pend_stage < RID_STAGES && c->rider_slot[p->pend_stage] == slot) {
+      const int st = p->pend_stage;
+      if (c->rider_alone[st] || !can_ride || rs->n == MAX_RIDERS) {
+        TimeScope ts(c, DFH_K_LOCALIZE);
+        launch_loc_stage(p, st, c->stream);
+        ++p->pend_stage;
+        continue;
+      }
+      Rider& r = rs->r[rs->n];
+      r.v = p->loc_v;
+      r.o = p->loc_o;
+      r.kind = (uint32_t)st;
+      r.nblk = (st == RID_COUNT || st == RID_SCATTER) ? (uint32_t)p->loc_v.ntiles : p->loc_gsort;
+      rs->first[rs->n + 1] = rs->first[rs->n] + ((r.nblk + 7u) & ~7u);
+      ++rs->n;
+      ++p->pend_stage;
+      break;  // the minibatch's next stage needs this launch to have ended
+    }
+  }
+  // emit (the stage the next step's lookup waits for) before the others: its blocks are dispatched first
+  for (uint32_t j = 1; j < rs->n; ++j) {
+    if (rs->r[j].kind == RID_EMIT && rs->r[0].kind != RID_EMIT) {
+      std::swap(rs->r[0], rs->r[j]);
+      uint32_t at = 0;
+      for (uint32_t q = 0; q < rs->n; ++q) {
+        rs->first[q] = at;
+        at += (rs->r[q].nblk + 7u) & ~7u;
+      }
+      rs->first[rs->n] = at;
+      break;
+    }
+  }
+  c->pend.erase(std::remove_if(c->pend.begin(), c->pend.end(), [](dfh_batch* p) { return p->pend_stage >= RID_STAGES; }), c->pend.end());
+  rs->ngroups = rs->first[rs->n] / 8u;
+  if (rs->ngroups) {
+    // every rider group needs a place: the last one sits at group (ngroups - 1) * period of main_groups + ngroups
+    uint32_t per = (uint32_t)std::max(1, c->rider_period[slot]);
+    if (rs->ngroups > 1) per = std::min(per, (main_groups + rs->ngroups - 1u) / (rs->ngroups - 1u));
+    rs->period = std::max(1u, per);
+  }
+}
+
 // Localizer::Compact of the loaded minibatch; with a table also the key-index probe of dfh_batch_lookup, done by the
 // emit pass itself (the thread that writes a unique key looks it up: one launch and one event record fewer per minibatch)
 int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
@@ -2451,6 +2652,10 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   }
   hipStream_t s = prep_of(b);
   b->looked_up = nullptr;
+  if (b->pend_stage < RID_STAGES) {  // localized twice without a step in between
+    int rc = flush_pending(b);
+    if (rc) return rc;
+  }
   if (N == 0) {
     // reference would index an empty vector (localizer.cc:35); define: no keys
     DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), s));  // U = 0
@@ -2486,7 +2691,7 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
   }
   if (P > 0 && !b->force_radix) {
     // hand-written sample sort (dfh_localize.hip)
-    LocView v;
+    LocView& v = b->loc_v;
     v.raw = b->d_raw;
     v.n = N;
     v.max_index = max_index;
@@ -2516,13 +2721,25 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     v.last_key = b->d_last_key;
     v.nheads = b->d_nheads;
     v.lh = b->d_lh;
-    SegListsOut sl;
-    sl.mid = b->d_mid;
-    sl.mid_ent = b->d_mid_ent;
-    sl.hot = b->d_hot;
-    sl.hot_ent = b->d_hot_ent;
-    sl.few = b->d_few;
-    sl.few_ent = b->d_few_ent;
+    EmitOut& o = b->loc_o;
+    o.value = b->has_value ? b->d_value : (const float*)nullptr;
+    o.feaids = b->d_feaids;
+    o.col_ptr = b->d_col_ptr;
+    o.index = b->d_index;
+    o.s_row = b->d_s_row;
+    o.s_val = b->d_s_val;
+    o.d_U = b->d_U;
+    o.sl.mid = b->d_mid;
+    o.sl.mid_ent = b->d_mid_ent;
+    o.sl.hot = b->d_hot;
+    o.sl.hot_ent = b->d_hot_ent;
+    o.sl.few = b->d_few;
+    o.sl.few_ent = b->d_few_ent;
+    b->loc_big = big;
+#ifndef DFH_LOC_GRID_CAP
+#define DFH_LOC_GRID_CAP 1024
+#endif
+    b->loc_gsort = (unsigned)std::min<int>(P, big ? LOC_BIG_BUCKETS : DFH_LOC_GRID_CAP);
     if (cold && P > 1) {
       const uint32_t S = (uint32_t)P * LOC_OVERSAMPLE;
       const uint32_t nt = (S + 255) / 256;
@@ -2530,27 +2747,16 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
       hipLaunchKernelGGL(k_ss_rank, dim3(nt * nt), dim3(256), 0, s, v);
       hipLaunchKernelGGL(k_loc_splitters, dim3(nt), dim3(256), 0, s, v);
     }
-    if (big) {
-      hipLaunchKernelGGL(k_loc_count<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-      hipLaunchKernelGGL(k_loc_scatter<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+    // single-queue step: note the four stages; they ride in the launches of the steps that follow (dfh_riders.hip).  Not
+    // for a first call (its splitters are being bootstrapped right here), the large size class (64 KB of LDS in count) or a
+    // probe folded into emit
+    if (c->single_queue && !cold && !big && !probe) {
+      b->pend_stage = 0;
+      c->pend.push_back(b);
     } else {
-      hipLaunchKernelGGL(k_loc_count<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, (uint32_t)b->nrows, b->d_offset, b->d_pos);
-      hipLaunchKernelGGL(k_loc_scatter<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      for (int st = 0; st < RID_STAGES; ++st) launch_loc_stage(b, st, s, probe);
     }
-#ifndef DFH_LOC_GRID_CAP
-#define DFH_LOC_GRID_CAP 1024
-#endif
-    const unsigned gsort = (unsigned)std::min<int>(P, big ? LOC_BIG_BUCKETS : DFH_LOC_GRID_CAP);
-    hipLaunchKernelGGL(k_loc_sort, dim3(gsort), dim3(LOC_SORT_THREADS), 0, s, v);
-    if (probe)
-      hipLaunchKernelGGL(k_loc_emit<true>, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
-                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                         b->d_s_val, b->d_U, sl, probe->v, b->d_urow);
-    else
-      hipLaunchKernelGGL(k_loc_emit<false>, dim3(gsort), dim3(LOC_EMIT_THREADS), 0, s, v,
-                         b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index, b->d_s_row,
-                         b->d_s_val, b->d_U, sl, TableView{}, (uint32_t*)nullptr);
-    b->spl_P = P;  // k_loc_emit left this minibatch's exact P-quantiles as the next call's splitters
+    b->spl_P = P;  // k_loc_emit leaves this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
   } else {
     // very large batches: library LSD radix sort
@@ -2734,7 +2940,7 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   b->defer_ready = true;
   rc = localize_impl(b, max_index, nullptr);
   lap(4);  // Localizer queued
-  if (!rc && nnz > kSmallBatchPairs) {   // (a small minibatch: the step's own pass probes, see dfh_batch_lookup)
+  if (!rc && nnz > kSmallBatchPairs && !c->single_queue) {   // (a small minibatch: the step's own pass probes, see dfh_batch_lookup)
     hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(b->nnz, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        (const float*)nullptr, b->d_col_ptr, 0, (uint32_t*)nullptr, 0, (uint2*)nullptr, AucFin{nullptr, 0u, nullptr});
     if (hipGetLastError() != hipSuccess) rc = DFH_ERR_HIP;
@@ -2795,6 +3001,7 @@ int dfh_batch_lookup(dfh_table* t, dfh_batch* b) {
   // takes exactly as long as the host needs to queue it): the step's own lookup pass probes in the launch it makes anyway.
   // 50.9 -> 44.8 us per step on the rcv1 shape (profiles/r05b_c2_launch_bound.txt).
   if (b->nnz <= kSmallBatchPairs) return DFH_OK;
+  if (c->single_queue) return DFH_OK;  // no preparation stream to probe on: the step's own pass probes and pushes in one
   DFH_HIP(hipSetDevice(c->device));
   int rc = table_reserve(t, b->nnz);  // U <= nnz keys may be new
   if (rc) return rc;
@@ -2887,7 +3094,9 @@ int dfh_batch_shape(dfh_batch* b, size_t* nrows, size_t* nnz, size_t* U) {
   if (U) {
     DFH_ARG(b->localized, "batch is not localized");
     uint32_t u = 0;
-    int rc = sync_all(b->ctx);
+    int rc = flush_pending(b);
+    if (rc) return rc;
+    rc = sync_all(b->ctx);
     if (rc) return rc;
     DFH_HIP(hipMemcpyAsync(&u, b->d_U, 4, hipMemcpyDeviceToHost, b->ctx->stream));
     DFH_HIP(hipStreamSynchronize(b->ctx->stream));
@@ -2918,6 +3127,7 @@ int dfh_batch_get_localized(dfh_batch* b, size_t* U, uint64_t* feaids, float* fe
 
 int dfh_batch_device_keys(dfh_batch* b, const uint64_t** d_feaids, const float** d_feacnt, size_t* U) {
   DFH_ARG(b && b->localized, "batch is not localized");
+  if (int rcf = flush_pending(b)) return rcf;  // the caller is about to read the arrays
   if (d_feaids) *d_feaids = b->d_feaids;
   if (d_feacnt) {
     if (!b->has_cnt) {
@@ -2960,6 +3170,7 @@ int dfh_batch_key_ranges(dfh_batch* b, int nparts, uint32_t* bounds) {
     for (int d = 0; d <= nparts; ++d) bounds[d] = 0;
     return DFH_OK;
   }
+  if (int rcf = flush_pending(b)) return rcf;
   hipLaunchKernelGGL(k_key_ranges, dim3((nparts + 256) / 256), dim3(256), 0, s, b->d_feaids, b->d_U, nparts, span, d_bounds);
   DFH_HIP(hipGetLastError());
   DFH_HIP(hipMemcpyAsync(bounds, d_bounds, (size_t)(nparts + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -2986,13 +3197,16 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   int rc = ensure_xv(b, kp);
   if (rc) return rc;
   b->nrows_seen += (float)b->nrows;
+  RiderSet none;  // (stages of later minibatches due in a launch this step does not make: they run alone)
   if (b->nnz == 0) {
     // rows without features: pred = 0 for every example; nothing to pull or push
     RowSrc src = table_src(t, b->d_urow);
     rc = main_begin(b);
     if (rc) return rc;
-    rc = launch_forward(b, src, k, kp);
+    collect_riders(c, 0, false, 0, &none);
+    rc = launch_forward(b, src, k, kp, nullptr, nullptr, true);
     if (rc) return rc;
+    collect_riders(c, 2, false, 0, &none);
     return main_end(b);
   }
   const bool refrand = t->v.p.init_mode == DFH_INIT_REFRAND && k > 0;
@@ -3016,7 +3230,16 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   {
     TimeScope ts(c, DFH_K_LOOKUP);
     // (the lookup's first block also adds up the AUC slots this batch object's previous step left behind)
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(Nb, c)), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+    const int gl = grid_for_threads(Nb, c);
+    RiderSet rs;  // single-queue step: the stages of later minibatches' Localizer that belong into this launch
+    collect_riders(c, 0, true, ((uint32_t)gl + 7u) / 8u, &rs);
+    if (rs.n)
+      hipLaunchKernelGGL(k_lookup_riders, dim3((((unsigned)gl + 7u) / 8u + rs.ngroups) * 8u), dim3(256), rider_smem(rs), s, t->v, b->d_feaids,
+                         b->d_U, 0u, b->d_urow, b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr,
+                         push_cnt ? (defer_cnt ? 2 : 1) : 0, refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b),
+                         (uint32_t)gl, rs);
+    else
+    hipLaunchKernelGGL(k_lookup, dim3(gl), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
                        refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b));
     b->auc_pending_n = 0;
@@ -3027,7 +3250,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     if (rc) return rc;
   }
   RowSrc src = table_src(t, b->d_urow);
-  rc = launch_forward(b, src, k, kp, uw);
+  rc = launch_forward(b, src, k, kp, uw, nullptr, true);
   if (rc) return rc;
   // BinClassMetric::AUC of every minibatch (sgd_learner.cc:153-155): in a training step it rides in the update launch
   // (k_update_fused: the pair counting is VALU work beside a memory-bound kernel), otherwise it is a launch of its own
@@ -3040,7 +3263,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   if (is_train) {
     if (refrand) DFH_HIP(hipMemsetAsync(b->d_need, 0, (size_t)Nb * 4, s));
     const bool wanted = auc_rides;
-    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw, defer_cnt, &auc_rides);
+    rc = launch_backward<true>(b, src, t->v, nullptr, 0, k, kp, b->d_need, kAllKeys, uw, defer_cnt, &auc_rides, true);
     if (rc) return rc;
     if (wanted && !auc_rides) {  // k_backward_all ran (upd_kernel = 0) or the minibatch is beyond the pair-counting size
       TimeScope ts(c, DFH_K_AUC);
@@ -3053,6 +3276,7 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     }
   } else {
     BatchView bv = batch_view(b);
+    collect_riders(c, 2, false, 0, &none);
     hipLaunchKernelGGL((k_penalty<1>), dim3(std::min(grid_for_waves(Nb, c), PROG_SLOTS)), dim3(256), 0, s, bv, src, t->v, k, kp, kAllKeys);
     DFH_HIP(hipGetLastError());
   }

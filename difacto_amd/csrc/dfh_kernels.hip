@@ -320,11 +320,12 @@ struct AucFin {
 
 // unit `unit` of auc_units(n): 256-thread blocks only.  part[unit] = pairs counted; part[auc_units(n) + rt] = positives of
 // row tile rt (written by the tile's first unit)
+constexpr size_t AUC_SMEM = (size_t)AUC_TILE * 8 + 16 * 4;  // working memory of auc_pairs_block
 __device__ __forceinline__ void auc_pairs_block(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n, uint32_t unit,
-                                                uint32_t* __restrict__ part) {
-  __shared__ unsigned long long colp[AUC_TILE];  // positives of the current column tile: image of pred_j << 32 | j
-  __shared__ uint32_t npos_tile;
-  __shared__ uint32_t red[8];
+                                                uint32_t* __restrict__ part, char* smem /* AUC_SMEM bytes, 16 B aligned */) {
+  unsigned long long* colp = reinterpret_cast<unsigned long long*>(smem);  // positives of the current column tile: image of pred_j << 32 | j
+  uint32_t* red = reinterpret_cast<uint32_t*>(colp + AUC_TILE);            // [8]
+  uint32_t& npos_tile = red[8];
   const uint32_t ntile = (n + AUC_TILE - 1) / AUC_TILE;
   const uint32_t nct = auc_nct(n);
   const uint32_t rt = unit / nct, ct = unit % nct;
@@ -420,7 +421,8 @@ __device__ __forceinline__ void auc_finalize_block(const AucFin f) {
 
 __global__ void __launch_bounds__(256) k_auc_pairs(const float* __restrict__ pred, const float* __restrict__ label, uint32_t n,
                                                    uint32_t* __restrict__ part) {
-  auc_pairs_block(pred, label, n, blockIdx.x, part);
+  __shared__ __attribute__((aligned(16))) char smem[AUC_SMEM];
+  auc_pairs_block(pred, label, n, blockIdx.x, part, smem);
 }
 __global__ void __launch_bounds__(256) k_auc_finalize(AucFin f) { auc_finalize_block(f); }
 
@@ -433,11 +435,11 @@ __global__ void __launch_bounds__(256) k_auc_finalize(AucFin f) { auc_finalize_b
 __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
-                         int rows_known, uint2* __restrict__ uw, AucFin fin) {
+                         int rows_known, uint2* __restrict__ uw, AucFin fin, const uint32_t bid, const uint32_t nblk) {
   // a step's lookup also closes the AUC its batch object's previous step left pending (dfh_sgd_step; fin.n == 0: none)
-  if (fin.n && blockIdx.x == 0) auc_finalize_block(fin);
+  if (fin.n && bid == 0) auc_finalize_block(fin);
   uint32_t n = d_n ? *d_n : n_static;
-  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+  for (uint32_t u = bid * blockDim.x + threadIdx.x; u < n; u += nblk * blockDim.x) {
     uint64_t key = keys[u];
     // rows_known: urow was filled by an earlier (prep-stream) lookup of the same keys
     uint32_t r = rows_known ? urow[u] : find_or_insert(t, key);
@@ -485,7 +487,7 @@ __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const u
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
                          int rows_known, uint2* __restrict__ uw, AucFin fin) {
-  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin);
+  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, blockIdx.x, gridDim.x);
 }
 
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
@@ -516,7 +518,7 @@ __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const
 __global__ void k_lookup_uw_remote(TableView t, const uint64_t* __restrict__ keys, uint32_t n_static, uint32_t* __restrict__ urow,
                                    const float* __restrict__ cnt, const uint32_t* __restrict__ col_ptr, int push_cnt,
                                    uint2* __restrict__ uw, AucFin fin, UwRemote m) {
-  lookup_body(t, keys, nullptr, n_static, urow, cnt, col_ptr, push_cnt, nullptr, 0, uw, fin);
+  lookup_body(t, keys, nullptr, n_static, urow, cnt, col_ptr, push_cnt, nullptr, 0, uw, fin, blockIdx.x, gridDim.x);
   uw_remote_body(m);
 }
 
@@ -609,15 +611,18 @@ struct MixSrc {
   size_t vstride2;
 };
 
+// block `bid` of `nblk` 256-thread blocks (the whole launch of k_forward; a block range of a launch that also carries
+// riders: dfh_riders.hip)
 template <int L, int FWD_DEPTH, bool MIXED>
-__global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, RowSrc src, int k, int kp, MixSrc mix) {
+__device__ __forceinline__ void forward_body(const BatchView& b, const RowSrc& src, const int k, const int kp, const MixSrc& mix,
+                                             const uint32_t bid, const uint32_t nblk, double* blk /* [4] shared */) {
   constexpr int G = 64 / L;
   const int lane = lane_id();
   const int grp = lane / L;
   const int sub = lane % L;
   const bool sub_ok = sub * 4 < kp;  // L may exceed kp/4 when kp/4 is not a power of two
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = (bid * 256u + threadIdx.x) >> 6;
+  const int nwaves = (nblk * 256u) >> 6;
   double loss_acc = 0.0;
 
   for (uint32_t i = wave; i < b.nrows; i += nwaves) {
@@ -715,10 +720,15 @@ __global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, Row
   }
   // the batch's logloss: one private slot per block (same-address atomics
   // serialise at ~12 ns each on this chip: 2k blocks would cost 25 us)
-  __shared__ double blk[4];
   if (lane == 0) blk[threadIdx.x >> 6] = loss_acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&b.prog[PROG_LOSS * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], blk[0] + blk[1] + blk[2] + blk[3]);
+  if (threadIdx.x == 0) atomicAdd(&b.prog[PROG_LOSS * PROG_SLOTS + (bid % PROG_SLOTS)], blk[0] + blk[1] + blk[2] + blk[3]);
+}
+
+template <int L, int FWD_DEPTH, bool MIXED>
+__global__ void __launch_bounds__(256, DFH_FWD_WAVES) k_forward(BatchView b, RowSrc src, int k, int kp, MixSrc mix) {
+  __shared__ double blk[4];
+  forward_body<L, FWD_DEPTH, MIXED>(b, src, k, kp, mix, blockIdx.x, gridDim.x, blk);
 }
 
 // ---------------------------------------------------------------------------

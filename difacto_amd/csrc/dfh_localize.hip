@@ -136,9 +136,9 @@ __device__ __forceinline__ uint64_t make_key(uint64_t id, uint64_t max_index) {
   return reverse_bytes(m);
 }
 
-// tiles are dealt to the XCDs round robin (workgroup id mod 8); a wrong guess costs write-combining, not correctness
+// tiles are dealt to the XCDs round robin (tile number mod 8 — the workgroup id of a launch of its own, and of a rider too:
+// riders sit in the launch in groups of 8 blocks); a wrong guess costs write-combining, not correctness
 constexpr int LOC_XCDS = 8;
-__device__ __forceinline__ uint32_t loc_xcd() { return blockIdx.x & (LOC_XCDS - 1); }
 
 __device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t pa, uint64_t kb, uint32_t pb) {
   return ka < kb || (ka == kb && pa < pb);
@@ -260,45 +260,59 @@ __global__ void __launch_bounds__(256) k_loc_splitters(LocView v) {
 // ---------------------------------------------------------------------------------------
 // count: bucket + rank-in-(tile, bucket) of every pair; the tile's runs reserve their places
 // ---------------------------------------------------------------------------------------
+// Every stage below is a BLOCK FUNCTION: block `bid` of `nblk` of its stage, THREADS threads, working memory carved out of
+// `smem` — so that a stage can run as a launch of its own (the k_loc_* wrappers) or as a RIDER: a block range of a launch
+// that exists anyway (k_lookup / k_forward / k_update_fused of an earlier minibatch's step, dfh_riders.h), which is how the
+// single-queue step gets the Localizer of minibatch t+1 done without a second hardware queue.
 template <int MAXB>
-__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint32_t nrows, const uint32_t* __restrict__ offset,
-                                                                uint32_t* __restrict__ rowid) {
-  __shared__ uint64_t sk[MAXB];
-  __shared__ uint32_t sp[MAXB];
-  __shared__ uint32_t hist[MAXB];
+constexpr size_t loc_count_smem() { return (size_t)MAXB * 16; }
+template <int MAXB, int THREADS>
+constexpr size_t loc_scatter_smem() { return (size_t)MAXB * 4 + (THREADS / 64) * 4; }
+constexpr size_t loc_sort_smem() { return (size_t)LOC_LDS_CAP * 24 + 2 * (LOC_SORT_THREADS / 64) * 4; }
+constexpr size_t loc_emit_smem() { return (2 * (LOC_EMIT_THREADS / 64) + 4) * 4; }
+
+template <int MAXB, int THREADS>
+__device__ __forceinline__ void loc_count_block(const LocView& v, const uint32_t bid, const uint32_t nblk, char* smem) {
+  constexpr int PER = LOC_TILE / THREADS;
+  static_assert(PER * THREADS == LOC_TILE, "a tile is a whole number of elements per thread");
+  uint64_t* sk = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* sp = reinterpret_cast<uint32_t*>(smem + (size_t)MAXB * 8);
+  uint32_t* hist = sp + MAXB;
   const int P = v.P;
-  for (int b = threadIdx.x; b < P; b += blockDim.x) {
+  for (int b = threadIdx.x; b < P; b += THREADS) {
     hist[b] = 0;
     sk[b] = b < P - 1 ? v.spl_key[b] : ~0ULL;  // spl[P-1] = +inf
     sp[b] = b < P - 1 ? v.spl_pos[b] : ~0u;
   }
-  const uint32_t base = blockIdx.x * LOC_TILE;
-  uint64_t key[LOC_PER_THREAD];
+  const uint32_t base = bid * LOC_TILE;
+  uint64_t key[PER];
 #pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {  // independent loads first
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < PER; ++e) {  // independent loads first
+    const uint32_t i = base + e * THREADS + threadIdx.x;
     key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
   }
   // side job, independent of the sort until k_loc_emit: rowid[pos] = row of nnz position pos,
   // this block's share of the rows
   {
-    const uint32_t rpb = (nrows + gridDim.x - 1) / gridDim.x;
-    const uint32_t r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+    uint32_t* __restrict__ rowid = const_cast<uint32_t*>(v.rowid);
+    const uint32_t* __restrict__ offset = v.offset;
+    const uint32_t rpb = (v.nrows + nblk - 1) / nblk;
+    const uint32_t r0 = bid * rpb, r1 = min(v.nrows, r0 + rpb);
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += THREADS) {
       const uint32_t e = offset[r + 1];
       for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
     }
   }
   __syncthreads();
-  // LOC_PER_THREAD interleaved binary searches: first b with (key, i) < spl[b]
-  int lo[LOC_PER_THREAD], hi[LOC_PER_THREAD];
+  // PER interleaved binary searches: first b with (key, i) < spl[b]
+  int lo[PER], hi[PER];
 #pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) { lo[e] = 0; hi[e] = P - 1; }
+  for (int e = 0; e < PER; ++e) { lo[e] = 0; hi[e] = P - 1; }
   for (int step = P; step > 1; step = (step + 1) >> 1) {  // ceil(log2 P) rounds
 #pragma unroll
-    for (int e = 0; e < LOC_PER_THREAD; ++e) {
+    for (int e = 0; e < PER; ++e) {
       if (lo[e] < hi[e]) {
-        const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+        const uint32_t i = base + e * THREADS + threadIdx.x;
         const int mid = (lo[e] + hi[e]) >> 1;
         // the pair's own row bits are not known here (another block writes rowid[i]); they only matter for the pair
         // that IS a splitter, and that one may fall on either side of it
@@ -307,8 +321,8 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
     }
   }
 #pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < PER; ++e) {
+    const uint32_t i = base + e * THREADS + threadIdx.x;
     if (i < v.n) {
       const uint32_t r = atomicAdd(&hist[lo[e]], 1u);
       v.packed[i] = ((uint32_t)lo[e] << 16) | r;
@@ -318,27 +332,36 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v, uint3
   // one global atomic per non-empty (tile, bucket) run: its offset inside the bucket.  The order in
   // which the tiles arrive differs from run to run; the bucket is sorted afterwards, so the
   // result does not.
-  for (int b = threadIdx.x; b < P; b += blockDim.x) {
+  for (int b = threadIdx.x; b < P; b += THREADS) {
     const uint32_t h = hist[b];
-    v.run_off[blockIdx.x * P + b] = h ? atomicAdd(&v.btotal[loc_xcd() * MAXB + b], h) : 0u;
+    v.run_off[bid * P + b] = h ? atomicAdd(&v.btotal[(bid & (LOC_XCDS - 1)) * MAXB + b], h) : 0u;
   }
+}
+
+template <int MAXB>
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v) {
+  __shared__ __attribute__((aligned(16))) char smem[loc_count_smem<MAXB>()];
+  loc_count_block<MAXB, LOC_TILE_THREADS>(v, blockIdx.x, gridDim.x, smem);
 }
 
 
 // ---- scatter into bucket-major order; every block derives the bucket starts from the totals
 // (block 0 publishes them)
-template <int MAXB>
-__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
-  constexpr int LOC_BPT = MAXB / LOC_TILE_THREADS;  // buckets per thread in the scan of the bucket totals
-  __shared__ uint32_t off[MAXB];
-  __shared__ uint32_t wsum[LOC_TILE_THREADS / 64];
+template <int MAXB, int THREADS>
+__device__ __forceinline__ void loc_scatter_block(const LocView& v, const uint32_t bid, char* smem) {
+  constexpr int PER = LOC_TILE / THREADS;
+  constexpr int LOC_BPT = MAXB / THREADS;  // buckets per thread in the scan of the bucket totals
+  static_assert(LOC_BPT * THREADS == MAXB, "the scan of the bucket totals gives every thread the same number of buckets");
+  uint32_t* off = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* wsum = off + MAXB;
   const int P = v.P;
-  const uint32_t base = blockIdx.x * LOC_TILE;
-  uint64_t raw[LOC_PER_THREAD];
-  uint32_t pk[LOC_PER_THREAD], rw[LOC_PER_THREAD];
+  const uint32_t xcd = bid & (LOC_XCDS - 1);
+  const uint32_t base = bid * LOC_TILE;
+  uint64_t raw[PER];
+  uint32_t pk[PER], rw[PER];
 #pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = min(base + e * LOC_TILE_THREADS + threadIdx.x, v.n - 1);  // clamped: the loads stay unconditional
+  for (int e = 0; e < PER; ++e) {
+    const uint32_t i = min(base + e * THREADS + threadIdx.x, v.n - 1);  // clamped: the loads stay unconditional
     raw[e] = v.raw[i];
     pk[e] = v.packed[i];
     rw[e] = v.rowid[i];
@@ -353,38 +376,44 @@ __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
     const int bb = min(b0 + q, P - 1);
     const uint32_t in = b0 + q < P ? 1u : 0u;
     tt[q] = 0;
-    ro[q] = v.run_off[blockIdx.x * P + bb];
+    ro[q] = v.run_off[bid * P + bb];
 #pragma unroll
     for (int x = 0; x < LOC_XCDS; ++x) {
       const uint32_t h = v.btotal[x * MAXB + bb];
       tt[q] += h;
-      ro[q] += (x < (int)loc_xcd() ? 1u : 0u) * h;  // the groups before this tile's
+      ro[q] += (x < (int)xcd ? 1u : 0u) * h;  // the groups before this tile's
     }
     tt[q] *= in;
     ro[q] *= in;
     sum += tt[q];
   }
   uint32_t total;
-  uint32_t ex = block_exclusive_scan<LOC_TILE_THREADS / 64>(sum, wsum, &total);
+  uint32_t ex = block_exclusive_scan<THREADS / 64>(sum, wsum, &total);
 #pragma unroll
   for (int q = 0; q < LOC_BPT; ++q) {
     if (b0 + q < P) {
       off[b0 + q] = ex + ro[q];
-      if (blockIdx.x == 0) v.bstart[b0 + q] = ex;
+      if (bid == 0) v.bstart[b0 + q] = ex;
     }
     ex += tt[q];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) v.bstart[P] = total;
+  if (bid == 0 && threadIdx.x == 0) v.bstart[P] = total;
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < LOC_PER_THREAD; ++e) {
-    const uint32_t i = base + e * LOC_TILE_THREADS + threadIdx.x;
+  for (int e = 0; e < PER; ++e) {
+    const uint32_t i = base + e * THREADS + threadIdx.x;
     if (i < v.n) {
       const uint32_t dst = off[pk[e] >> 16] + (pk[e] & 0xFFFFu);
       v.bkeys[dst] = make_key(raw[e], v.max_index);
       v.bpos[dst] = (i << v.tb) | (rw[e] & ((1u << v.tb) - 1u));
     }
   }
+}
+
+template <int MAXB>
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_scatter(LocView v) {
+  __shared__ __attribute__((aligned(16))) char smem[loc_scatter_smem<MAXB, LOC_TILE_THREADS>()];
+  loc_scatter_block<MAXB, LOC_TILE_THREADS>(v, blockIdx.x, smem);
 }
 
 // ---- sort of one bucket [beg, beg + n) of the bucket-major arrays by (key, pos).  Buckets of up to
@@ -582,16 +611,15 @@ __device__ __forceinline__ BucketSummary loc_bucket_summary(const uint64_t* sk, 
   return r;
 }
 
-// ---- sort one bucket; summary of its runs of equal keys (four-launch form)
-__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
-  __shared__ uint64_t ak[LOC_LDS_CAP];
-  __shared__ uint32_t ap[LOC_LDS_CAP];
-  __shared__ uint64_t bk[LOC_LDS_CAP];
-  __shared__ uint32_t bp[LOC_LDS_CAP];
-  __shared__ uint32_t red[2][LOC_SORT_THREADS / 64];
-  // the grid may be smaller than the number of buckets (a capped grid leaves more of the chip to
-  // the training step this preparation work runs beside)
-  for (uint32_t b = blockIdx.x; b < (uint32_t)v.P; b += gridDim.x) {
+// ---- sort one bucket; summary of its runs of equal keys (four-launch form).  Block `bid` of `nblk`: the grid may be
+// smaller than the number of buckets (a capped grid leaves more of the chip to the training step this work runs beside)
+__device__ __forceinline__ void loc_sort_block(const LocView& v, const uint32_t bid, const uint32_t nblk, char* smem) {
+  uint64_t* ak = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* bk = ak + LOC_LDS_CAP;
+  uint32_t* ap = reinterpret_cast<uint32_t*>(bk + LOC_LDS_CAP);
+  uint32_t* bp = ap + LOC_LDS_CAP;
+  uint32_t (*red)[LOC_SORT_THREADS / 64] = reinterpret_cast<uint32_t (*)[LOC_SORT_THREADS / 64]>(bp + LOC_LDS_CAP);
+  for (uint32_t b = bid; b < (uint32_t)v.P; b += nblk) {
     __syncthreads();  // LDS of the previous bucket is done with
     const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
     const uint32_t n = end - beg;
@@ -608,7 +636,7 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
     const uint64_t* sk;
     const uint32_t* sp;
     if (loc_sort_bucket(v, beg, n, ak, ap, bk, bp, &sk, &sp)) {
-      for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+      for (uint32_t t = threadIdx.x; t < n; t += LOC_SORT_THREADS) {
         v.skeys[beg + t] = sk[t];
         v.spos[beg + t] = sp[t];
       }
@@ -621,6 +649,10 @@ __global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
       v.last_key[b] = sm.last_key;
     }
   }
+}
+__global__ void __launch_bounds__(LOC_SORT_THREADS) k_loc_sort(LocView v) {
+  __shared__ __attribute__((aligned(16))) char smem[loc_sort_smem()];
+  loc_sort_block(v, blockIdx.x, gridDim.x, smem);
 }
 
 // ---- emit: one block per bucket stitches itself to its predecessors (unique keys before the
@@ -727,17 +759,31 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
   }
 }
 
+// what emit writes, apart from the next call's splitters (LocView)
+struct EmitOut {
+  const float* value;    // [N] feature values in row order, or NULL
+  uint64_t* feaids;
+  uint32_t* col_ptr;
+  uint32_t* index;
+  uint32_t* s_row;
+  float* s_val;
+  uint32_t* d_U;
+  SegListsOut sl;
+};
+
 template <bool PROBE>
-__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const float* __restrict__ value, uint64_t* __restrict__ feaids,
-                                                                uint32_t* __restrict__ col_ptr, uint32_t* __restrict__ index,
-                                                                uint32_t* __restrict__ s_row, float* __restrict__ s_val,
-                                                                uint32_t* __restrict__ d_U, SegListsOut sl, TableView tab,
-                                                                uint32_t* __restrict__ urow) {
+__device__ __forceinline__ void loc_emit_block(const LocView& v, const EmitOut& o, const TableView& tab, uint32_t* __restrict__ urow,
+                                               const uint32_t bid, const uint32_t nblk, char* smem) {
   constexpr int NW = LOC_EMIT_THREADS / 64;
-  __shared__ uint32_t wsum[NW], wmax[NW];
-  __shared__ uint32_t sh_cont, n_mid, n_hot, n_few;
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* wmax = wsum + NW;
+  uint32_t& sh_cont = wmax[NW];
+  uint32_t& n_mid = wmax[NW + 1];
+  uint32_t& n_hot = wmax[NW + 2];
+  uint32_t& n_few = wmax[NW + 3];
+  const SegListsOut& sl = o.sl;
   const uint32_t P = (uint32_t)v.P;
-  for (uint32_t b = blockIdx.x; b < P; b += gridDim.x) {
+  for (uint32_t b = bid; b < P; b += nblk) {
     __syncthreads();  // the shared counters of the previous bucket have been published
     const uint32_t beg = v.bstart[b], end = v.bstart[b + 1];
     const uint32_t n = end - beg;
@@ -755,7 +801,7 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     // over the buckets q < b: unique keys (nheads[q] - cont[q], cont[q]: first_key[q] equals the last key of the
     // previous NON-EMPTY bucket) and the position of the last run head that opens a new key
     uint32_t part = 0, carry1 = 0;  // carry1: position + 1 (0: none)
-    for (uint32_t q0 = threadIdx.x; q0 <= b; q0 += blockDim.x) {
+    for (uint32_t q0 = threadIdx.x; q0 <= b; q0 += LOC_EMIT_THREADS) {
       const uint32_t bq = v.bstart[q0], nq = v.bstart[q0 + 1] - bq;
       if (nq == 0) continue;
       int p = (int)q0 - 1;
@@ -774,9 +820,15 @@ __global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, const 
     block_exclusive_scan<NW>(part, wsum, &ubase);
     block_exclusive_max<NW>(carry1, wmax, &carry_all);
     __syncthreads();
-    loc_emit_bucket<NW, PROBE>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, value, feaids, col_ptr,
-                               index, s_row, s_val, d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few, tab, urow);
+    loc_emit_bucket<NW, PROBE>(v, b, beg, n, v.skeys + beg, v.spos + beg, sh_cont, ubase, carry_all, o.value, o.feaids, o.col_ptr,
+                               o.index, o.s_row, o.s_val, o.d_U, sl, wsum, wmax, &n_mid, &n_hot, &n_few, tab, urow);
   }
+}
+
+template <bool PROBE>
+__global__ void __launch_bounds__(LOC_EMIT_THREADS) k_loc_emit(LocView v, EmitOut o, TableView tab, uint32_t* __restrict__ urow) {
+  __shared__ __attribute__((aligned(16))) char smem[loc_emit_smem()];
+  loc_emit_block<PROBE>(v, o, tab, urow, blockIdx.x, gridDim.x, smem);
 }
 
 }  // namespace dfh

@@ -329,9 +329,10 @@ __device__ __forceinline__ bool upd_team(uint32_t unit, uint32_t units, uint32_t
 }
 
 // ---- hot: one key per block and iteration
+constexpr size_t UPD_HOT_SMEM = (size_t)UPD_NW * (2 + 256) * 4;
 template <int L, bool EXACT, int DB, bool HAS_VAL, bool MIXED>
-__device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uint32_t nblk, float& pen) {
-  __shared__ float part[UPD_NW][2 + 256];  // per wave: gw, xxp, gv[kp <= 256]
+__device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uint32_t nblk, float& pen, char* smem /* UPD_HOT_SMEM bytes */) {
+  float (*part)[2 + 256] = reinterpret_cast<float (*)[2 + 256]>(smem);  // per wave: gw, xxp, gv[kp <= 256]
   const int lane = lane_id();
   const int grp = lane / L, sub = lane % L;
   const int kp = EXACT ? 4 * L : a.kp, k = a.k;
@@ -555,7 +556,7 @@ __device__ __forceinline__ void upd_singles_role(const UpdArgs& a, uint32_t wave
 
 // penalty of the pulled weights (sgd_learner.cc:249-273): per-lane fp32 partials (a handful of terms each),
 // widened here; one private slot per block (same-address atomics serialise)
-__device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
+__device__ __forceinline__ void upd_flush_penalty(double* prog, float pen, const uint32_t blk) {
   __shared__ double pen_blk[UPD_NW];
   const uint32_t w = threadIdx.x >> 6;
   const double pw = wave_sum_d((double)pen);
@@ -565,14 +566,17 @@ __device__ __forceinline__ void upd_flush_penalty(double* prog, float pen) {
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < UPD_NW; ++i) t += pen_blk[i];
-    if (t != 0.0) atomicAdd(&prog[PROG_PENALTY * PROG_SLOTS + (blockIdx.x % PROG_SLOTS)], t);
+    if (t != 0.0) atomicAdd(&prog[PROG_PENALTY * PROG_SLOTS + (blk % PROG_SLOTS)], t);
   }
 }
 
-template <int L, bool EXACT, bool HAS_VAL, bool MIXED = false>
-__global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
-  if (blockIdx.x < a.nb_auc) {  // uniform per block; nb_auc is auc_units(nrows) rounded up to 8 (see the XCD note below)
-    if (blockIdx.x < auc_units(a.nrows)) auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blockIdx.x, a.auc_part);
+// block `bid` of the update's `nblk` blocks (the whole launch of k_update_fused; a block range of a launch that also
+// carries riders: dfh_riders.hip).  smem: max(AUC_SMEM, UPD_HOT_SMEM) bytes — a block is an AUC unit or a role, never both.
+constexpr size_t UPD_SMEM = AUC_SMEM > UPD_HOT_SMEM ? AUC_SMEM : UPD_HOT_SMEM;
+template <int L, bool EXACT, bool HAS_VAL, bool MIXED>
+__device__ __forceinline__ void update_body(const UpdArgs& a, const uint32_t blk_in, const uint32_t nblk, char* smem) {
+  if (blk_in < a.nb_auc) {  // uniform per block; nb_auc is auc_units(nrows) rounded up to 8 (see the XCD note below)
+    if (blk_in < auc_units(a.nrows)) auc_pairs_block(a.auc_pred, a.auc_label, a.nrows, blk_in, a.auc_part, smem);
     return;
   }
   if (threadIdx.x == 0) upd_init_list()[0] = 0u;
@@ -583,8 +587,8 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
   // stream most of the launch's HBM traffic: dispatched in that order the former would hold every block slot of
   // the chip for the length of their chains before the first model row moves.  Interleaved 1 : (R - 1) both kinds
   // are resident from the start.
-  const uint32_t nb_list = a.nb_hot + a.nb_mid + a.nb_few, nb_single = gridDim.x - a.nb_auc - nb_list;
-  uint32_t bid = blockIdx.x - a.nb_auc;
+  const uint32_t nb_list = a.nb_hot + a.nb_mid + a.nb_few, nb_single = nblk - a.nb_auc - nb_list;
+  uint32_t bid = blk_in - a.nb_auc;
   bool list_role = bid < nb_list;
   if (a.ileave > 1u) {
     // groups of [8 list blocks, 8 (R - 1) singles blocks] while both kinds last, then the rest: list blocks, singles blocks.
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
     upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL, MIXED>(a, bid * UPD_NW + w, nb_single * UPD_NW, pen);
   } else if (bid < a.nb_hot) {
     if (DFH_UPD_ROLES & 1)
-    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen);
+    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
   } else if ((bid -= a.nb_hot) < a.nb_mid) {
     if (DFH_UPD_ROLES & 2)
     upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);
@@ -620,7 +624,13 @@ __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(Upd
     upd_few_role<L, EXACT, HAS_VAL, MIXED>(a, bid * UPD_NW + w, a.nb_few * UPD_NW, pen);
   }
   upd_init_rows(a, L);
-  upd_flush_penalty(a.prog, pen);
+  upd_flush_penalty(a.prog, pen, blk_in);
+}
+
+template <int L, bool EXACT, bool HAS_VAL, bool MIXED = false>
+__global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused(UpdArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[UPD_SMEM];
+  update_body<L, EXACT, HAS_VAL, MIXED>(a, blockIdx.x, gridDim.x, smem);
 }
 
 // Measured dead end (round 4; profiles/r04a_fwd_singles_ab.txt): the singles role as the EPILOGUE OF THE
