@@ -65,7 +65,8 @@ struct dfh_ctx {
   int single_queue = 0;
   int rider_slot[4] = {2, 0, 1, 2};     // count, scatter, sort, emit
   int rider_alone[4] = {0, 0, 0, 0};
-  int rider_period[3] = {3, 3, 4};      // L, F, U: one group of 8 rider blocks every n groups of 8 blocks (1: riders first)
+  int rider_period[3] = {1, 1, 1};      // L, F, U: one group of 8 rider blocks every n groups of 8 blocks (1: riders first — the best measured, profiles/r06a_*)
+  int rider_start[3] = {0, 0, 0};       // L, F, U: per cent of the carrier's own blocks dispatched before the first rider group
   std::vector<dfh_batch*> pend;
   // The library's code object (8 MB, a few hundred kernel instantiations) is loaded by the runtime on the FIRST launch of any
   // of its kernels: 30-40 ms that used to fall into a job's first minibatch (build/difacto: the first dfh_batch_prepare_rows
@@ -1048,6 +1049,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
     const int st = n == "rider_slot_count" ? 0 : n == "rider_slot_scatter" ? 1 : n == "rider_slot_sort" ? 2 : 3;
     c->rider_slot[st] = value & 3;
     c->rider_alone[st] = (value >> 2) & 1;
+  } else if (n == "rider_start_lookup" || n == "rider_start_forward" || n == "rider_start_update") {
+    DFH_ARG(value >= 0 && value <= 100, "rider_start_*: per cent of the carrier's own blocks dispatched before the first rider group");
+    c->rider_start[n == "rider_start_lookup" ? 0 : n == "rider_start_forward" ? 1 : 2] = value;
   } else if (n == "rider_period_lookup" || n == "rider_period_forward" || n == "rider_period_update") {
     DFH_ARG(value >= 1 && value <= 4096, "rider_period_*: one group of 8 rider blocks every n groups (1: riders first)");
     c->rider_period[n == "rider_period_lookup" ? 0 : n == "rider_period_forward" ? 1 : 2] = value;
@@ -2591,6 +2595,7 @@ void collect_riders(dfh_ctx* c, int slot, bool can_ride, uint32_t main_groups, R
   rs->n = 0;
   rs->ngroups = 0;
   rs->period = 1;
+  rs->start = 0;
   rs->first[0] = 0;
   if (!c->single_queue || c->pend.empty()) return;
   for (size_t i = 0; i < c->pend.size(); ++i) {
@@ -2631,8 +2636,10 @@ void collect_riders(dfh_ctx* c, int slot, bool can_ride, uint32_t main_groups, R
   rs->ngroups = rs->first[rs->n] / 8u;
   if (rs->ngroups) {
     // every rider group needs a place: the last one sits at group (ngroups - 1) * period of main_groups + ngroups
+    rs->start = (uint32_t)((uint64_t)main_groups * (uint64_t)c->rider_start[slot] / 100u);
+    const uint32_t left = main_groups - rs->start;   // main groups among which the rider groups are dealt
     uint32_t per = (uint32_t)std::max(1, c->rider_period[slot]);
-    if (rs->ngroups > 1) per = std::min(per, (main_groups + rs->ngroups - 1u) / (rs->ngroups - 1u));
+    if (rs->ngroups > 1) per = std::min(per, (left + rs->ngroups - 1u) / (rs->ngroups - 1u));
     rs->period = std::max(1u, per);
   }
 }

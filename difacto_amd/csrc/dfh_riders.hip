@@ -41,6 +41,7 @@ struct RiderSet {
   uint32_t n;                      // riders in this launch (0: none)
   uint32_t ngroups;                // rider blocks / 8 (every rider's range is padded to a multiple of 8)
   uint32_t period;                 // one rider group every `period` groups of 8 blocks (1: all riders first)
+  uint32_t start;                  // main groups dispatched before the first rider group (0: riders from the first block on)
   uint32_t first[MAX_RIDERS + 1];  // rider j owns rider blocks [first[j], first[j + 1])
   Rider r[MAX_RIDERS];
 };
@@ -63,14 +64,20 @@ inline size_t rider_smem(const RiderSet& rs) {
 
 // launch index -> rider block (true, idx among the rider blocks) or main block (false, idx among the main blocks)
 __device__ __forceinline__ bool rider_map(const RiderSet& rs, const uint32_t i, uint32_t& idx) {
-  const uint32_t g = i >> 3, l = i & 7u;
+  uint32_t g = i >> 3;
+  const uint32_t l = i & 7u;
+  if (g < rs.start) {  // the carrier's first blocks: its long chains are under way before the first rider takes a slot
+    idx = i;
+    return false;
+  }
+  g -= rs.start;
   const uint32_t q = g / rs.period, rem = g - q * rs.period;
   if (rem == 0 && q < rs.ngroups) {
     idx = q * 8u + l;
     return true;
   }
   const uint32_t before = min(q + 1u, rs.ngroups);  // rider groups at or before group g
-  idx = (g - before) * 8u + l;
+  idx = (rs.start + g - before) * 8u + l;
   return false;
 }
 

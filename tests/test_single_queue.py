@@ -42,6 +42,9 @@ POLICIES = [
     ({"rider_slot_count": 0, "rider_slot_scatter": 1, "rider_slot_sort": 2, "rider_slot_emit": 0}, 2),
     ({"rider_period_lookup": 1, "rider_period_forward": 1, "rider_period_update": 1}, 2),
     ({"rider_period_lookup": 64, "rider_period_forward": 64, "rider_period_update": 64}, 2),
+    ({"rider_start_lookup": 100, "rider_start_forward": 50, "rider_start_update": 80, "rider_period_update": 1}, 2),
+    ({"rider_slot_count": 2, "rider_slot_scatter": 2, "rider_slot_sort": 2, "rider_slot_emit": 2, "rider_start_update": 50,
+      "rider_period_update": 1}, 4),
 ]
 
 
@@ -103,6 +106,12 @@ def _same(a, b, what):
             assert np.array_equal(np.asarray(x), np.asarray(y)), "%s[%d]" % (what, i)
 
 
+def _sums(got, ref):
+    """progress sums: dfh_progress holds fp32 sums per batch object, added up here over a different number of objects — equal to fp32 rounding"""
+    for g, r in zip(got, ref):
+        assert g == pytest.approx(r, rel=1e-6), "progress sums"
+
+
 @pytest.mark.parametrize("opts,ahead", POLICIES)
 def test_single_queue_bit_identical_to_serial(capi, opts, ahead):
     """a stream of Criteo-shaped minibatches of one size class (the steady state: splitters stored, every stage rides) —
@@ -115,7 +124,7 @@ def test_single_queue_bit_identical_to_serial(capi, opts, ahead):
     ref = run_stream(capi, batches, kw, 8, 1500, False, {}, 1, nsteps, train)
     got = run_stream(capi, batches, kw, 8, 1500, True, opts, ahead, nsteps, train)
     _same(got[0], ref[0], "pred")
-    assert got[2] == ref[2], "progress sums"
+    _sums(got[2], ref[2])
     _same(list(got[3]), list(ref[3]), "model")
 
 
@@ -133,7 +142,7 @@ def test_single_queue_ragged_sizes_and_consumers(capi, V_dim, binary):
     got = run_stream(capi, batches, kw, V_dim, 400, True, {}, 2, nsteps, train, inspect_every=3)
     _same(got[1], ref[1], "localized")
     _same(got[0], ref[0], "pred")
-    assert got[2] == ref[2], "progress sums"
+    _sums(got[2], ref[2])
     _same(list(got[3]), list(ref[3]), "model")
 
 
