@@ -31,7 +31,7 @@ SYMBOLS = [
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
-    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
+    "dfh_comm_stats", "dfh_comm_info", "dfh_comm_selfcheck", "dfh_comm_wire_probe", "dfh_table_capacity", "dfh_batch_prepare_rows", "dfh_rowbuf_load_host_slices",
     "dfh_batch_create_many", "dfh_shard_multi_words", "dfh_shard_reserve", "dfh_comm_create_loopback", "dfh_comm_loopback_feed", "dfh_comm_loopback_wire", "dfh_comm_loopback_wire_time",
 ]
 XCHG_COUNTS, XCHG_KEYS, XCHG_CNT, XCHG_ROWS, XCHG_GRADS, XCHG_OTHER = range(6)
@@ -192,6 +192,7 @@ def lib():
     L.dfh_comm_stats.argtypes = [vp, i32, vp, vp, vp]
     L.dfh_comm_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.dfh_comm_selfcheck.argtypes = [vp, C.c_double]
+    L.dfh_comm_wire_probe.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.dfh_shard_balanced_splits.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfh_shard_set_exchange.argtypes = [vp, i32]
     L.dfh_shard_reserve.argtypes = [vp, sz, sz]
@@ -750,6 +751,13 @@ class Comm:
         buf = C.create_string_buffer(512)
         _ck(lib().dfh_comm_info(self.h, buf, 512))
         return buf.value.decode()
+
+    def wire_probe(self, bytes_per_peer, reps=20):
+        """microseconds per grouped exchange in which every rank sends bytes_per_peer to (and receives as much from) every
+        other rank; COLLECTIVE"""
+        us = C.c_double(0)
+        _ck(lib().dfh_comm_wire_probe(self.h, int(bytes_per_peer), int(reps), C.byref(us)))
+        return us.value
 
     def selfcheck(self, timeout_s=60.0):
         """collective start-up check (first exchange polled with a timeout): raises instead of hanging"""

@@ -203,6 +203,15 @@ struct dfh_batch {
   bool force_radix = false;        // tests: take the library-sort path of dfh_localize
   bool force_sort_fallback = false;  // tests: k_ss_sort's global-memory path for every bucket
   dfh_table* looked_up = nullptr;  // dfh_batch_lookup already resolved urow against this table
+  // device feed: a minibatch DESCRIBED by dfh_batch_prepare_rows whose rows are still in their row buffers: gathered by the
+  // Localizer's count pass itself (k_loc_count_gather) or, where that pass cannot (first call of a size class, the large size
+  // class, the library sort, a tile spanning too many rows, more than four buffers), by k_gather_rows_staged first
+  struct GatherSeg { struct dfh_rowbuf* rb; size_t at, n; };
+  std::vector<GatherSeg> gsegs;
+  GatherSrc gsrc{};
+  bool gather_pending = false, gather_fusable = false, gather_any_value = false, loc_fuse_gather = false;
+  const uint32_t *g_rows = nullptr, *g_off = nullptr;   // the description as the device sees it (mapped host memory)
+  const float* g_lab = nullptr;
   // single-queue step: the sample sort of the loaded minibatch as noted by dfh_localize (arguments of its four stages) and the
   // first stage that has not been queued yet (RID_STAGES: nothing pending)
   LocView loc_v{};
@@ -482,7 +491,7 @@ int table_reserve(dfh_table* t, uint64_t n) {
     if (rc) return rc;
   }
   if (t->rows_bound + n > v.capacity) {
-    set_error("model table is full: " + std::to_string(t->rows_bound) + " rows + " + std::to_string(n) + " keys exceed 2^29 - 1 rows");
+    set_error("model table is full: " + std::to_string(t->rows_bound) + " rows + " + std::to_string(n) + " keys exceed 2^28 - 1 rows");
     return DFH_ERR_CAPACITY;
   }
   t->rows_bound += n;
@@ -927,6 +936,7 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (!(getenv("DFH_WARM_LOAD") && atoi(getenv("DFH_WARM_LOAD")) == 0)) {   // (0: A/B)
+    try {
     c->warm = std::thread([device] {
       if (hipSetDevice(device) != hipSuccess) return;
       hipStream_t s = nullptr;
@@ -939,6 +949,8 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
       if (d) (void)hipFree(d);
       if (s) (void)hipStreamDestroy(s);
     });
+    } catch (...) {  // no thread to be had: the first launch loads the code object, as before round 5 (nothing crosses the C ABI)
+    }
   }
   *out = c;
   return DFH_OK;
@@ -1140,8 +1152,9 @@ int dfh_memcpy_d2h(dfh_ctx* c, void* dst, const void* src, size_t bytes) {
 int dfh_table_create(dfh_ctx* c, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out) {
   DFH_ARG(c && p && out, "dfh_table_create: NULL argument");
   DFH_ARG(p->V_dim >= 0 && p->V_dim <= 10000, "V_dim out of range [0, 10000] (FMLossParam, fm_loss.h:25)");
-  // the three top bits of a row word carry flags (kRemoteRow, kSingleRow, kCountLater); 2^29 rows of V_dim 64 would be 300 GB
-  DFH_ARG(capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^29), or 0: a table that grows");
+  // the four top bits of a row word carry flags (kRemoteRow, kSingleRow, kCountLater, kHasV); 2^28 rows of V_dim 64 are 150 GB,
+  // of V_dim 128 (C5: 1.25e8 rows per GPU) 296 GB: more than the HBM either way
+  DFH_ARG(capacity_rows <= (uint64_t)kRowMask, "capacity_rows must be in [1, 2^28), or 0: a table that grows");
   const bool auto_grow = capacity_rows == 0;
   if (auto_grow) capacity_rows = (uint64_t)c->grow_initial_rows;  // the first allocation (2^20 rows: 0.6 GB at V_dim 64); doubled as the model grows
   DFH_ARG(p->lr > 0, "lr must be > 0");
@@ -2073,16 +2086,23 @@ static int batch_create_impl(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_ba
   b->d_total = b->d_U + 1;
   // ev_ready / ev_free order streams of ONE device: no system-scope fence (cache write-back + invalidate) at the record
   const unsigned evf = hipEventDisableTiming | (c->event_flags ? hipEventDisableSystemFence : 0u);
-  DFH_HIP(hipEventCreateWithFlags(&b->ev_ready, evf));
-  DFH_HIP(hipEventCreateWithFlags(&b->ev_free, evf));
-  DFH_HIP(hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_BIG_BUCKETS * sizeof(uint32_t), c->stream));  // k_loc_sort keeps it zero between calls
+  // (a failure from here on gives the object — and its reference on a shared arena — back: ADVICE r5)
+  hipError_t e2 = hipEventCreateWithFlags(&b->ev_ready, evf);
+  if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&b->ev_free, evf);
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream);
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream);
+  // k_loc_sort keeps the bucket totals zero between calls
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_BIG_BUCKETS * sizeof(uint32_t), c->stream);
   // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
   // all-ones makes a stray use fault at once instead of reading some row
-  DFH_HIP(hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream));
-  DFH_HIP(hipMemsetAsync(b->d_uw, 0xFF, N * sizeof(uint2), c->stream));
-  if (sync) DFH_HIP(hipStreamSynchronize(c->stream));
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_urow, 0xFF, N * sizeof(uint32_t), c->stream);
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_uw, 0xFF, N * sizeof(uint2), c->stream);
+  if (e2 == hipSuccess && sync) e2 = hipStreamSynchronize(c->stream);
+  if (e2 != hipSuccess) {
+    set_error(std::string("dfh_batch_create: ") + hipGetErrorString(e2));
+    dfh_batch_destroy(b);
+    return DFH_ERR_HIP;
+  }
   *out = b;
   return DFH_OK;
 }
@@ -2106,22 +2126,23 @@ int dfh_batch_create_many(dfh_ctx* c, int n, size_t max_rows, size_t max_nnz, df
     return DFH_ERR_HIP;
   }
   for (int i = 0; i < n; ++i) out[i] = nullptr;
-  for (int i = 0; i < n; ++i) {
-    rc = batch_create_impl(c, max_rows, max_nnz, &out[i], sa, each * (size_t)i, nullptr, false);
-    if (rc) {
-      for (int j = 0; j < i; ++j) {
-        dfh_batch_destroy(out[j]);
-        out[j] = nullptr;
-      }
-      if (sa->refs == 0) {
-        hipFree(sa->base);
-        delete sa;
-      }
-      return rc;
+  sa->refs = 1;  // this call's own reference: the arena outlives every failure path below
+  for (int i = 0; i < n && !rc; ++i) rc = batch_create_impl(c, max_rows, max_nnz, &out[i], sa, each * (size_t)i, nullptr, false);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) {   // the objects' memsets
+    set_error("dfh_batch_create_many: hipStreamSynchronize failed");
+    rc = DFH_ERR_HIP;
+  }
+  if (rc) {
+    for (int j = 0; j < n; ++j) {
+      if (out[j]) dfh_batch_destroy(out[j]);
+      out[j] = nullptr;
     }
   }
-  DFH_HIP(hipStreamSynchronize(c->stream));   // the objects' memsets
-  return DFH_OK;
+  if (--sa->refs == 0) {  // no object holds it (every creation failed)
+    hipFree(sa->base);
+    delete sa;
+  }
+  return rc;
 }
 
 int dfh_batch_destroy(dfh_batch* b) {
@@ -2547,12 +2568,92 @@ int dfh_batch_gather_rows(dfh_batch* b, size_t nrows, const size_t* offset, cons
 }
 
 namespace {
+// dfh_batch_prepare_rows: the description of the minibatch (row numbers, offsets, labels) is read where the host wrote it —
+// page-locked host memory mapped into the device's address space — 256 rows per block, coalesced, and passed on: the
+// minibatch's own offsets / labels land in HBM by the same kernel that gathers its rows, no copy is queued.
+__global__ void __launch_bounds__(256) k_gather_rows_staged(const uint32_t* __restrict__ src_off, const uint64_t* __restrict__ src_idx,
+                                                            const float* __restrict__ src_val, const uint32_t* __restrict__ h_rows,
+                                                            const uint32_t* __restrict__ h_off, const float* __restrict__ h_lab, uint32_t n,
+                                                            uint32_t* __restrict__ dst_off, float* __restrict__ dst_lab,
+                                                            uint64_t* __restrict__ dst_idx, float* __restrict__ dst_val, int write_end) {
+  // GR rows per block and pass: few enough that a minibatch spreads over the whole chip (10 000 rows = 313 blocks; 256
+  // rows per block left 216 of the 256 CUs idle and took 92 us), enough that the description is read in 128 B pieces
+  constexpr uint32_t GR = 32;
+  __shared__ uint32_t s_lo[GR], s_len[GR], s_d0[GR];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  for (uint32_t q0 = blockIdx.x * GR; q0 < n; q0 += gridDim.x * GR) {
+    const uint32_t m = min(GR, n - q0);
+    __syncthreads();
+    if (threadIdx.x < m) {
+      const uint32_t q = q0 + threadIdx.x;
+      const uint32_t r = h_rows[q], o = h_off[q];
+      const uint32_t lo = src_off[r];
+      s_lo[threadIdx.x] = lo;
+      s_len[threadIdx.x] = src_off[r + 1] - lo;
+      s_d0[threadIdx.x] = o;
+      dst_off[q] = o;
+      dst_lab[q] = h_lab[q];
+    }
+    if (threadIdx.x == 255 && write_end && q0 + m == n) dst_off[n] = h_off[n];
+    __syncthreads();
+    for (uint32_t t = w; t < m; t += 4u) {   // 8 rows per wave, independent addresses: the copies overlap
+      const uint32_t lo = s_lo[t], len = s_len[t], d0 = s_d0[t];
+      for (uint32_t j = lane; j < len; j += 64u) {
+        dst_idx[d0 + j] = src_idx[lo + j];
+        if (dst_val) dst_val[d0 + j] = src_val ? src_val[lo + j] : 1.0f;   // a buffer without values holds ones
+      }
+    }
+  }
+}
+}  // namespace
+
+namespace {
+// after the launch(es) that read a described minibatch's rows out of their buffers have been queued on s: the buffers may be
+// refilled, the page-locked description rewritten, once those launches are through
+int gather_queued(dfh_batch* b, hipStream_t s) {
+  for (const auto& g : b->gsegs) {
+    dfh_rowbuf* rb = g.rb;
+    std::lock_guard<std::mutex> lk(rb->mu);
+    dfh_rowbuf::Used* u = nullptr;
+    for (auto& x : rb->used)
+      if (x.stream == s) u = &x;
+    if (!u) {
+      hipEvent_t ev = nullptr;
+      DFH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      rb->used.push_back({s, ev, false});
+      u = &rb->used.back();
+    }
+    DFH_HIP(hipEventRecord(u->ev, s));
+    u->pending = true;
+  }
+  DFH_HIP(hipEventRecord(b->ev_staged, s));   // the page-locked block may be rewritten once the launches have read it
+  b->staged_pending = true;
+  b->gather_pending = false;
+  return DFH_OK;
+}
+// the rows of a described minibatch by launches of their own (k_gather_rows_staged): where the count pass cannot gather
+int gather_alone(dfh_batch* b, hipStream_t s) {
+  for (const auto& g : b->gsegs) {
+    dfh_rowbuf* rb = g.rb;
+    const unsigned blocks = (unsigned)std::min<size_t>((g.n + 31) / 32, 2048);
+    hipLaunchKernelGGL(k_gather_rows_staged, dim3(blocks), dim3(256), 0, s, rb->d_off, rb->d_idx,
+                       rb->has_value ? rb->d_val : (const float*)nullptr, b->g_rows + g.at, b->g_off + g.at, b->g_lab + g.at, (uint32_t)g.n,
+                       b->d_offset + g.at, b->d_label + g.at, b->d_raw, b->gather_any_value ? b->d_value : (float*)nullptr,
+                       g.at + g.n == b->nrows ? 1 : 0);
+  }
+  DFH_HIP(hipGetLastError());
+  return gather_queued(b, s);
+}
+}  // namespace
+
+namespace {
 // one stage (RiderKind) of the noted sample sort of b's minibatch as a launch of its own on stream s
 void launch_loc_stage(dfh_batch* b, int stage, hipStream_t s, dfh_table* probe = nullptr) {
   const LocView& v = b->loc_v;
   switch (stage) {
     case RID_COUNT:
       if (b->loc_big) hipLaunchKernelGGL(k_loc_count<LOC_BIG_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
+      else if (b->loc_fuse_gather) hipLaunchKernelGGL(k_loc_count_gather<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v, b->gsrc);
       else hipLaunchKernelGGL(k_loc_count<LOC_MAX_BUCKETS>, dim3(v.ntiles), dim3(LOC_TILE_THREADS), 0, s, v);
       break;
     case RID_SCATTER:
@@ -2634,6 +2735,7 @@ void collect_riders(dfh_ctx* c, int slot, bool can_ride, uint32_t main_groups, R
   }
   c->pend.erase(std::remove_if(c->pend.begin(), c->pend.end(), [](dfh_batch* p) { return p->pend_stage >= RID_STAGES; }), c->pend.end());
   rs->ngroups = rs->first[rs->n] / 8u;
+  for (uint32_t q = rs->n + 1; q <= (uint32_t)MAX_RIDERS; ++q) rs->first[q] = rs->first[rs->n];  // (run_rider: no rider beyond n - 1)
   if (rs->ngroups) {
     // every rider group needs a place: the last one sits at group (ngroups - 1) * period of main_groups + ngroups
     rs->start = (uint32_t)((uint64_t)main_groups * (uint64_t)c->rider_start[slot] / 100u);
@@ -2664,6 +2766,10 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     if (rc) return rc;
   }
   if (N == 0) {
+    if (b->gather_pending) {  // rows without a single feature: their offsets and labels still have to arrive
+      int rcg = gather_alone(b, s);
+      if (rcg) return rcg;
+    }
     // reference would index an empty vector (localizer.cc:35); define: no keys
     DFH_HIP(hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), s));  // U = 0
     DFH_HIP(hipMemsetAsync(b->d_col_ptr, 0, 4, s));
@@ -2695,6 +2801,15 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     else if (N / LOC_MAX_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_MAX_BUCKETS;
     else if (P_want <= (size_t)LOC_BIG_BUCKETS) P = (int)P_want;
     else if (N / LOC_BIG_BUCKETS <= (uint32_t)LOC_MAX_AVG) P = LOC_BIG_BUCKETS;
+  }
+  // a described minibatch (device feed): the count pass of the small size class gathers the rows itself; everywhere else —
+  // a first call samples the raw ids before anything is counted, the large size class has no LDS to spare, the library sort
+  // has no count pass, the single-queue step may run the count pass much later — the gather is queued here, first
+  b->loc_fuse_gather = b->gather_pending && b->gather_fusable && !cold && P > 0 && P <= LOC_MAX_BUCKETS && !b->force_radix &&
+                       !c->single_queue && !getenv("DFH_GATHER_ALONE");
+  if (b->gather_pending && !b->loc_fuse_gather) {
+    int rcg = gather_alone(b, s);
+    if (rcg) return rcg;
   }
   if (P > 0 && !b->force_radix) {
     // hand-written sample sort (dfh_localize.hip)
@@ -2761,7 +2876,14 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
       b->pend_stage = 0;
       c->pend.push_back(b);
     } else {
-      for (int st = 0; st < RID_STAGES; ++st) launch_loc_stage(b, st, s, probe);
+      for (int st = 0; st < RID_STAGES; ++st) {
+        launch_loc_stage(b, st, s, probe);
+        if (st == RID_COUNT && b->loc_fuse_gather) {  // the rows have been read once this launch is through
+          int rcg = gather_queued(b, s);
+          b->loc_fuse_gather = false;
+          if (rcg) return rcg;
+        }
+      }
     }
     b->spl_P = P;  // k_loc_emit leaves this minibatch's exact P-quantiles as the next call's splitters
     b->seg_nb = (uint32_t)P;
@@ -2794,45 +2916,6 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
 }
 }  // namespace
 
-namespace {
-// dfh_batch_prepare_rows: the description of the minibatch (row numbers, offsets, labels) is read where the host wrote it —
-// page-locked host memory mapped into the device's address space — 256 rows per block, coalesced, and passed on: the
-// minibatch's own offsets / labels land in HBM by the same kernel that gathers its rows, no copy is queued.
-__global__ void __launch_bounds__(256) k_gather_rows_staged(const uint32_t* __restrict__ src_off, const uint64_t* __restrict__ src_idx,
-                                                            const float* __restrict__ src_val, const uint32_t* __restrict__ h_rows,
-                                                            const uint32_t* __restrict__ h_off, const float* __restrict__ h_lab, uint32_t n,
-                                                            uint32_t* __restrict__ dst_off, float* __restrict__ dst_lab,
-                                                            uint64_t* __restrict__ dst_idx, float* __restrict__ dst_val, int write_end) {
-  // GR rows per block and pass: few enough that a minibatch spreads over the whole chip (10 000 rows = 313 blocks; 256
-  // rows per block left 216 of the 256 CUs idle and took 92 us), enough that the description is read in 128 B pieces
-  constexpr uint32_t GR = 32;
-  __shared__ uint32_t s_lo[GR], s_len[GR], s_d0[GR];
-  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  for (uint32_t q0 = blockIdx.x * GR; q0 < n; q0 += gridDim.x * GR) {
-    const uint32_t m = min(GR, n - q0);
-    __syncthreads();
-    if (threadIdx.x < m) {
-      const uint32_t q = q0 + threadIdx.x;
-      const uint32_t r = h_rows[q], o = h_off[q];
-      const uint32_t lo = src_off[r];
-      s_lo[threadIdx.x] = lo;
-      s_len[threadIdx.x] = src_off[r + 1] - lo;
-      s_d0[threadIdx.x] = o;
-      dst_off[q] = o;
-      dst_lab[q] = h_lab[q];
-    }
-    if (threadIdx.x == 255 && write_end && q0 + m == n) dst_off[n] = h_off[n];
-    __syncthreads();
-    for (uint32_t t = w; t < m; t += 4u) {   // 8 rows per wave, independent addresses: the copies overlap
-      const uint32_t lo = s_lo[t], len = s_len[t], d0 = s_d0[t];
-      for (uint32_t j = lane; j < len; j += 64u) {
-        dst_idx[d0 + j] = src_idx[lo + j];
-        if (dst_val) dst_val[d0 + j] = src_val ? src_val[lo + j] : 1.0f;   // a buffer without values holds ones
-      }
-    }
-  }
-}
-}  // namespace
 
 int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_t* offset, const float* label, int nseg,
                            dfh_rowbuf* const* bufs, const uint32_t* const* rows, const size_t* seg_rows, uint64_t max_index) {
@@ -2868,7 +2951,8 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   const size_t o_off = 0, o_lab = (b->max_rows + 1) * 4, o_idx = ((o_lab + b->max_rows * 4 + 255) & ~(size_t)255),
                o_val = o_idx + b->max_nnz * 8, stage_total = o_val + b->max_nnz * 4;
   (void)stage_total;   // (the layout of dfh_batch_load_host; only the head of it is used here)
-  rc = ensure_stage(b, o_idx + (b->max_rows + 1) * 4);
+  const size_t o_tile = o_idx + (b->max_rows + 1) * 4;   // the tiles' first rows (k_loc_count_gather), behind the row numbers
+  rc = ensure_stage(b, o_tile + (b->max_tiles + 2) * 4);
   if (rc) return rc;
   if (!b->d_stage_view) DFH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_stage_view), b->h_stage, 0));
   lap(0);  // set-up, prep_begin (wait for the batch object's previous step)
@@ -2901,6 +2985,9 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
   const uint32_t* v_off = reinterpret_cast<const uint32_t*>(b->d_stage_view + o_off);
   const float* v_lab = reinterpret_cast<const float*>(b->d_stage_view + o_lab);
   const uint32_t* v_rows = reinterpret_cast<const uint32_t*>(b->d_stage_view + o_idx);
+  // the rows stay where they are for now: the Localizer's count pass gathers them as it reads them (k_loc_count_gather), or
+  // localize_impl queues k_gather_rows_staged first where that pass cannot (see dfh_batch::gsegs)
+  b->gsegs.clear();
   at = 0;
   for (int g = 0; g < nseg; ++g) {
     dfh_rowbuf* rb = bufs[g];
@@ -2912,30 +2999,52 @@ int dfh_batch_prepare_rows(dfh_table* t, dfh_batch* b, size_t nrows, const size_
       if (!waited) rb->seen_loaded.push_back(s);
     }
     if (!waited) DFH_HIP(hipStreamWaitEvent(s, rb->ev_loaded, 0));
-    const unsigned blocks = (unsigned)std::min<size_t>((seg_rows[g] + 31) / 32, 2048);
-    hipLaunchKernelGGL(k_gather_rows_staged, dim3(blocks), dim3(256), 0, s, rb->d_off, rb->d_idx,
-                       rb->has_value ? rb->d_val : (const float*)nullptr, v_rows + at, v_off + at, v_lab + at, (uint32_t)seg_rows[g],
-                       b->d_offset + at, b->d_label + at, b->d_raw, any_value ? b->d_value : (float*)nullptr,
-                       at + seg_rows[g] == nrows ? 1 : 0);
-    {
-      std::lock_guard<std::mutex> lk(rb->mu);
-      dfh_rowbuf::Used* u = nullptr;
-      for (auto& x : rb->used)
-        if (x.stream == s) u = &x;
-      if (!u) {
-        hipEvent_t ev = nullptr;
-        DFH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        rb->used.push_back({s, ev, false});
-        u = &rb->used.back();
-      }
-      DFH_HIP(hipEventRecord(u->ev, s));
-      u->pending = true;
-    }
+    b->gsegs.push_back({rb, at, seg_rows[g]});
     at += seg_rows[g];
   }
-  DFH_HIP(hipEventRecord(b->ev_staged, s));   // the page-locked block may be rewritten once the gathers have read it
-  b->staged_pending = true;
-  DFH_HIP(hipGetLastError());
+  b->g_rows = v_rows;
+  b->g_off = v_off;
+  b->g_lab = v_lab;
+  b->gather_any_value = any_value;
+  b->gather_pending = true;
+  // what the count pass needs on top: the first row of every tile of LOC_TILE positions (the last row that starts at or before
+  // the tile), behind the row numbers in the same page-locked block; a tile may span LOC_GATHER_ROWS rows, a minibatch
+  // LOC_GATHER_SEGS buffers
+  {
+    GatherSrc& gs = b->gsrc;
+    const size_t ntiles = (nnz + LOC_TILE - 1) / LOC_TILE;
+    uint32_t* h_tile = reinterpret_cast<uint32_t*>(b->h_stage + o_tile);
+    bool ok = nnz > 0 && b->gsegs.size() <= (size_t)LOC_GATHER_SEGS;
+    size_t r = 0;
+    for (size_t t = 0; t < ntiles && ok; ++t) {
+      const uint32_t p = (uint32_t)(t * LOC_TILE);
+      while (r + 1 < nrows && h_off[r + 1] <= p) ++r;   // the last row with off[r] <= p
+      h_tile[t] = (uint32_t)r;
+      if (t > 0 && r - h_tile[t - 1] + 1 > (size_t)LOC_GATHER_ROWS) ok = false;
+    }
+    if (ok) {
+      h_tile[ntiles] = (uint32_t)nrows;
+      if (nrows - h_tile[ntiles - 1] > (size_t)LOC_GATHER_ROWS) ok = false;   // (the last tile's rows, trailing empty ones included)
+    }
+    b->gather_fusable = ok;
+    gs.nseg = (int)b->gsegs.size();
+    for (int g = 0; g <= LOC_GATHER_SEGS; ++g) gs.seg_row0[g] = (uint32_t)nrows;
+    for (int g = 0; g < LOC_GATHER_SEGS; ++g) {
+      const bool have = g < gs.nseg && ok;
+      gs.seg_row0[g] = have ? (uint32_t)b->gsegs[g].at : (uint32_t)nrows;
+      gs.src_off[g] = have ? b->gsegs[g].rb->d_off : nullptr;
+      gs.src_idx[g] = have ? b->gsegs[g].rb->d_idx : nullptr;
+      gs.src_val[g] = (have && b->gsegs[g].rb->has_value) ? b->gsegs[g].rb->d_val : nullptr;
+    }
+    gs.h_rows = v_rows;
+    gs.h_off = v_off;
+    gs.h_lab = v_lab;
+    gs.h_tile_row = reinterpret_cast<const uint32_t*>(b->d_stage_view + o_tile);
+    gs.dst_raw = b->d_raw;
+    gs.dst_val = any_value ? b->d_value : nullptr;
+    gs.dst_off = b->d_offset;
+    gs.dst_lab = b->d_label;
+  }
   b->nrows = nrows;
   b->nnz = nnz;
   b->has_value = any_value;

@@ -77,11 +77,16 @@ struct SegLists {
 };
 
 // flag bits of the row word k_lookup / k_uw_remote leave per unique key in uw[]: a table holds fewer
-// than 2^29 rows (dfh_table_create), so the three top bits are free
+// than 2^28 rows (dfh_table_create), so the four top bits are free
 constexpr uint32_t kRemoteRow = 0x80000000u;  // the row is in the pulled-rows buffer, not in the table (sharded store)
 constexpr uint32_t kSingleRow = 0x40000000u;  // the key occurs exactly once in this minibatch
 constexpr uint32_t kCountLater = 0x20000000u; // k_lookup left this key's Push(kFeaCount) to the step's update kernel
-constexpr uint32_t kRowMask = 0x1FFFFFFFu;
+// the key HAS its V (SGDEntry::V != nullptr as of this step's Pull, sgd_updater.cc:47-52): the forward multiplies a key's V row by
+// its feature value iff this bit is set — SpMM::Times skips a key without V (V_pos = -1, spmm.h:108) and does NOT skip an
+// allocated row that happens to hold zeros (round 6; until then the forward tested the loaded 16 B slice for all-zero instead,
+// which made an allocated all-zero slice times an Inf / NaN value neutral where the reference gives NaN)
+constexpr uint32_t kHasV = 0x10000000u;
+constexpr uint32_t kRowMask = 0x0FFFFFFFu;
 
 // "row source" seen by the forward / backward kernels: either the table
 // itself (rows addressed through urow[u]) or a packed [U x stride] buffer of

@@ -66,10 +66,11 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
 // acc + a * b the way SpMV does it (src/common/spmv.h:125, :155): an operand `a` that is exactly zero is SKIPPED, not
 // multiplied.  Neutral for finite b; for b = Inf / NaN (a non-finite feature value) it is the difference between the
 // reference's result and NaN: a zero weight (pulled as 0: no entry yet, or clipped by l1) and a slope that underflowed to 0
-// do not see the value at all.  The forward treats V rows likewise, slice by slice: a key WITHOUT V is skipped by SpMM
-// (V_pos = -1, spmm.h:108) and is an all-zero row here; a lane whose 16 B slice of a row is all zero multiplies by x = 0
-// instead of the value (k_forward).  The one case left apart: an ALLOCATED row four consecutive coordinates of which
-// are exactly 0.0, times a non-finite value — NaN in the reference, neutral here.
+// do not see the value at all.  V rows: a key WITHOUT V is skipped by SpMM (V_pos = -1, spmm.h:108) and is an all-zero row
+// here, loaded speculatively; the forward multiplies it by x = 0 instead of the value, decided by the key's has-V flag
+// (kHasV in its row word, the header flag of packed rows) — an ALLOCATED row is used whatever it holds, as in the reference
+// (round 6: the test of the loaded slice for all-zero that stood in for the flag through round 5 is gone, and with it the
+// one documented deviation).
 __device__ __forceinline__ float fma_skip0(float a, float b, float acc) { return a != 0.f ? __builtin_fmaf(a, b, acc) : acc; }
 
 // The sharding-independent V init: must match oracle/difacto_oracle.c:orc_hash_init_value
@@ -442,9 +443,11 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
   for (uint32_t u = bid * blockDim.x + threadIdx.x; u < n; u += nblk * blockDim.x) {
     uint64_t key = keys[u];
     // rows_known: urow was filled by an earlier (prep-stream) lookup of the same keys
-    uint32_t r = rows_known ? urow[u] : find_or_insert(t, key);
+    // (rows_known: a row word of k_resolve_multi may carry its worker mark in bit 31 — dfh_shard_push_count_resolved)
+    uint32_t r = rows_known ? (urow[u] & kRowMask) : find_or_insert(t, key);
     if (urow && !rows_known) urow[u] = r;
     float w = 0.f;
+    bool hasv = false;
     if (push_cnt) {
       float c = cnt ? cnt[u] : (float)(col_ptr[u + 1] - col_ptr[u]);
       RowHdr& h = t.hdr[r];
@@ -454,23 +457,27 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
       // (sgd_updater.cc:62-73, :122-126) — so the value is the same and this pass stays read-only for it.
       if (push_cnt == 2 && uw && h.has_V != 0) {
         if (need_init) need_init[u] = 0u;
-        uw[u] = make_uint2(r | kCountLater | ((col_ptr != nullptr && col_ptr[u + 1] - col_ptr[u] == 1u) ? kSingleRow : 0u),
+        uw[u] = make_uint2(r | kCountLater | kHasV | ((col_ptr != nullptr && col_ptr[u + 1] - col_ptr[u] == 1u) ? kSingleRow : 0u),
                            __float_as_uint(w));
         continue;
       }
       float fc = h.fea_cnt + c;
       h.fea_cnt = fc;
-      bool init = t.k > 0 && h.has_V == 0 && w != 0 && fc > (float)t.p.V_threshold;
+      hasv = h.has_V != 0;
+      bool init = t.k > 0 && !hasv && w != 0 && fc > (float)t.p.V_threshold;
       if (t.p.init_mode == DFH_INIT_HASH) {
         if (init) {
           init_v_hash_row(t, r, key);
           h.has_V = 1;
         }
       } else if (need_init) {
-        need_init[u] = init ? 1u : 0u;
+        need_init[u] = init ? 1u : 0u;   // (REFRAND: the row is written by k_refrand_init right after this launch, before the forward)
       }
+      hasv = hasv || init;   // InitV at count-push time (sgd_updater.cc:69-72): this step's Pull sees the new V
     } else if (uw) {
-      w = t.hdr[r].w;
+      const uint2 wh = *reinterpret_cast<const uint2*>(&t.hdr[r]);  // {w, has_V}: one 8 B load
+      w = __uint_as_float(wh.x);
+      hasv = wh.y != 0u;
     }
     // {row, w} per unique key, batch-local and L2-resident: the forward then touches nothing of a
     // row but its V lines (the weight is read here once per KEY instead of once per nonzero)
@@ -478,7 +485,7 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
     // example, without the key-ordered view)
     if (uw) {
       const bool single = col_ptr != nullptr && col_ptr[u + 1] - col_ptr[u] == 1u;
-      uw[u] = make_uint2(r | (single ? kSingleRow : 0u), __float_as_uint(w));
+      uw[u] = make_uint2(r | (single ? kSingleRow : 0u) | (hasv ? kHasV : 0u), __float_as_uint(w));
     }
   }
 }
@@ -506,7 +513,8 @@ __device__ __forceinline__ void uw_remote_body(const UwRemote& m) {
     if (u - m.lo < m.hi - m.lo) continue;
     // (bit 30: the key occurs once in the minibatch — the singles role of the mixed update launch takes it)
     const uint32_t single = (m.col_ptr && m.col_ptr[u + 1] - m.col_ptr[u] == 1u) ? kSingleRow : 0u;
-    m.uw[u] = make_uint2(u | kRemoteRow | single, __float_as_uint(m.rows[(size_t)u * m.stride]));
+    const float2 wh = *reinterpret_cast<const float2*>(m.rows + (size_t)u * m.stride);   // [w, has_V (0 / 1 as float), ...]
+    m.uw[u] = make_uint2(u | kRemoteRow | single | (wh.y != 0.f ? kHasV : 0u), __float_as_uint(wh.x));
   }
 }
 __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,
@@ -642,8 +650,8 @@ __device__ __forceinline__ void forward_body(const BatchView& b, const RowSrc& s
           // {row, w} of the key from the batch-local table k_lookup left in L2: no header access;
           // a row without V holds zeros, so its flag is not needed either
           const uint2 e = b.uw[b.index[j]];
-          r = e.x & ~(kSingleRow | kCountLater);
-          hv = 1u;
+          r = e.x & (kRowMask | kRemoteRow);
+          hv = e.x & kHasV;   // SpMM::Times skips a key without V (spmm.h:108); an allocated row is used whatever it holds
           wsum = fma_skip0(__uint_as_float(e.y), x, wsum);  // spmv.h:125
         } else {
           const uint32_t u = b.index[j];
@@ -680,12 +688,9 @@ __device__ __forceinline__ void forward_body(const BatchView& b, const RowSrc& s
           }
 #pragma unroll
           for (int q = 0; q < FWD_DEPTH; ++q) {
-            // a key WITHOUT V is skipped by SpMM (V_pos = -1, spmm.h:108); here it is a row of zeros that was loaded
-            // speculatively: a slice that is all zero takes x = 0, so that an Inf / NaN feature value on such a key gives
-            // 0 * 0 and not NaN.  (One test per 16 B slice, not per coordinate: per-coordinate selects cost the forward
-            // 1.4 us of 20.)
-            const uint32_t any = (__float_as_uint(v[q].x) | __float_as_uint(v[q].y) | __float_as_uint(v[q].z) | __float_as_uint(v[q].w)) << 1;
-            const float xx = any ? xs[q] : 0.f;
+            // a key WITHOUT V is skipped by SpMM (V_pos = -1, spmm.h:108): its x is 0 here (xs[q], from the key's has-V flag),
+            // so that an Inf / NaN feature value on such a key meets the speculatively loaded row of zeros as 0 * 0, not as NaN
+            const float xx = xs[q];
             xv.x += v[q].x * xx; xv.y += v[q].y * xx; xv.z += v[q].z * xx; xv.w += v[q].w * xx;
             const float x2 = xx * xx;
             xxvv.x += (v[q].x * v[q].x) * x2; xxvv.y += (v[q].y * v[q].y) * x2;
@@ -1487,7 +1492,7 @@ __global__ void __launch_bounds__(256) k_pull_resolved(TableView t, const uint32
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   for (uint32_t u = group; u < n; u += ngroups) {
-    const uint32_t r = rowid[u] & 0x1FFFFFFFu;  // (k_resolve_multi marks a key's worker entry in bit 31)
+    const uint32_t r = rowid[u] & kRowMask;  // (k_resolve_multi marks a key's worker entry in bit 31)
     const float4 h0 = ld4(reinterpret_cast<const float*>(t.hdr + r));  // {w, has_V, sqrt_g, z}
     const bool hv = __float_as_uint(h0.y) != 0u;
     float* out = rows + (size_t)u * stride;
@@ -1508,7 +1513,7 @@ __global__ void __launch_bounds__(256) k_push_grad_resolved(TableView t, const u
   const uint32_t group = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GPW + lane / L;
   const uint32_t ngroups = ((gridDim.x * blockDim.x) >> 6) * GPW;
   for (uint32_t u = group; u < n; u += ngroups) {
-    const uint32_t r = rowid[u] & 0x1FFFFFFFu;
+    const uint32_t r = rowid[u] & kRowMask;
     const float* g = grads + (size_t)u * stride;
     const float4 g0 = ld4(g);
     const bool had_v = g0.y != 0.0f;
@@ -1575,7 +1580,7 @@ struct SegOff {
   int slot;          // which of the two per-row step words (RowHdr::pad[0..1]) this step uses: two steps
                      // may be in flight on an owner (one resolved and pulled, the other awaiting its gradients)
 };
-constexpr uint32_t ROW_ID_MASK = 0x1FFFFFFFu;  // a table holds fewer than 2^29 rows
+constexpr uint32_t ROW_ID_MASK = kRowMask;  // a table holds fewer than 2^28 rows
 constexpr uint32_t ROW_WORKER = 0x80000000u;
 constexpr int MULTI_FAST = 8;                  // entries per key ordered in registers (one node: 7 peers)
 __host__ __device__ __forceinline__ uint32_t multi_xs(int nsrc) { return (uint32_t)((nsrc - 1 + 3) / 4 * 4 > 0 ? (nsrc - 1 + 3) / 4 * 4 : 4); }
@@ -1590,14 +1595,28 @@ __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, 
     const uint32_t r = find_or_insert(t, keys[e]);
     uint32_t* word = &t.hdr[r].pad[g.slot];
     uint32_t old = atomicCAS(word, 0u, (e + 1) << 5);
-    if (old != 0u) {  // the key has its worker: take a place among its extras
-      old = atomicAdd(word, 1u);
-      // (a source's list is unique, so a key has at most nsrc - 1 <= XS extras; a list with a repeated key is a caller's
-      // error: flagged like a duplicate key instead of writing past the worker's extras)
-      if ((old & 31u) < XS) extra[(size_t)((old >> 5) - 1u) * XS + (old & 31u)] = e;
-      else atomicOr(t.err, 2u);
+    const bool worker = old == 0u;
+    if (!worker) {  // the key has its worker: take a place among its extras
+      // A source's list is unique, so a key has at most nsrc - 1 <= XS extras.  More entries on one row are an error of the
+      // caller (a list that repeats a key) or a table that overflowed (find_or_insert parks every key beyond the capacity on
+      // the last row): flagged, and the count SATURATES — the Push kernels are queued before the host reads the error word,
+      // and a count beyond the extras (or a carry out of the low five bits into the worker's index) would have them read
+      // indices that were never written.
+      const uint32_t lim = (uint32_t)(g.nsrc - 1);
+      for (;;) {
+        if ((old & 31u) >= lim) {
+          atomicOr(t.err, 2u);
+          break;
+        }
+        const uint32_t seen = atomicCAS(word, old, old + 1u);
+        if (seen == old) {
+          extra[(size_t)((old >> 5) - 1u) * XS + (old & 31u)] = e;
+          break;
+        }
+        old = seen;
+      }
     }
-    rowid[e] = r | (old == 0u ? ROW_WORKER : 0u);
+    rowid[e] = r | (worker ? ROW_WORKER : 0u);
   }
 }
 
@@ -1623,7 +1642,7 @@ __global__ void k_push_count_multi(TableView t, const uint32_t* __restrict__ row
     const uint32_t r = rw & ROW_ID_MASK;
     RowHdr& h = t.hdr[r];
     float fc = h.fea_cnt + cnt[e];
-    const uint32_t m = h.pad[g.slot] & 31u;
+    const uint32_t m = min(h.pad[g.slot] & 31u, XS);
     for (uint32_t i = 0; i < m; ++i) fc += cnt[extra[(size_t)e * XS + i]];
     h.fea_cnt = fc;
     if (t.k > 0 && h.has_V == 0 && h.w != 0 && fc > (float)t.p.V_threshold) {
@@ -1710,7 +1729,7 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
         adagrad_update_v(gv.w, v.w, acc.w, t.p);
       }
     };
-    const uint32_t m = word & 31u;  // entries of this key besides the worker's own
+    const uint32_t m = min(word & 31u, XS);  // entries of this key besides the worker's own
     if (m == 0) {                   // the usual case: one source carries the key
       apply(go0.x, go_v);
     } else if (m < MULTI_FAST) {

@@ -260,6 +260,40 @@ __global__ void __launch_bounds__(256) k_loc_splitters(LocView v) {
 // ---------------------------------------------------------------------------------------
 // count: bucket + rank-in-(tile, bucket) of every pair; the tile's runs reserve their places
 // ---------------------------------------------------------------------------------------
+// Device feed (dfh_batch_prepare_rows): the minibatch is DESCRIBED — row numbers into device-resident row buffers (the shuffle
+// buffers of BatchReader, src/reader/batch_reader.cc:29-78), its own offsets and labels, all in page-locked host memory the
+// device reads in place — and k_loc_count gathers it while it counts: a tile takes the rows that cover its 2048 positions
+// (the host, which wrote the offsets, also wrote the first row of every tile), stages their {offset, source position} in
+// LDS, reads every pair's raw id straight out of the row buffer and leaves it in the minibatch's own array for
+// k_loc_scatter.  Until round 6 a launch of its own (k_gather_rows_staged, 16 us at C3 size) opened the preparation chain.
+constexpr int LOC_GATHER_ROWS = 1024;   // rows a tile may span (the host checks; beyond: the gather runs as its own launch)
+constexpr int LOC_GATHER_SEGS = 4;      // row buffers one minibatch may draw from
+struct GatherSrc {
+  int nseg;                                // 0: no gather (v.raw holds the minibatch already)
+  uint32_t seg_row0[LOC_GATHER_SEGS + 1];  // rows [seg_row0[g], seg_row0[g + 1]) of the minibatch come from buffer g
+  const uint32_t* src_off[LOC_GATHER_SEGS];
+  const uint64_t* src_idx[LOC_GATHER_SEGS];
+  const float* src_val[LOC_GATHER_SEGS];   // NULL: a buffer without values holds ones
+  const uint32_t* h_rows;     // [nrows] row numbers inside their buffers   (page-locked host memory, mapped)
+  const uint32_t* h_off;      // [nrows + 1] the minibatch's own offsets    (likewise)
+  const float* h_lab;         // [nrows]                                    (likewise)
+  const uint32_t* h_tile_row; // [ntiles + 1] first row whose range reaches into the tile; [ntiles] = nrows   (likewise)
+  uint64_t* dst_raw;          // the minibatch's arrays in HBM
+  float* dst_val;             // or NULL (no buffer of the minibatch carries values)
+  uint32_t* dst_off;
+  float* dst_lab;
+};
+constexpr size_t loc_gather_smem() { return (size_t)(LOC_GATHER_ROWS + 1) * 4 + 4 + (size_t)LOC_GATHER_ROWS * 8; }
+// a[sg] of a small array inside a by-value kernel argument: compile-time indices and selects (a run-time index would make the
+// compiler copy the whole argument struct into scratch)
+template <typename T>
+__device__ __forceinline__ T loc_sel(const T (&a)[LOC_GATHER_SEGS], uint32_t sg) {
+  T r = a[0];
+#pragma unroll
+  for (int x = 1; x < LOC_GATHER_SEGS; ++x) r = sg == (uint32_t)x ? a[x] : r;
+  return r;
+}
+
 // Every stage below is a BLOCK FUNCTION: block `bid` of `nblk` of its stage, THREADS threads, working memory carved out of
 // `smem` — so that a stage can run as a launch of its own (the k_loc_* wrappers) or as a RIDER: a block range of a launch
 // that exists anyway (k_lookup / k_forward / k_update_fused of an earlier minibatch's step, dfh_riders.h), which is how the
@@ -271,8 +305,9 @@ constexpr size_t loc_scatter_smem() { return (size_t)MAXB * 4 + (THREADS / 64) *
 constexpr size_t loc_sort_smem() { return (size_t)LOC_LDS_CAP * 24 + 2 * (LOC_SORT_THREADS / 64) * 4; }
 constexpr size_t loc_emit_smem() { return (2 * (LOC_EMIT_THREADS / 64) + 4) * 4; }
 
-template <int MAXB, int THREADS>
-__device__ __forceinline__ void loc_count_block(const LocView& v, const uint32_t bid, const uint32_t nblk, char* smem) {
+template <int MAXB, int THREADS, bool GATHER = false>
+__device__ __forceinline__ void loc_count_block(const LocView& v, const uint32_t bid, const uint32_t nblk, char* smem,
+                                                const GatherSrc* gp = nullptr) {
   constexpr int PER = LOC_TILE / THREADS;
   static_assert(PER * THREADS == LOC_TILE, "a tile is a whole number of elements per thread");
   uint64_t* sk = reinterpret_cast<uint64_t*>(smem);
@@ -286,21 +321,69 @@ __device__ __forceinline__ void loc_count_block(const LocView& v, const uint32_t
   }
   const uint32_t base = bid * LOC_TILE;
   uint64_t key[PER];
+  if (GATHER) {
+    // the rows that cover this tile: their offsets and where they start in their row buffer, in LDS
+    const GatherSrc& g = *gp;
+    uint32_t* roff = reinterpret_cast<uint32_t*>(smem + loc_count_smem<MAXB>());   // [nr + 1] the rows' offsets in the minibatch
+    uint64_t* rsrc = reinterpret_cast<uint64_t*>(roff + LOC_GATHER_ROWS + 2);       // [nr] source position << 2 | buffer
+    const uint32_t row0 = g.h_tile_row[bid], row1 = g.h_tile_row[bid + 1];          // rows [row0, row1] reach into the tile
+    const uint32_t nr = min(row1, v.nrows - 1u) - row0 + 1u;                        // (the host made sure: <= LOC_GATHER_ROWS)
+    for (uint32_t q = threadIdx.x; q <= nr; q += THREADS) roff[q] = g.h_off[row0 + q];
+    for (uint32_t q = threadIdx.x; q < nr; q += THREADS) {
+      const uint32_t r = row0 + q;
+      uint32_t sg = 0;
 #pragma unroll
-  for (int e = 0; e < PER; ++e) {  // independent loads first
-    const uint32_t i = base + e * THREADS + threadIdx.x;
-    key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
+      for (int x = 1; x < LOC_GATHER_SEGS; ++x) sg += (x < g.nseg && r >= g.seg_row0[x]) ? 1u : 0u;
+      rsrc[q] = ((uint64_t)loc_sel(g.src_off, sg)[g.h_rows[r]] << 2) | sg;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const uint32_t i = base + e * THREADS + threadIdx.x;
+      key[e] = ~0ULL;
+      if (i < v.n) {
+        // the last of the staged rows that starts at or before i (rows without nonzeros share their successor's offset)
+        uint32_t lo = 0, hi = nr - 1u;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (roff[mid] <= i) lo = mid; else hi = mid - 1u;
+        }
+        const uint64_t sw = rsrc[lo];
+        const uint32_t sg = (uint32_t)(sw & 3u);
+        const size_t at = (size_t)(sw >> 2) + (i - roff[lo]);
+        const uint64_t id = loc_sel(g.src_idx, sg)[at];
+        g.dst_raw[i] = id;   // k_loc_scatter reads the minibatch's own array
+        if (g.dst_val) {
+          const float* sv = loc_sel(g.src_val, sg);
+          g.dst_val[i] = sv ? sv[at] : 1.0f;
+        }
+        key[e] = make_key(id, v.max_index);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {  // independent loads first
+      const uint32_t i = base + e * THREADS + threadIdx.x;
+      key[e] = i < v.n ? make_key(v.raw[i], v.max_index) : ~0ULL;
+    }
   }
   // side job, independent of the sort until k_loc_emit: rowid[pos] = row of nnz position pos,
   // this block's share of the rows
   {
     uint32_t* __restrict__ rowid = const_cast<uint32_t*>(v.rowid);
-    const uint32_t* __restrict__ offset = v.offset;
+    // (gathering: the minibatch's offsets and labels arrive in HBM by this pass too — another block's share, so they are read
+    // where the host wrote them)
+    const uint32_t* __restrict__ offset = GATHER ? gp->h_off : v.offset;
     const uint32_t rpb = (v.nrows + nblk - 1) / nblk;
     const uint32_t r0 = bid * rpb, r1 = min(v.nrows, r0 + rpb);
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += THREADS) {
-      const uint32_t e = offset[r + 1];
-      for (uint32_t j = offset[r]; j < e; ++j) rowid[j] = r;
+      const uint32_t b0 = offset[r], e = offset[r + 1];
+      if (GATHER) {
+        gp->dst_off[r] = b0;
+        gp->dst_lab[r] = gp->h_lab[r];
+        if (r + 1 == v.nrows) gp->dst_off[r + 1] = e;
+      }
+      for (uint32_t j = b0; j < e; ++j) rowid[j] = r;
     }
   }
   __syncthreads();
@@ -342,6 +425,11 @@ template <int MAXB>
 __global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count(LocView v) {
   __shared__ __attribute__((aligned(16))) char smem[loc_count_smem<MAXB>()];
   loc_count_block<MAXB, LOC_TILE_THREADS>(v, blockIdx.x, gridDim.x, smem);
+}
+template <int MAXB>
+__global__ void __launch_bounds__(LOC_TILE_THREADS) k_loc_count_gather(LocView v, GatherSrc g) {
+  __shared__ __attribute__((aligned(16))) char smem[loc_count_smem<MAXB>() + loc_gather_smem()];
+  loc_count_block<MAXB, LOC_TILE_THREADS, true>(v, blockIdx.x, gridDim.x, smem, &g);
 }
 
 

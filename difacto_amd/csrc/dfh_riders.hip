@@ -22,6 +22,8 @@
 // Results are bit-identical to the stages run as launches of their own: the same block functions on the same arguments.
 #ifndef DFH_RIDERS_HIP_
 #define DFH_RIDERS_HIP_
+#include <cstddef>
+
 #include "dfh_internal.h"
 
 namespace dfh {
@@ -81,26 +83,32 @@ __device__ __forceinline__ bool rider_map(const RiderSet& rs, const uint32_t i, 
   return false;
 }
 
-// rider block `idx` of the launch: one block of one stage of one later minibatch.  (Compile-time rider index: a run-time
-// index into the by-value argument struct makes the compiler copy all of it into scratch.)
-template <int J>
-__device__ __forceinline__ void run_rider_j(const RiderSet& rs, const uint32_t idx, char* smem) {
-  if constexpr (J < MAX_RIDERS) {
-    if (idx >= rs.first[J + 1]) {
-      run_rider_j<J + 1>(rs, idx, smem);
-      return;
-    }
-    const uint32_t bid = idx - rs.first[J];
-    const uint32_t nblk = rs.r[J].nblk;
-    if (bid >= nblk) return;  // padding up to the next group of 8
-    const uint32_t kind = rs.r[J].kind;
-    if (kind == RID_COUNT) loc_count_block<LOC_MAX_BUCKETS, RID_THREADS>(rs.r[J].v, bid, nblk, smem);
-    else if (kind == RID_SCATTER) loc_scatter_block<LOC_MAX_BUCKETS, RID_THREADS>(rs.r[J].v, bid, smem);
-    else if (kind == RID_SORT) loc_sort_block(rs.r[J].v, bid, nblk, smem);
-    else loc_emit_block<false>(rs.r[J].v, rs.r[J].o, TableView{}, nullptr, bid, nblk, smem);
-  }
+// rider block `idx` of the launch: one block of one stage of one later minibatch.  `rs` points INTO THE KERNEL ARGUMENT
+// SEGMENT (rider_args): a run-time index into the by-value argument struct would make the compiler copy all of it into
+// scratch, and a compile-time index per rider four inlined copies of every stage in every carrier kernel; read through the
+// segment's own address the rider's arguments are scalar loads at a uniform offset.
+__device__ __forceinline__ void run_rider(const RiderSet* __restrict__ rs, const uint32_t idx, char* smem) {
+  uint32_t j = 0;
+#pragma unroll
+  for (int q = 1; q < MAX_RIDERS; ++q) j += idx >= rs->first[q] ? 1u : 0u;   // (first[q] = first[n] for q > n: no rider beyond n - 1)
+  j = min(j, (uint32_t)MAX_RIDERS - 1u);
+  const Rider& r = rs->r[j];
+  const uint32_t bid = idx - rs->first[j];
+  const uint32_t nblk = r.nblk;
+  if (j >= rs->n || bid >= nblk) return;  // padding up to the next group of 8
+  const uint32_t kind = r.kind;
+  if (kind == RID_COUNT) loc_count_block<LOC_MAX_BUCKETS, RID_THREADS>(r.v, bid, nblk, smem);
+  else if (kind == RID_SCATTER) loc_scatter_block<LOC_MAX_BUCKETS, RID_THREADS>(r.v, bid, smem);
+  else if (kind == RID_SORT) loc_sort_block(r.v, bid, nblk, smem);
+  else loc_emit_block<false>(r.v, r.o, TableView{}, nullptr, bid, nblk, smem);
 }
-__device__ __forceinline__ void run_rider(const RiderSet& rs, const uint32_t idx, char* smem) { run_rider_j<0>(rs, idx, smem); }
+// the RiderSet argument of the running kernel where the command processor put it: KA mirrors the kernel's parameter list
+// (arguments sit in the segment in order, each at its natural alignment)
+template <typename KA>
+__device__ __forceinline__ const RiderSet* rider_args() {
+  typedef __attribute__((address_space(4))) const char* ka_ptr;   // the constant address space: scalar loads
+  return (const RiderSet*)((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KA, rs));
+}
 
 extern __shared__ __attribute__((aligned(16))) char dfh_dyn_smem[];
 
@@ -110,9 +118,13 @@ __global__ void __launch_bounds__(RID_THREADS, 6) k_lookup_riders(TableView t, c
                                                               const uint32_t* __restrict__ col_ptr, int push_cnt,
                                                               uint32_t* __restrict__ need_init, int rows_known, uint2* __restrict__ uw,
                                                               AucFin fin, uint32_t nblk_main, RiderSet rs) {
+  struct KA {
+    TableView t; const uint64_t* keys; const uint32_t* d_n; uint32_t n_static; uint32_t* urow; const float* cnt; const uint32_t* col_ptr;
+    int push_cnt; uint32_t* need_init; int rows_known; uint2* uw; AucFin fin; uint32_t nblk_main; RiderSet rs;
+  };
   uint32_t idx;
   if (rider_map(rs, blockIdx.x, idx)) {
-    run_rider(rs, idx, dfh_dyn_smem);
+    run_rider(rider_args<KA>(), idx, dfh_dyn_smem);
     return;
   }
   if (idx >= nblk_main) return;
@@ -123,9 +135,10 @@ __global__ void __launch_bounds__(RID_THREADS, 6) k_lookup_riders(TableView t, c
 template <int L, int FWD_DEPTH>
 __global__ void __launch_bounds__(RID_THREADS, DFH_FWD_WAVES) k_forward_riders(BatchView b, RowSrc src, int k, int kp, uint32_t nblk_main,
                                                                               RiderSet rs) {
+  struct KA { BatchView b; RowSrc src; int k, kp; uint32_t nblk_main; RiderSet rs; };
   uint32_t idx;
   if (rider_map(rs, blockIdx.x, idx)) {
-    run_rider(rs, idx, dfh_dyn_smem);
+    run_rider(rider_args<KA>(), idx, dfh_dyn_smem);
     return;
   }
   if (idx >= nblk_main) return;
@@ -136,9 +149,10 @@ __global__ void __launch_bounds__(RID_THREADS, DFH_FWD_WAVES) k_forward_riders(B
 template <int L, bool EXACT, bool HAS_VAL>
 __global__ void __launch_bounds__(UPD_THREADS, DFH_UPD_WAVES) k_update_fused_riders(UpdArgs a, uint32_t nblk_main, RiderSet rs) {
   static_assert(UPD_THREADS == RID_THREADS, "riders are 256-thread blocks");
+  struct KA { UpdArgs a; uint32_t nblk_main; RiderSet rs; };
   uint32_t idx;
   if (rider_map(rs, blockIdx.x, idx)) {
-    run_rider(rs, idx, dfh_dyn_smem);
+    run_rider(rider_args<KA>(), idx, dfh_dyn_smem);
     return;
   }
   if (idx >= nblk_main) return;

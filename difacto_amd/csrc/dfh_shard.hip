@@ -646,6 +646,68 @@ int dfh_comm_selfcheck(dfh_comm* c, double timeout_s) {
   return DFH_OK;
 }
 
+// What do the wires give?  `reps` grouped exchanges in which this rank sends bytes_per_peer to and receives bytes_per_peer
+// from EVERY other rank (the shape of dfh_shard_step's K / RW / G exchanges: on a full xGMI mesh every link carries one
+// message each way at once), timed with HIP events on the context's stream after two untimed ones.  *us_per_exchange: the
+// average; bytes_per_peer / that = what one link gave per direction.  COLLECTIVE.  The projection of DESIGN 6a rests on an
+// assumed link rate: with this the first run on a real node replaces the assumption by itself (bench.py --gpus N).
+int dfh_comm_wire_probe(dfh_comm* c, size_t bytes_per_peer, int reps, double* us_per_exchange) {
+  DFH_ARG(c && us_per_exchange && bytes_per_peer >= 1 && bytes_per_peer <= ((size_t)1 << 30) && reps >= 1 && reps <= 1000,
+          "dfh_comm_wire_probe: 1 <= bytes_per_peer <= 1 GiB, 1 <= reps <= 1000");
+  dfh_ctx* ctx = c->ctx;
+  DFH_HIP(hipSetDevice(ctx->device));
+  const int W = c->world;
+  *us_per_exchange = 0;
+  if (W < 2) return DFH_OK;
+  char *d_s = nullptr, *d_r = nullptr;
+  const size_t total = (size_t)W * bytes_per_peer;
+  if (hipMalloc(reinterpret_cast<void**>(&d_s), total) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_r), total) != hipSuccess) {
+    if (d_s) (void)hipFree(d_s);
+    (void)hipGetLastError();
+    set_error("dfh_comm_wire_probe: no device memory for the probe's buffers");
+    return DFH_ERR_HIP;
+  }
+  std::vector<size_t> cnt(W, bytes_per_peer);
+  cnt[c->rank] = 0;   // nothing to itself: the wires are what is measured
+  const uint64_t bs = c->bytes_sent, br = c->bytes_recv, gr = c->groups;   // the probe is not part of the job's statistics
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = DFH_OK;
+  auto fail = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFH_OK) {
+      set_error(std::string("dfh_comm_wire_probe: ") + hipGetErrorString(e));
+      rc = DFH_ERR_HIP;
+    }
+  };
+  fail(hipMemsetAsync(d_s, 1, total, ctx->stream));
+  fail(hipEventCreate(&e0));
+  fail(hipEventCreate(&e1));
+  // (offsets spelled out: a peer's slot is W-indexed although this rank's own slot carries nothing)
+  std::vector<size_t> off(W);
+  for (int p = 0; p < W; ++p) off[p] = (size_t)p * bytes_per_peer;
+  XPart x{d_s, cnt.data(), off.data(), d_r, cnt.data(), off.data()};
+  for (int i = 0; i < 2 && rc == DFH_OK; ++i) rc = comm_exchange(c, &x, 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (rc == DFH_OK) fail(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps && rc == DFH_OK; ++i) rc = comm_exchange(c, &x, 1);
+  if (rc == DFH_OK) fail(hipEventRecord(e1, ctx->stream));
+  if (rc == DFH_OK) fail(hipStreamSynchronize(ctx->stream));
+  if (rc == DFH_OK) {
+    float ms = 0;
+    fail(hipEventElapsedTime(&ms, e0, e1));
+    // the host-callback transport exchanges on the host between two drains of the stream: its time is the host's
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    *us_per_exchange = (c->fn ? host_us : (double)ms * 1e3) / reps;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_s);
+  (void)hipFree(d_r);
+  c->bytes_sent = bs;
+  c->bytes_recv = br;
+  c->groups = gr;
+  return rc;
+}
+
 int dfh_comm_allgather(dfh_comm* c, const void* send, size_t bytes, void* recv) {
   DFH_ARG(c && send && recv && bytes >= 1 && bytes <= (1u << 24), "dfh_comm_allgather: 1 <= bytes <= 16 MiB of host memory");
   dfh_ctx* ctx = c->ctx;

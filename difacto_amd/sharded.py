@@ -136,19 +136,53 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
     hyper["V_lr"] = hyper["V_lr"] / world
     ctx = capi.Context(local_rank)
     ctx.set_pipeline(1)
-    if shared:
-        def exchange(send, sb, recv, rb):
-            out = torch.empty(sum(rb), dtype=torch.uint8)
-            dist.all_to_all_single(out, torch.from_numpy(np.array(send, copy=True)), output_split_sizes=rb, input_split_sizes=sb)
-            recv[:] = out.numpy()
-        comm = capi.Comm.callback(ctx, rank, world, exchange)
-    else:
-        ids = [capi.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = capi.Comm.rccl(ctx, rank, world, ids[0])
-    # a bad rendezvous (a rank that never joins) fails here within a minute instead of hanging the first step
-    comm.selfcheck(float(os.environ.get("DFH_SELFCHECK_TIMEOUT", "60")))
+    # transport start-up: a failure here (RCCL initialisation, a rank that never joins: dfh_comm_selfcheck polls for
+    # DFH_SELFCHECK_TIMEOUT seconds) becomes a JSON line with "error" on rank 0's stdout and a non-zero exit, not a hang
+    comm, err = None, None
+    try:
+        if shared:
+            def exchange(send, sb, recv, rb):
+                out = torch.empty(sum(rb), dtype=torch.uint8)
+                dist.all_to_all_single(out, torch.from_numpy(np.array(send, copy=True)), output_split_sizes=rb, input_split_sizes=sb)
+                recv[:] = out.numpy()
+            comm = capi.Comm.callback(ctx, rank, world, exchange)
+        else:
+            ids = [capi.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = capi.Comm.rccl(ctx, rank, world, ids[0])
+        comm.selfcheck(float(os.environ.get("DFH_SELFCHECK_TIMEOUT", "60")))
+    except Exception as ex:  # noqa: BLE001 — whatever the transport raised goes into the line
+        err = "rank %d: %r" % (rank, ex)
+    errs = [None] * world
+    try:
+        dist.all_gather_object(errs, err)
+    except Exception as ex:  # noqa: BLE001 — the rendezvous itself is gone: every rank reports what it has
+        errs = [err or ("rank %d: rendezvous lost: %r" % (rank, ex))]
+    if any(errs):
+        if rank == 0:
+            os.dup2(real_stdout, 1)
+            print(json.dumps({"metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % args.vdim, "value": None,
+                              "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "error": "transport start-up failed: " + "; ".join(e for e in errs if e)}), flush=True)
+        return 1
     comm_info = comm.info()
+    # the wires, measured before anything else uses them: grouped ncclSend / ncclRecv all-to-all of 1 / 5 / 35 MB per peer on
+    # the library's own communicator (the sizes of the K, RW / G exchanges at N = 8 and N = 2: DESIGN 6a)
+    wire_probe = None
+    if world > 1:
+        sizes = [int(x) for x in os.environ.get("DFH_WIRE_PROBE_BYTES", "1000000,5000000,35000000").split(",") if x]
+        wire_probe = dict(transport=comm_info, peers=world - 1, per_size=[],
+                          note="every rank sends and receives `bytes_per_peer` to / from every other rank in ONE grouped exchange "
+                               "(dfh_comm_wire_probe, %d timed repetitions after 2 untimed); GB/s per link and direction = "
+                               "bytes_per_peer / time; max over ranks of the time" % 10)
+        for nb in sizes:
+            us = comm.wire_probe(nb, reps=10)
+            t_ = torch.tensor([us], dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            us = float(t_.item())
+            wire_probe["per_size"].append(dict(bytes_per_peer=nb, us_per_grouped_exchange=us,
+                                               gbps_per_link_and_direction=(nb / us / 1e3) if us > 0 else None))
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
     t0 = time.time()
     splits, ranges_mode = bench_splits(args, world, lambda: synth.CriteoSynth(total_ids=args.ids, seed=42), S)
@@ -306,6 +340,12 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
                               frac_of_links_in_use=(ach / (links * XGMI_LINK_GBPS)) if ach is not None else None,
                               peak_note="7 xGMI links x 153.6 GB/s per GPU, both directions together; with N ranks N - 1 links carry traffic",
                               message_groups_per_step=x_groups / max(x_steps, 1))
+            if wire_probe and wire_probe["per_size"] and ach is not None:
+                # ... and against what THIS node's wires gave the probe: the largest probed size, both directions of N - 1 links
+                best = max((p_["gbps_per_link_and_direction"] or 0.0) for p_ in wire_probe["per_size"])
+                if best > 0:
+                    roofline_x["measured_wire_gbps_per_link_and_direction"] = best
+                    roofline_x["frac_of_measured_wire"] = ach / (2.0 * links * best)
         out = {
             "metric": "examples/sec (FM SGD worker step, Criteo-shape, V_dim=%d)" % k,
             "value": ex_per_s, "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -330,6 +370,8 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
                        "transport_bound": comm_info, "distinct_batches_per_rank": nd,
                        "auc_every_minibatch": not getattr(args, "no_auc", False),
                        "owned_keys_rank0": int(owned)},
+            "lr_divided_by_world": world,
+            "wire_probe": wire_probe,
             "stage_ms_per_step": stage_ms,
             "stage_ms_per_step_note": "separate instrumented pass; max over ranks per stage; counts/K/G/RW run on the "
                                       "collectives' stream in overlap mode and overlap F/R/P on the main stream",

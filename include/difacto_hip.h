@@ -122,7 +122,7 @@ uint64_t dfh_encode_fea_grp_id(uint64_t x, int gid, int nbits);
  * capacity_rows = 0: the table GROWS like the reference's map (it starts at 2^20 rows and is re-allocated at twice
  * the size whenever fewer than 32 launches' worth of new keys would still fit; row ids are stable, only the key index
  * is rebuilt; needs old + new arrays side by side, so a model beyond a third of the HBM wants an explicit capacity).
- * capacity_rows > 0: fixed; inserting beyond it is reported as DFH_ERR_CAPACITY, never silent.  At most 2^29 - 1 rows. */
+ * capacity_rows > 0: fixed; inserting beyond it is reported as DFH_ERR_CAPACITY, never silent.  At most 2^28 - 1 rows (the four top bits of a row word carry flags). */
 int dfh_table_create(dfh_ctx* ctx, const dfh_updater_param* p, uint64_t capacity_rows, dfh_table** out);
 /* rows the arrays hold now, and how often the table has grown (0 for a fixed capacity) */
 int dfh_table_capacity(dfh_table* t, uint64_t* capacity_rows, uint64_t* grows);
@@ -399,6 +399,12 @@ int dfh_comm_info(dfh_comm* c, char* buf, size_t n);
  * The reference's Store has no such call: its ps-lite van blocks in Postoffice::Barrier (include/difacto/store.h:53-93
  * is the interface this transport serves). */
 int dfh_comm_selfcheck(dfh_comm* c, double timeout_s);
+/* what the wires give: `reps` grouped exchanges (after two untimed ones) in which this rank sends bytes_per_peer to and
+ * receives bytes_per_peer from EVERY other rank — the shape of dfh_shard_step's key / row / gradient exchanges (the
+ * reference's ps-lite Push / Pull traffic, include/difacto/store.h:53-93), every xGMI link of a full mesh carrying one
+ * message each way at once — timed on the context's stream.  *us_per_exchange = the average; bytes_per_peer over it is
+ * what one link gave per direction.  COLLECTIVE; 0 with one rank.  bench.py --gpus N runs it before the timed region. */
+int dfh_comm_wire_probe(dfh_comm* c, size_t bytes_per_peer, int reps, double* us_per_exchange);
 /* Split keys that balance the shards on the DATA instead of on the key space: every rank hands in a sample of the
  * reversed keys it will see (n may differ per rank, 0 allowed); the samples are gathered and splits[world-1] receives
  * the (identical on every rank) quantiles of their union — the argument for dfh_shard_create.  With feature-group ids

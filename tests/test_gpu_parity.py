@@ -1002,6 +1002,83 @@ def test_device_row_gather_matches_host_load(capi, oracle, streams):
     ctx.close()
 
 
+@pytest.mark.parametrize("streams", [0, 2])
+def test_device_feed_count_pass_gathers(capi, oracle, streams):
+    """round 6: the Localizer's count pass gathers a described minibatch out of the row buffers itself (k_loc_count_gather;
+    BatchReader's shuffle buffer, src/reader/batch_reader.cc:29-78, read in HBM) — minibatches of many tiles drawn from one
+    to four buffers, with and without values, rows repeated, runs of empty rows inside a tile — and falls back to the gather
+    launch where it cannot: a tile that spans more than 1 024 rows (thousands of empty rows in a row), five buffers, the first
+    call of a size class.  Everything bit for bit what dfh_batch_load_host of the same minibatch gives."""
+    rng = np.random.default_rng(43)
+    bufs_host = [random_batch(rng, 4000, 1 << 30, 24, empty_rows=True), random_batch(rng, 3000, 1 << 30, 30, binary=True),
+                 random_batch(rng, 2000, 1 << 30, 16), random_batch(rng, 1500, 1 << 30, 40, binary=True),
+                 random_batch(rng, 1000, 1 << 30, 8)]
+    # a buffer of empty rows only (and one row with features at its end): 3 000 rows that all start at the same position
+    empty = dict(offset=np.concatenate([np.zeros(3001, np.uint64), [5]]).astype(np.uint64), index=np.arange(5, dtype=np.uint64) + 77,
+                 value=None, label=np.ones(3001, np.float32))
+    bufs_host.append(empty)
+    kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=5)
+    ctx = capi.Context(0)
+    ctx.set_pipeline(streams)
+    rbs = []
+    for hb in bufs_host:
+        rb = capi.RowBuf(ctx, len(hb["label"]), max(int(hb["offset"][-1]), 1))
+        rb.load_host(hb["offset"], hb["index"], hb["value"])
+        rbs.append(rb)
+
+    def host_minibatch(segments):
+        off, idx, val, lab = [0], [], [], []
+        anyv = any(bufs_host[g]["value"] is not None for g, _ in segments)
+        for g, rows in segments:
+            hb = bufs_host[g]
+            for r in rows:
+                lo, hi = int(hb["offset"][r]), int(hb["offset"][r + 1])
+                idx.append(hb["index"][lo:hi])
+                if anyv:
+                    val.append(hb["value"][lo:hi] if hb["value"] is not None else np.ones(hi - lo, np.float32))
+                lab.append(hb["label"][r])
+                off.append(off[-1] + hi - lo)
+        return dict(offset=np.array(off, np.uint64), index=np.concatenate(idx) if idx else np.zeros(0, np.uint64),
+                    value=np.concatenate(val).astype(np.float32) if anyv else None, label=np.array(lab, np.float32))
+
+    take = lambda g, n: (g, rng.permutation(len(bufs_host[g]["label"]))[:n])
+    plans = [[take(0, 3000)], [take(0, 2500)], [take(0, 1500), take(1, 1500)], [take(1, 2000), take(2, 1000), take(3, 500)],
+             [take(3, 1200), take(0, 900), take(2, 700), take(1, 400)],             # four buffers: still gathered by the count pass
+             [take(0, 800), take(1, 600), take(2, 500), take(3, 400), take(4, 300)],  # five: the gather launch
+             [take(0, 1000), (5, np.arange(3000)), take(0, 1000)],                    # 3 000 empty rows inside one tile: the gather launch
+             [take(0, 2000), (0, np.array([7, 7, 7, 9, 7]))], [take(2, 2000)], [take(0, 3000)]]
+    results = []
+    for device in (False, True):
+        tb = capi.Table(ctx, 1 << 18, V_dim=8, init_mode=capi.INIT_HASH, **kw)
+        bts = [capi.Batch(ctx, 5100, 5100 * 24) for _ in range(2)]
+        out = []
+        for step, segments in enumerate(plans):
+            mb = host_minibatch(segments)
+            bt = bts[step % 2]
+            if device:
+                bt.prepare_rows(tb, mb["offset"], mb["label"], [(rbs[g], rows) for g, rows in segments])
+            else:
+                bt.load_host(mb["offset"], mb["index"], mb["value"], mb["label"])
+                bt.localize()
+            got = bt.get_localized()
+            want = oracle.localize(mb["offset"], mb["index"])
+            assert np.array_equal(got["feaids"], want["feaids"]) and np.array_equal(got["index"], want["index"]) \
+                and np.array_equal(got["feacnt"], want["feacnt"]), (device, step)
+            bt.sgd_step(tb, is_train=True, push_cnt=step < 4)
+            out.append(bt.pred())
+        keys = np.unique(np.concatenate([hb["index"] for hb in bufs_host]))
+        results.append((out, tb.pull(oracle.reverse_bytes(keys))))
+        for o in bts + [tb]:
+            o.close()
+    (p0, (v0, l0)), (p1, (v1, l1)) = results
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(l0, l1) and np.array_equal(v0, v1)
+    for rb in rbs:
+        rb.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("streams,nbatch,prep_lookup", [(1, 2, True), (2, 4, False), (3, 5, True), (1, 3, "fused"), (2, 4, "fused")])
 def test_pipelined_prep_matches_serial(capi, oracle, streams, nbatch, prep_lookup):
     """preparing later batches on 1..3 preparation streams (with as many or more batch objects in

@@ -252,7 +252,7 @@ def _zero_row_scenario(k):
 
 @pytest.mark.parametrize("k", [4, 64])
 def test_allocated_all_zero_V_row_times_nonfinite_value_reference_side(oracle, ref, k):
-    """the reference's side of the one documented deviation: SpMM has no zero skip (spmm.h:108-118 tests V_pos only), so an
+    """the reference's side of what was, through round 5, the one documented deviation: SpMM has no zero skip (spmm.h:108-118 tests V_pos only), so an
     allocated row of zeros times Inf / NaN is NaN, and so is the logit (fm_loss.h:118 clamps +-Inf, never NaN)"""
     off, idx, val, lab, W, lens = _zero_row_scenario(k)
     wp, vp = oracle.get_pos(lens)
@@ -265,31 +265,59 @@ def test_allocated_all_zero_V_row_times_nonfinite_value_reference_side(oracle, r
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [4, 64])
 def test_allocated_all_zero_V_row_times_nonfinite_value(capi, ctx, oracle, k):
-    """... and the device's: k_forward loads V rows speculatively and takes a 16 B slice that is all zero for "no V" (the
-    per-coordinate test costs the forward 1.4 of 20 us), so the all-zero ALLOCATED row is neutral: the logit of the two
-    poisoned examples is what it would be without that key (its w is 0: SpMV skips it on both sides, spmv.h:125).  A model
-    reaches this state only by import / load: InitV draws from +-V_init_scale / 2 and AdaGrad steps do not return a whole
-    row to exact zero."""
+    """... and the device's — since round 6 the reference's.  Through round 5 k_forward took a 16 B slice of a speculatively
+    loaded V row that was all zero for "no V" and this state (reachable by import / load only) came out neutral where the
+    reference gives NaN: the one documented deviation.  Now a key's has-V flag travels with its row word (kHasV, left by
+    k_lookup / k_uw_remote; the header flag of packed rows) and decides, as V_pos = -1 does in SpMM::Times (spmm.h:108-118):
+    both forward paths — packed rows (dfh_batch_forward) and the fused step's row words (dfh_sgd_step) — give the
+    reference's NaN pattern and its finite logits."""
     from oracle import tolerance as T
     off, idx, val, lab, W, lens = _zero_row_scenario(k)
     wp, vp = oracle.get_pos(lens)
-    # what the logits are WITHOUT key 1 (drop its nonzeros): the device's answer for all three examples
-    keep = idx != 1
-    off2 = np.array([0, 2, 4, 6], np.uint64)
-    po_without = oracle.fm_predict(k, off2, idx[keep], val[keep], W, wp, vp)
+    po = oracle.fm_predict(k, off, idx, val, W, wp, vp)
+    assert np.isfinite(po[0]) and np.isnan(po[1]) and np.isnan(po[2])
     stride = capi.row_stride(k)
     rows = T.packed_rows(W, lens, k, stride)
     bt = capi.Batch(ctx, 3, 9)
     raw = np.array([5, 9, 12], np.uint64)   # any three distinct ids; ranks follow the reversed order
-    order = np.argsort(np.array([capi.reverse_bytes(int(x)) for x in raw], dtype=np.uint64))
+    keys = np.array([capi.reverse_bytes(int(x)) for x in raw], dtype=np.uint64)
+    order = np.argsort(keys)
     bt.load_host(off, raw[order][idx], val, lab)   # raw[order][r]: the raw id whose reversed key has rank r
     bt.localize()
     d_rows = capi.DeviceBuffer.from_numpy(ctx, rows)
     bt.forward(k, d_rows.ptr)
     pg = bt.pred()
-    assert np.all(np.isfinite(pg)), pg
-    np.testing.assert_allclose(pg[1:], po_without[1:], rtol=1e-5, atol=1e-6)
-    for o in (bt, d_rows):
+    assert np.array_equal(np.isnan(pg), np.isnan(po)), (pg, po)
+    np.testing.assert_allclose(pg[0], po[0], rtol=1e-5, atol=1e-6)
+    # the fused step: the same model imported (every key WITH V, the middle one's row exactly zero), a prediction step
+    tb = capi.Table(ctx, 1 << 10, V_dim=k, init_mode=capi.INIT_HASH, l1=0.0, l2=0.0, V_threshold=0, seed=1)
+    Wm = W.reshape(3, 1 + k)
+    scal = np.stack([np.full(3, 5.0), Wm[:, 0], np.full(3, 0.5), np.zeros(3)], 1).astype(np.float32)   # fea_cnt, w, sqrt_g, z
+    V = np.concatenate([Wm[:, 1:], np.full((3, k), 0.1)], 1).astype(np.float32)                        # V | accumulators
+    tb.import_(keys[order], scal, np.ones(3, np.int32), V)
+    bt.load_host(off, raw[order][idx], val, lab)
+    bt.localize()
+    bt.sgd_step(tb, is_train=False, push_cnt=False)
+    pf = bt.pred()
+    assert np.array_equal(np.isnan(pf), np.isnan(po)), (pf, po)
+    np.testing.assert_allclose(pf[0], po[0], rtol=1e-5, atol=1e-6)
+    # ... and a key WITHOUT V stays skipped whatever its value: has_V = 0 for the middle key -> all three logits finite
+    tb2 = capi.Table(ctx, 1 << 10, V_dim=k, init_mode=capi.INIT_HASH, l1=0.0, l2=0.0, V_threshold=1000, seed=1)
+    has = np.array([1, 0, 1], np.int32)
+    V2 = V.copy()
+    V2[1] = 0
+    tb2.import_(keys[order], scal, has, V2)
+    bt.load_host(off, raw[order][idx], val, lab)
+    bt.localize()
+    bt.sgd_step(tb2, is_train=False, push_cnt=False)
+    pn = bt.pred()
+    lens2 = np.array([1 + k, 1, 1 + k], np.int32)
+    W2 = np.concatenate([Wm[0], Wm[1, :1], Wm[2]]).astype(np.float32)
+    wp2, vp2 = oracle.get_pos(lens2)
+    po2 = oracle.fm_predict(k, off, idx, val, W2, wp2, vp2)
+    assert np.all(np.isfinite(po2)) and np.all(np.isfinite(pn)), (pn, po2)
+    np.testing.assert_allclose(pn, po2, rtol=1e-5, atol=1e-6)
+    for o in (bt, d_rows, tb, tb2):
         o.close()
 
 

@@ -196,6 +196,11 @@ def _worker(rank, world, port, out_dir, balanced, prefetch, mode="sync"):
 
     comm = capi.Comm.callback(ctx, rank, world, exchange)
     comm.selfcheck(30.0)   # collective: every rank's id arrives everywhere, or an error instead of a hang
+    # the wire probe bench.py --gpus N runs before its timed region (dfh_comm_wire_probe): collective, a positive time per
+    # grouped exchange, and the job's own statistics untouched by it
+    st0 = comm.stats(reset=False)
+    assert comm.wire_probe(4096, reps=2) > 0.0
+    assert comm.stats(reset=False) == st0
     assert "callback" in comm.info()
     comm.stats(reset=True)
     splits = None
@@ -326,6 +331,7 @@ def test_shard_step_world1_over_rccl_matches_fused():
     ctx = capi.Context(0)
     comm = capi.Comm.rccl(ctx, 0, 1, capi.Comm.unique_id())
     comm.selfcheck(30.0)
+    assert comm.wire_probe(1 << 20, reps=2) == 0.0   # one rank: no wires
     info = comm.info()   # which RCCL: version + the file it was bound from (the bench line logs it)
     assert info.startswith("rccl ") and "librccl" in info and int(info.split()[1]) > 20000, info
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=0, V_init_scale=0.2, seed=2)
