@@ -82,8 +82,8 @@ def parse_args():
     ap.add_argument("--two-queues", dest="single_queue", action="store_false",
                     help="rounds 2-5: Localizer + probe of minibatch t+1 on a low-priority preparation stream")
     ap.add_argument("--ahead", type=int, default=0,
-                    help="single-queue step: minibatches prepared (noted) ahead of the one training (default 2: count(t+2) rides "
-                         "in the update launch of step t)")
+                    help="minibatches prepared ahead of the one training.  Single-queue step: default 2 (count(t+2) rides in the "
+                         "update launch of step t); two queues: default = the number of preparation streams")
     ap.add_argument("--no-prep-lookup", dest="prep_lookup", action="store_false",
                     help="probe the key index inside the step instead of on the preparation stream")
     ap.add_argument("--fused-probe", action="store_true",
@@ -453,7 +453,7 @@ def main():
     ctx.set_pipeline(depth)
     if sq:
         ctx.set_option("single_queue", 1)
-    ahead = (args.ahead or 2) if sq else max(depth, 1)
+    ahead = (args.ahead or 2) if sq else max(args.ahead or depth, 1)
     # one spare object so that a new Localizer never waits for the step that just ended to release its buffers
     # (single queue: everything is ordered by the one stream, ahead + 1 objects rotate)
     bts = [capi.Batch(ctx, B, max_nnz) for _ in range(ahead + (2 if depth else 1))]

@@ -147,6 +147,75 @@ __global__ void k_rehash(const HEntry* __restrict__ old_ht, uint64_t old_slots, 
   }
 }
 
+// find_or_insert for a whole 256-thread block of DISTINCT keys (k_lookup: one thread per unique key of a minibatch), rows
+// handed out per BLOCK: the threads that win a slot are counted (ballot, one LDS atomic per wavefront) and ONE atomicAdd on the
+// table's row counter serves them all.  Every row a launch allocates used to cost an atomic on that one address per
+// wavefront with a winner, and same-address atomics serialise at ~12 ns each on this part: a first-epoch minibatch (every key
+// new: ~147 000 inserts) queued ~1 600 of them, ~20 us of one memory channel's time beside whatever else ran (profiles/r05j_*:
+// "probe + 20 us"), now a quarter of that.  Same protocol as find_or_insert towards concurrent launches: a slot's winner publishes
+// the row id with a device-scope store, other carriers of the key wait for it — but only AFTER this block's own winners have
+// published (nobody waits inside the counted phase: a block that waited there could hold back the winner it waits for).
+// All threads of the block call it together (`active`: this thread has a key); sh: 8 shared words.
+__device__ __forceinline__ uint32_t find_or_insert_block(const TableView& t, uint64_t key, bool active, uint32_t* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // sh may still be read from the previous call
+  if (threadIdx.x == 0) sh[0] = 0u;
+  __syncthreads();
+  uint64_t h = splitmix64(key) & t.hmask;
+  uint32_t r = kNoRow;
+  bool won = false, pending = false;
+  if (active) {
+    for (;;) {
+      uint64_t k = __hip_atomic_load(&t.ht[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == kEmptyKey) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.ht[h].key), (unsigned long long)kEmptyKey,
+                                                 (unsigned long long)key);
+        if (old == kEmptyKey) {
+          won = true;
+          break;
+        }
+        k = (uint64_t)old;
+      }
+      if (k == key) {
+        r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = r == kNoRow;  // its winner (another launch) is between its CAS and its store: looked at again below
+        break;
+      }
+      h = (h + 1) & t.hmask;
+    }
+  }
+  // rows for this block's winners: rank inside the wavefront from the ballot, the wavefront's offset from one LDS atomic
+  const unsigned long long m = __ballot(won);
+  uint32_t woff = 0;
+  if (lane == 0 && m) woff = atomicAdd(&sh[0], (uint32_t)__popcll(m));
+  woff = __shfl(woff, 0, 64);
+  __syncthreads();
+  if (threadIdx.x == 0) sh[1] = sh[0] ? atomicAdd(t.nrows, sh[0]) : 0u;
+  __syncthreads();
+  if (won) {
+    r = sh[1] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (r >= t.capacity) {
+      atomicOr(t.err, 1u);
+      r = t.capacity - 1;  // keep memory safe; the host reports DFH_ERR_CAPACITY
+    }
+    __hip_atomic_store(&t.ht[h].row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (pending) {
+    for (uint32_t spins = 0;; ++spins) {
+      r = __hip_atomic_load(&t.ht[h].row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r != kNoRow) break;
+      if (spins > (1u << 22)) {  // seconds: the winner of this slot is gone
+        atomicOr(t.err, 8u);
+        r = 0u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  (void)w;
+  return r;
+}
+
 // read-only probe (export / tests)
 __device__ __forceinline__ uint32_t find_only(const TableView& t, uint64_t key) {
   uint64_t h = splitmix64(key) & t.hmask;
@@ -440,11 +509,19 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
   // a step's lookup also closes the AUC its batch object's previous step left pending (dfh_sgd_step; fin.n == 0: none)
   if (fin.n && bid == 0) auc_finalize_block(fin);
   uint32_t n = d_n ? *d_n : n_static;
-  for (uint32_t u = bid * blockDim.x + threadIdx.x; u < n; u += nblk * blockDim.x) {
-    uint64_t key = keys[u];
+  __shared__ uint32_t ins_sh[8];
+  // (block-uniform trip count: the insert below is a block-wide call)
+  for (uint32_t u0 = bid * blockDim.x; u0 < n; u0 += nblk * blockDim.x) {
+    const uint32_t u = u0 + threadIdx.x;
+    const bool active = u < n;
+    uint64_t key = active ? keys[u] : 0ull;
     // rows_known: urow was filled by an earlier (prep-stream) lookup of the same keys
     // (rows_known: a row word of k_resolve_multi may carry its worker mark in bit 31 — dfh_shard_push_count_resolved)
-    uint32_t r = rows_known ? (urow[u] & kRowMask) : find_or_insert(t, key);
+    uint32_t r;
+    if (rows_known) r = active ? (urow[u] & kRowMask) : 0u;
+    else if (blockDim.x == 256) r = find_or_insert_block(t, key, active, ins_sh);
+    else r = active ? find_or_insert(t, key) : 0u;
+    if (!active) continue;
     if (urow && !rows_known) urow[u] = r;
     float w = 0.f;
     bool hasv = false;

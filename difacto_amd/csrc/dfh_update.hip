@@ -116,28 +116,44 @@ __device__ __forceinline__ uint32_t ld_rowword(const uint2* p) {  // .x of {row 
 // lane instead of one lane's 2 kp scalar stores, and outside the roles' loops, whose register budget it does not touch
 // (written inline at the end of upd_apply the same stores cost the warm step 1.4 %).  One array per block in LDS.
 constexpr uint32_t UPD_INIT_CAP = 511;
+constexpr int UPD_INIT_BATCH = 4;   // rows a lane group initialises per round trip (their keys are fetched together)
 __device__ __forceinline__ uint32_t* upd_init_list() {
-  __shared__ uint32_t list[1 + UPD_INIT_CAP];  // [0]: entries noted (may exceed the capacity: the surplus was written inline)
+  // [0]: entries noted (may exceed the capacity: the surplus was written inline); then {key rank u, table row r} per entry
+  __shared__ uint32_t list[2 + 2 * UPD_INIT_CAP];
   return list;
 }
+// Round 6: the epilogue used to fetch every listed row's word and key one row after the other — a dependent global round trip
+// per row and lane group, eight in a row for the ~125 rows a singles block of a COLD step lists (every key of the first epoch's
+// minibatches is new), i.e. most of the 25 us a cold update launch took beyond a warm one (profiles/r05j_*).  The noting lane
+// now leaves the row id beside the key's rank, and a lane group fetches the keys of UPD_INIT_BATCH rows together.
 __device__ __forceinline__ void upd_init_rows(const UpdArgs& a, int L) {
   __syncthreads();
   const uint32_t* il = upd_init_list();
   const uint32_t n = min(il[0], UPD_INIT_CAP);
   const int k = a.k, kp = a.kp;
-  for (uint32_t e = threadIdx.x / L; e < n; e += UPD_THREADS / L) {
-    const uint32_t u = il[1 + e];
-    const uint32_t r = a.uw[u].x & kRowMask;
-    const uint64_t key = a.feaids[u];
-    float* va = a.va + (size_t)r * (size_t)(2 * kp);
-    for (int d0 = (threadIdx.x % L) * 4; d0 < kp; d0 += L * 4) {
-      float4 nv;
-      nv.x = d0 + 0 < k ? hash_init_value(key, d0 + 0, a.p.seed, a.p.V_init_scale) : 0.f;
-      nv.y = d0 + 1 < k ? hash_init_value(key, d0 + 1, a.p.seed, a.p.V_init_scale) : 0.f;
-      nv.z = d0 + 2 < k ? hash_init_value(key, d0 + 2, a.p.seed, a.p.V_init_scale) : 0.f;
-      nv.w = d0 + 3 < k ? hash_init_value(key, d0 + 3, a.p.seed, a.p.V_init_scale) : 0.f;
-      st4_nt(va + d0, nv);
-      st4_nt(va + kp + d0, make_float4(0.f, 0.f, 0.f, 0.f));
+  const uint32_t G = UPD_THREADS / L;
+  for (uint32_t e0 = threadIdx.x / L; e0 < n; e0 += G * UPD_INIT_BATCH) {
+    uint64_t key[UPD_INIT_BATCH];
+    uint32_t row[UPD_INIT_BATCH];
+#pragma unroll
+    for (int q = 0; q < UPD_INIT_BATCH; ++q) {  // entries past the list: the last one again (an unconditional load), never written
+      const uint32_t e = min(e0 + q * G, n - 1u);
+      row[q] = il[3 + 2 * e];
+      key[q] = a.feaids[il[2 + 2 * e]];
+    }
+#pragma unroll
+    for (int q = 0; q < UPD_INIT_BATCH; ++q) {
+      if (e0 + q * G >= n) break;
+      float* va = a.va + (size_t)row[q] * (size_t)(2 * kp);
+      for (int d0 = (threadIdx.x % L) * 4; d0 < kp; d0 += L * 4) {
+        float4 nv;
+        nv.x = d0 + 0 < k ? hash_init_value(key[q], d0 + 0, a.p.seed, a.p.V_init_scale) : 0.f;
+        nv.y = d0 + 1 < k ? hash_init_value(key[q], d0 + 1, a.p.seed, a.p.V_init_scale) : 0.f;
+        nv.z = d0 + 2 < k ? hash_init_value(key[q], d0 + 2, a.p.seed, a.p.V_init_scale) : 0.f;
+        nv.w = d0 + 3 < k ? hash_init_value(key[q], d0 + 3, a.p.seed, a.p.V_init_scale) : 0.f;
+        st4_nt(va + d0, nv);
+        st4_nt(va + kp + d0, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
     }
   }
 }
@@ -185,7 +201,8 @@ __device__ __forceinline__ void upd_apply(const UpdArgs& a, uint32_t r, uint32_t
         uint32_t* il = upd_init_list();
         const uint32_t slot = atomicAdd(&il[0], 1u);
         if (slot < UPD_INIT_CAP) {
-          il[1 + slot] = u;
+          il[2 + 2 * slot] = u;
+          il[3 + 2 * slot] = r;
         } else {  // list full: as before
           const uint64_t key = a.feaids[u];
           for (int j = 0; j < kp; ++j) {

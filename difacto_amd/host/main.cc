@@ -4,6 +4,8 @@
  * example/<name>.conf), `task=train learner=sgd` by default; unknown keys are
  * reported as warnings.  Reference: src/main.cc, src/common/arg_parser.h.
  */
+#include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include "difacto/learner.h"
@@ -71,6 +73,11 @@ int main(int argc, char* argv[]) {
     return 0;
   }
   using namespace difacto;
+  // DIFACTO_PROFILE=1: where the PROCESS spends its wall-clock outside the worker loop (start-up and teardown are most of a
+  // one-epoch job: profiles/r05e_e2e_startup.txt)
+  const bool prof = getenv("DIFACTO_PROFILE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   ArgParser parser;
   for (int i = 1; i < argc; ++i) parser.AddArg(argv[i]);
   DifactoParam param;
@@ -78,8 +85,13 @@ int main(int argc, char* argv[]) {
   if (param.task == "train") {
     Learner* learner = Learner::Create(param.learner);
     WarnUnknownKWArgs(param, learner->Init(kwargs_remain));
+    const double t1 = now();
     learner->Run();
+    const double t2 = now();
     delete learner;
+    if (prof)
+      LOG(INFO) << "process: main() to the learner initialised (HIP runtime, device context, model table) " << t1 - t0 << " s, Run "
+                << t2 - t1 << " s, learner destroyed in " << now() - t2 << " s";
   } else if (param.task == "predict") {
     // the reference stops at a TODO here (main.cc:61-62); its SGDLearnerParam already names model_in as the model of
     // "a prediction task" (sgd_param.h:24-28).  The learner runs one forward pass over the data and writes pred_out.

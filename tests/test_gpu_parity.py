@@ -930,6 +930,48 @@ def test_resolve_multi_refuses_a_repeated_key_inside_one_source(capi, ctx):
     tb.close()
 
 
+def test_resolve_multi_saturates_on_an_overflowing_table(capi, ctx):
+    """a fixed-capacity owner table that overflows parks every key beyond its capacity on the LAST row
+    (find_or_insert keeps memory safe, the host reports DFH_ERR_CAPACITY) — far more entries on one row than its worker has
+    extras for.  The count of a row's extras must saturate: the Push kernels are queued before the host reads the error
+    word, and a count beyond the extras (or its carry into the worker's index) would have them follow indices nobody
+    wrote.  Four sources x 200 keys into a table of 64 rows: resolve, pull, count push, gradient push all complete, the
+    error is reported, and the table still answers."""
+    import torch
+    dev = torch.device("cuda", 0)
+    kw = dict(l1=0.0, l2=0.0, lr=0.1, V_lr=0.05, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=1)
+    tb = capi.Table(ctx, 64, V_dim=4, init_mode=capi.INIT_HASH, **kw)
+    nsrc, per = 4, 200
+    rng = np.random.default_rng(3)
+    lists = [np.sort(rng.choice(1 << 40, size=per, replace=False).astype(np.uint64)) for _ in range(nsrc)]
+    keys = np.concatenate(lists)
+    seg = np.concatenate([[0], np.cumsum([per] * nsrc)])
+    n = len(keys)
+    stride = capi.row_stride(4)
+    d_keys = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
+    rowid = torch.zeros(capi.multi_words(n, nsrc), dtype=torch.int32, device=dev)
+    rows = torch.zeros((n, stride), dtype=torch.float32, device=dev)
+    cnt = torch.ones(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    tb.shard_resolve_multi(d_keys, seg, rowid)
+    tb.shard_push_count_multi(rowid, d_keys, seg, cnt)
+    tb.shard_pull_resolved(rowid, n, rows)
+    ctx.sync()
+    g = np.zeros((n, stride), np.float32)
+    g[:, 0] = 0.5
+    g[:, 1] = rows[:, 1].cpu().numpy()
+    grads = torch.from_numpy(g).to(dev)
+    torch.cuda.synchronize()
+    tb.shard_push_grad_multi(rowid, d_keys, seg, grads)   # must not fault: counts saturated, indices inside the extras
+    ctx.sync()
+    with pytest.raises(capi.DfhError) as ei:
+        tb.check()
+    assert "full" in str(ei.value) or "repeats a key" in str(ei.value)
+    rw = rowid[:n].cpu().numpy().view(np.uint32)
+    assert int((rw & np.uint32(0x0FFFFFFF)).max()) <= 63    # every row word names a row of the table
+    tb.close()
+
+
 @pytest.mark.parametrize("streams", [0, 1])
 def test_device_row_gather_matches_host_load(capi, oracle, streams):
     """the device feed (dfh_rowbuf_load_host + dfh_batch_gather_rows, or dfh_batch_prepare_rows = gather + Localizer + lookup

@@ -54,7 +54,7 @@ def run(path, fmt):
     loss = [l for l in r.stderr.splitlines() if "Training: loss" in l]
     loop_s = None
     for l in r.stderr.splitlines():
-        if "host loop over" in l or "reader: " in l or "batch reader" in l or "start-up:" in l or "dfh_table:" in l:   # DIFACTO_PROFILE=1
+        if "host loop over" in l or "reader: " in l or "batch reader" in l or "start-up:" in l or "dfh_table:" in l or "process:" in l:   # DIFACTO_PROFILE=1
             sys.stderr.write(fmt + " " + exe + ": " + l.split("INFO")[-1].strip() + "\n")
         m = re.search(r"host loop over (\d+) minibatches: reader ([0-9.e+-]+) s, stage \+ localize \+ lookup ([0-9.e+-]+) s.*step ([0-9.e+-]+) s", l)
         if m:   # the worker loop's own clock: process start, HIP initialisation and the table allocation are outside it
