@@ -42,7 +42,10 @@ PRESETS = {
     # src/sgd/sgd_param.h:95-105
     "c3-refdefaults": dict(hyper=dict(l1=1.0, V_threshold=10)),
     "c5-slice": dict(vdim=128, ids=200_000_000, hyper=dict(l1=1.0)),
-    "c2": dict(vdim=8, rows=100, ids=47_236, hyper=dict(l1=1.0, lr=0.1)),
+    # (single_queue: minibatches this small are launch latency, not throughput — the Localizer's stages ride in the step's own three
+    # launches instead of taking five launches and two event hand-overs on a second queue: the same device time, half the host
+    # time per step, which is what bounds this preset)
+    "c2": dict(vdim=8, rows=100, ids=47_236, hyper=dict(l1=1.0, lr=0.1), single_queue=True),
 }
 
 
@@ -76,7 +79,7 @@ def parse_args():
     ap.add_argument("--prep-streams", type=int, default=1,
                     help="preparation streams = minibatches localized ahead of the one training (sgd_learner.cc:219-223 "
                          "keeps 2 in flight)")
-    ap.add_argument("--single-queue", dest="single_queue", action="store_true", default=False,
+    ap.add_argument("--single-queue", dest="single_queue", action="store_true", default=None,
                     help="the single-queue step (csrc/dfh_riders.hip): no preparation stream; the Localizer's stages of the next "
                          "minibatches ride as extra blocks of this step's own three launches")
     ap.add_argument("--two-queues", dest="single_queue", action="store_false",
@@ -137,6 +140,8 @@ def parse_args():
     if args.v_threshold is not None:
         hyper["V_threshold"] = args.v_threshold
     args.hyper = hyper
+    if args.single_queue is None:
+        args.single_queue = bool(pre.get("single_queue", False))
     if args.key_ranges is None:
         args.key_ranges = "blend" if args.preset == "c5-slice" else "data"
     return args
@@ -223,7 +228,8 @@ def secondary_lines(args):
             if name == "c2":
                 e["cpu_baseline"] = d.get("cpu_baseline")
             e["config"] = {k: d["config"].get(k) for k in ("workload", "rows_per_step", "unique_keys_per_batch", "model_keys",
-                                                           "table_bytes", "hyper", "prefilled")}
+                                                           "table_bytes", "hyper", "prefilled", "single_queue",
+                                                           "minibatches_prepared_ahead")}
             e["wall_seconds"] = time.time() - t0
             out[name] = e
         except Exception as ex:  # noqa: BLE001 — the headline line must survive anything here

@@ -130,3 +130,21 @@ def test_committed_default_line_carries_the_request_ceiling():
     assert sec["c3-cold"]["config"]["prefilled"] is False and sec["c3-cold"]["steps"] == 256 and sec["c3-cold"]["warmup"] == 0
     c2 = sec["c2"]
     assert c2["cpu_baseline"]["kind"] in ("reference", "port") and c2["value"] > 5 * c2["cpu_baseline"]["value"]
+
+
+def test_committed_dry_run_line_carries_the_wire_probe():
+    """`bench.py --gpus N` measures the wires before its timed region (dfh_comm_wire_probe: grouped all-to-all
+    of fixed sizes per peer on the library's own communicator), so that the first run on a real node replaces the assumed
+    link rate of the projection by itself.  Checked on the committed 8-rank dry run (ranks sharing one GPU, exchange staged
+    over gloo: the rates are the host's, the block's shape is the real run's)."""
+    d = json.loads(open(newest("r0[6-9]*_dryrun_shared_gpu_w8.json", "r06z_dryrun_shared_gpu_w8.json")).read().strip().splitlines()[-1])
+    assert d["n_gpus"] == 8 and d["lr_divided_by_world"] == 8 and d["value"] > 0
+    wp = d["wire_probe"]
+    assert wp["peers"] == 7 and len(wp["per_size"]) >= 2
+    for p in wp["per_size"]:
+        assert p["bytes_per_peer"] > 0 and p["us_per_grouped_exchange"] > 0
+        assert abs(p["gbps_per_link_and_direction"] - p["bytes_per_peer"] / p["us_per_grouped_exchange"] / 1e3) < 1e-9
+    x = d["roofline_exchange"]
+    best = max(p["gbps_per_link_and_direction"] for p in wp["per_size"])
+    assert abs(x["measured_wire_gbps_per_link_and_direction"] - best) < 1e-12
+    assert abs(x["frac_of_measured_wire"] - x["achieved"] / (2.0 * 7 * best)) < 1e-9

@@ -37,6 +37,7 @@ line c2 --preset c2
 line c2_single_queue --preset c2 --single-queue
 line sharded_w1_native_overlap --force-sharded --exchange overlap
 line sharded_w1_native_sync --force-sharded --exchange sync
+( time timeout 600 python bench.py --force-sharded --min-time 1 ) > $O/bench_sharded_w1_full.json 2> $O/bench_sharded_w1_full.err; tail -2 $O/bench_sharded_w1_full.err
 timeout 900 python bench.py --emulate-world 8 --emulate-rank auto --cpu-batches 0 --min-time 1 > $O/emul_c4_w8.json 2> $O/emul_c4_w8.err
 python -c "
 import json
@@ -84,5 +85,5 @@ for l in open(sys.argv[1]):
 PY
 DIFACTO_PROFILE=1 E2E_FORMATS=libsvm E2E_BATCH_SIZE=100 E2E_VDIM=8 timeout 600 python $R/tools/e2e_cli.py 100000 4 > $O/e2e_c2shape.jsonl 2> $O/e2e_c2shape.err; grep 'host loop over' $O/e2e_c2shape.err | tail -2
 DFH_BENCH_BACKEND=gloo DFH_WIRE_PROBE_BYTES=100000,1000000 timeout 900 python bench.py --gpus 8 --steps 5 --warmup 2 --min-time 0 --ids 2000000 --rows 2000 --distinct 8 --cpu-batches 0 > $O/dryrun_shared_gpu_w8.json 2> $O/dryrun_shared_gpu_w8.err; tail -c 300 $O/dryrun_shared_gpu_w8.json; echo
-find $O -name "*.db" -delete; rm -rf $O/pmc_* $O/pmc5_* $O/pmcs_* $O/req_* $O/reqs_* $O/prof_c3 $O/prof_c3_np $O/prof_c3_cold
+find $O -name "*.db" -delete; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc5_FETCH_SIZE $O/pmc5_WRITE_SIZE $O/pmcs_FETCH_SIZE $O/pmcs_WRITE_SIZE $O/req_TCC* $O/reqs_TCC* $O/prof_c3 $O/prof_c3_np $O/prof_c3_cold
 du -sh $O
