@@ -375,7 +375,17 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   // whose inputs are already in HBM (no gather), loses 5 % with two: it keeps one
   const char* ps = getenv("DIFACTO_PREP_STREAMS");
   const bool feed_wanted = job.type == sgd::Job::kTraining && param_.shuffle > 0 && getenv("DIFACTO_HOST_FEED") == nullptr;
-  DFH_CALL(dfh_ctx_set_pipeline(ctx, ps ? std::max(1, std::min(atoi(ps), 4)) : (feed_wanted ? 2 : 1)));
+  // DIFACTO_SINGLE_QUEUE=1: the single-queue step (csrc/dfh_riders.hip: the Localizer's stages riding in the step's own three
+  // launches, no preparation stream, no events; minibatches then prepared TWO ahead so that every stage finds a launch to ride
+  // in).  Off by default: measured through this loop it loses at every size (profiles/r06m_*: batch 100, V_dim 8 from libsvm 2.22
+  // against 1.59 M rows/s; batch 2 000 Criteo rows 28.7 against 21.9 M) — with the device feed the row gather is one more launch
+  // on the ONE queue and a launch with riders is as long as its longest rider, while two queues hide the whole preparation
+  // behind the step.  (Inputs resident in HBM, bench.py's C2 preset: the same rate with half the host time per step.)
+  const char* sqe = getenv("DIFACTO_SINGLE_QUEUE");
+  const bool single_queue = sqe != nullptr && atoi(sqe) != 0;
+  DFH_CALL(dfh_ctx_set_option(ctx, "single_queue", single_queue ? 1 : 0));
+  DFH_CALL(dfh_ctx_set_pipeline(ctx, ps ? std::max(1, std::min(atoi(ps), 4)) : (feed_wanted ? 2 : 1)));  // (ignored on the single queue)
+  const int ahead = single_queue ? 2 : 1;
   // minibatches are cut (permutation + row selection) two ahead on the reader's own thread, the reference's reader /
   // executor overlap (sgd_learner.cc:196-224).  Training with a shuffle buffer: the buffers go to HBM and the rows are
   // gathered there (device feed; DIFACTO_HOST_FEED=1 keeps the host-side gather)
@@ -499,39 +509,42 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   if (device_feed && !all_there() && !(getenv("DIFACTO_FEED_PRECREATE") && atoi(getenv("DIFACTO_FEED_PRECREATE")) == 0))
     ensure(param_.batch_size, static_cast<size_t>(param_.batch_size) * ids_per_row);
   const double t_created = prof ? now() : 0;
-  bool have = reader.Next();
-  const double t_first = prof ? now() : 0;
-  if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
-  int i = 0;
-  if (have) prepare(0);
-  if (prof) {
-    const double t1 = now();
-    LOG(INFO) << "start-up: batch objects " << t_created - (t_first - t_read) << " s, first minibatch from the reader after "
-              << t_first - t_created << " s more, its preparation queued in " << t1 - t_first << " s";
-    t_prep += t1 - t0;
-    t0 = t1;
-  }
-  while (have) {
-    const int cur = i % nrot, nxt = (i + 1) % nrot;
-    const bool have_next = reader.Next();
-    if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
-    bool stepped = false;
-    if (have_next && needs_growth(reader.Value())) {
-      // growing re-creates ALL batch objects: the prepared, not yet trained batch goes first
-      DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
-      if (predict) WritePredictions(batch_[cur]);
-      stepped = true;
-    }
-    if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
-    if (have_next) prepare(nxt);
-    if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
-    if (!stepped) {
-      DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
-      if (predict) WritePredictions(batch_[cur]);
-    }
-    if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
-    have = have_next;
+  // minibatch i sits in object i mod nrot.  `ahead` minibatches are prepared in front of the one that steps (1: prepare(i + 1),
+  // step(i) — the two minibatches the reference keeps in flight, sgd_learner.cc:219-223; 2 on the single queue)
+  static_assert(kFusedBatches >= 3, "three objects in rotation at least");
+  int prepared = 0, i = 0;   // minibatches prepared / stepped so far
+  bool more = true;
+  auto step_one = [&] {
+    const int cur = i % nrot;
+    DFH_CALL(dfh_sgd_step(table, batch_[cur], train ? 1 : 0, push_cnt ? 1 : 0));
+    if (predict) WritePredictions(batch_[cur]);
     ++i;
+  };
+  double t_first = 0;
+  auto prepare_next = [&] {   // -> false: the reader is exhausted
+    if (!more) return false;
+    more = reader.Next();
+    if (prepared == 0 && prof) t_first = now();
+    if (prof) { const double t1 = now(); t_read += t1 - t0; t0 = t1; }
+    if (!more) return false;
+    if (needs_growth(reader.Value())) {
+      // growing re-creates ALL batch objects: the prepared, not yet trained minibatches go first
+      while (i < prepared) step_one();
+      if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
+    }
+    prepare(prepared % nrot);
+    ++prepared;
+    if (prof) { const double t1 = now(); t_prep += t1 - t0; t0 = t1; }
+    return true;
+  };
+  for (int a = 0; a < ahead; ++a) prepare_next();
+  if (prof)
+    LOG(INFO) << "start-up: batch objects " << t_created - (t_first - t_read) << " s, first minibatch from the reader after "
+              << t_first - t_created << " s more, the first preparations queued in " << now() - t_first << " s";
+  while (i < prepared) {
+    prepare_next();
+    step_one();
+    if (prof) { const double t1 = now(); t_step += t1 - t0; t0 = t1; }
   }
   if (prof)
     LOG(INFO) << "host loop over " << i << " minibatches: reader " << t_read << " s, stage + localize + lookup " << t_prep
@@ -566,6 +579,7 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
   PrefetchSource reader(new BatchReader(JobData(job), param_.data_format, job.part_idx, job.num_parts, param_.batch_size,
                                         train ? param_.batch_size * param_.shuffle : 0, train ? param_.neg_sampling : 1.0f), 2);
   dfh_ctx* ctx = DeviceContext::Get();
+  DFH_CALL(dfh_ctx_set_option(ctx, "single_queue", 0));  // (a fused job of small minibatches may have left it on)
   DFH_CALL(dfh_ctx_set_pipeline(ctx, 1));
   auto drain = [&](dfh_batch* b) {
     dfh_progress p;
