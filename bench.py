@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=256,
                     help="distinct synthetic batches cycled through (independent of --steps; SURVEY 8d asks for a stream of "
                          "1 000: 256 x 390 000 ids already revisits a batch only every ~30 ms of device time)")
+    ap.add_argument("--bias-slots", type=int, default=0,
+                    help="diagnostic (NOT the metric): the first n slots carry ONE id in every row (a bias-like feature, the token of a "
+                         "missing value): keys with B occurrences per minibatch, the update kernel's longest segments")
     ap.add_argument("--no-auc", action="store_true",
                     help="A/B: leave BinClassMetric::AUC out of the step (the reference computes it for every minibatch, "
                          "sgd_learner.cc:153-155; the default step does too)")
@@ -415,7 +418,13 @@ def main():
     if criteo:
         capacity = int(args.ids * 1.02) + 4 * B * S
         bgen = synth.CriteoSynth(total_ids=args.ids, seed=42)   # its own generator object: `gen` serves the prefill
-        fut_batches = pool.submit(lambda: [bgen.batch(B) for _ in range(nd)])
+
+        def draw():
+            hb = bgen.batch(B)
+            for g in range(min(args.bias_slots, S)):   # (--bias-slots: one id in every row of the slot)
+                hb["index"].reshape(B, S)[:, g] = bgen.ids_of(g, np.zeros(1, np.int64))[0]
+            return hb
+        fut_batches = pool.submit(lambda: [draw() for _ in range(nd)])
     else:
         capacity = int(args.ids * 1.5) + 4096
         fut_batches = pool.submit(rcv1_shaped_batches, np.random.default_rng(42), nd, B, args.ids)

@@ -50,6 +50,7 @@ struct dfh_ctx {
   // found: 58.7 us; more list blocks cost more in block dispatch than they save in chain length)
   int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
   int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
+  int upd_split = 1;           // keys with more than HOT_SPLIT occurrences part by part, a block per part (0: the hot role walks them whole; A/B)
   int auc_in_update = 1;       // a training step's AUC as the first blocks of k_update_fused (1) or a launch of its own (0)
   int shard_mixed_update = 1;  // sharded step: one k_update_fused<MIXED> launch for own + others' keys (1) or round 4's two launches (0)
   int grow_initial_rows = 1 << 20;  // first allocation of a growing table (dfh_table_create with capacity_rows = 0)
@@ -185,6 +186,11 @@ struct dfh_batch {
   // long-segment key lists for the backward pass (SegLists): list buckets = sort buckets
   uint2 *d_mid = nullptr, *d_hot = nullptr, *d_few = nullptr;  // [list buckets] {cnt, off}
   SegEnt *d_mid_ent = nullptr, *d_hot_ent = nullptr, *d_few_ent = nullptr;
+  // the parts of the keys with more than HOT_SPLIT_MIN occurrences (SegLists::split_ent), their partial sums and tickets
+  SegEnt* d_split_ent = nullptr;
+  uint32_t* d_split_ticket = nullptr;
+  float* d_split_part = nullptr;
+  size_t split_cap = 0;
   uint32_t seg_nb = 0;                              // list buckets of the current localized view
   uint2* d_uw = nullptr;           // {table row, w} per unique key, written by the step's k_lookup
   uint32_t *d_urow = nullptr, *d_need = nullptr, *d_rank = nullptr, *d_total = nullptr;
@@ -546,6 +552,8 @@ BatchView batch_view(const dfh_batch* b) {
   v.seg.hot_ent = b->d_hot_ent;
   v.seg.few = b->d_few;
   v.seg.few_ent = b->d_few_ent;
+  v.seg.split_ent = b->d_split_ent;
+  v.seg.split_n = b->d_U + 2;   // the batch's device scalar block: [0] U, [1] REFRAND total, [2] entries of the split list
   return v;
 }
 
@@ -705,6 +713,11 @@ UpdArgs upd_args(dfh_batch* b, const TableView& tv, int k, int kp, uint32_t* nee
   a.seg.hot_ent = b->d_hot_ent;
   a.seg.few = b->d_few;
   a.seg.few_ent = b->d_few_ent;
+  a.seg.split_ent = b->d_split_ent;
+  a.seg.split_n = b->d_U + 2;
+  a.split_part = b->d_split_part;
+  a.split_ticket = b->d_split_ticket;
+  a.nb_split = 0;
   a.nrows = (uint32_t)b->nrows;
   a.nlist = b->seg_nb;
   a.k = k;
@@ -757,6 +770,8 @@ int launch_update_fused(dfh_batch* b, const TableView& tv, int k, int kp, uint32
   // slopes of a block's four examples sit in that XCD's L2): the blocks before it add up to a multiple of 8.  (Measured in
   // round 4 by shifting the role 1 or 4 blocks: no difference, 86.0 against 85.9 M examples/sec — kept because it is free.)
   a.nb_few += (8u - (a.nb_hot + a.nb_mid + a.nb_few) % 8u) % 8u;
+  // the parts of keys with more than HOT_SPLIT_MIN occurrences: taken by the hot role's blocks before their own lists
+  a.nb_split = (c->upd_split && nnz > HOT_SPLIT_MIN) ? 1u : 0u;
   const size_t nb_single = std::max<size_t>(1, std::min<size_t>((b->nrows + UPD_NW - 1) / UPD_NW, (size_t)c->upd_single_blocks));
   hipEvent_t ea = nullptr, eb = nullptr;  // timing rides on the dispatch, like the forward's
   if ((c->timing >> DFH_K_BACKWARD) & 1u) {
@@ -1033,6 +1048,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "shard_mixed_update") {
     DFH_ARG(value == 0 || value == 1, "shard_mixed_update must be 0 or 1");
     c->shard_mixed_update = value;
+  } else if (n == "upd_split") {
+    DFH_ARG(value == 0 || value == 1, "upd_split must be 0 (one block per hot key, whatever its length) or 1 (a block per part of 1 024 occurrences)");
+    c->upd_split = value;
   } else if (n == "upd_interleave") {
     DFH_ARG(value >= 0 && value <= 64, "upd_interleave must be in [0, 64]");
     c->upd_interleave = value;
@@ -2067,6 +2085,10 @@ static int batch_create_impl(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_ba
   DFH_ALLOC(b->d_mid_ent, N / (BWD_SMALL + 1) + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
   DFH_ALLOC(b->d_hot_ent, N / (BWD_MID + 1) + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
   DFH_ALLOC(b->d_few_ent, N / 2 + 2 * LOC_BIG_BUCKETS + 16, SegEnt);
+  b->split_cap = 2 * (N / HOT_SPLIT) + 16;   // >= the sum over the segments longer than HOT_SPLIT_MIN of ceil(len / HOT_SPLIT)
+  DFH_ALLOC(b->d_split_ent, b->split_cap, SegEnt);
+  DFH_ALLOC(b->d_split_ticket, b->split_cap, uint32_t);
+  DFH_ALLOC(b->d_split_part, b->split_cap * UPD_SPLIT_STRIDE, float);
   DFH_ALLOC(b->d_mid, LOC_BIG_BUCKETS, uint2);
   DFH_ALLOC(b->d_hot, LOC_BIG_BUCKETS, uint2);
   DFH_ALLOC(b->d_few, LOC_BIG_BUCKETS, uint2);
@@ -2091,6 +2113,8 @@ static int batch_create_impl(dfh_ctx* c, size_t max_rows, size_t max_nnz, dfh_ba
   if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&b->ev_free, evf);
   if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_prog, 0, (2 * PROG_SLOTS + 64) * sizeof(double), c->stream);
   if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_U, 0, 64 * sizeof(uint32_t), c->stream);
+  // a key's ticket is back at zero when its last part has been applied (upd_split_role)
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_split_ticket, 0, b->split_cap * sizeof(uint32_t), c->stream);
   // k_loc_sort keeps the bucket totals zero between calls
   if (e2 == hipSuccess) e2 = hipMemsetAsync(b->d_btotal, 0, LOC_XCDS * LOC_BIG_BUCKETS * sizeof(uint32_t), c->stream);
   // row ids are written by the lookups of the keys a step resolves; anything else must never be used as one:
@@ -2857,6 +2881,9 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     o.sl.hot_ent = b->d_hot_ent;
     o.sl.few = b->d_few;
     o.sl.few_ent = b->d_few_ent;
+    o.sl.split_ent = b->d_split_ent;
+    o.sl.split_n = b->d_U + 2;
+    v.split_n = b->d_U + 2;
     b->loc_big = big;
 #ifndef DFH_LOC_GRID_CAP
 #define DFH_LOC_GRID_CAP 1024
@@ -2899,7 +2926,7 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
                        b->d_offset, b->has_value ? b->d_value : (const float*)nullptr, b->d_feaids, b->d_col_ptr, b->d_index,
                        b->d_s_row, b->d_s_val, b->d_U);
     // keys with long segments, for the backward pass: one list bucket
-    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few);
+    hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few, b->d_U + 2);
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((N + 1023) / 1024, 256))), dim3(1024), 0, s,
                        b->d_col_ptr, b->d_U, b->d_mid, b->d_hot, b->d_few, b->d_mid_ent, b->d_hot_ent, b->d_few_ent);
     b->seg_nb = 1;
@@ -3187,7 +3214,7 @@ int dfh_batch_load_localized_host(dfh_batch* b, size_t nrows, const size_t* offs
   if (U && feacnt) DFH_HIP(hipMemcpyAsync(b->d_feacnt, feacnt, U * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_col_ptr, col_ptr.data(), (U + 1) * 4, hipMemcpyHostToDevice, s));
   DFH_HIP(hipMemcpyAsync(b->d_U, &U32, 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few);
+  hipLaunchKernelGGL(k_seg_lists_reset, dim3(1), dim3(64), 0, s, b->d_mid, b->d_hot, b->d_few, b->d_U + 2);
   if (U) {
     hipLaunchKernelGGL(k_seg_lists, dim3((unsigned)std::min<size_t>((U + 1023) / 1024, 256)), dim3(1024), 0, s, b->d_col_ptr,
                        b->d_U, b->d_mid, b->d_hot, b->d_few, b->d_mid_ent, b->d_hot_ent, b->d_few_ent);

@@ -1442,11 +1442,12 @@ __global__ void __launch_bounds__(1024) k_seg_lists(const uint32_t* __restrict__
 }
 
 // one list bucket at offset 0, empty: what k_seg_lists adds to
-__global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0, uint2* few0) {
+__global__ void k_seg_lists_reset(uint2* mid0, uint2* hot0, uint2* few0, uint32_t* split_n) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     *mid0 = make_uint2(0u, 0u);
     *hot0 = make_uint2(0u, 0u);
     *few0 = make_uint2(0u, 0u);
+    *split_n = 0u;   // (these paths list whole segments only: no part lists)
   }
 }
 

@@ -96,7 +96,13 @@ struct UpdArgs {
   const float* rrows;       // pulled rows, rstride floats each, indexed by the key's rank
   float* grows;             // gradient rows out, same layout
   uint32_t rstride;
+  // round 6: the keys with more than HOT_SPLIT_MIN occurrences, one block per PART of HOT_SPLIT (upd_split_role): partial sums per part in
+  // split_part[entry][UPD_SPLIT_STRIDE], a ticket per key in split_ticket[first entry] (zero between launches)
+  float* split_part;
+  uint32_t* split_ticket;
+  uint32_t nb_split;        // 1: the hot role's blocks take the split list's parts first; 0: keys of any length go through the hot role whole
 };
+constexpr int UPD_SPLIT_STRIDE = 4 + 256;   // gw, xxp, -, - | gv[kp <= 256]
 
 // Model rows (V, accumulators) are loaded and stored with streaming (nt) hints.  Measured dead end, kept as
 // -DDFH_UPD_NT=1: the same hints on everything else that is read once per launch (occurrence lists, row words, segment
@@ -366,6 +372,7 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
       const uint32_t u = e.x;
       if (!key_in(a.rg, u)) continue;  // uniform per block
       const uint32_t beg = e.y, end = e.z;
+      if (a.nb_split && end - beg > HOT_SPLIT_MIN) continue;  // its parts are in the split list: upd_split_role
       const uint32_t rw = ld_rowword(a.uw + u);
       const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
@@ -395,6 +402,82 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
         }
         upd_apply<EXACT, MIXED>(a, r, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)(end - beg), (rw & kCountLater) != 0u,
                                 (rw & kRemoteRow) != 0u);
+      }
+    }
+  }
+}
+
+// ---- split: one PART (<= HOT_SPLIT occurrences) of a very hot key per block and iteration.  A key in every row of the minibatch
+// (a bias-like feature, the token of a missing value) is a segment of B occurrences: in the hot role ONE block walks it, 40
+// tiles per wave at C3 size, ~3 dependent round trips each — a launch as long as that chain whatever else it holds.  Here
+// every part has a block; a part's sums go to split_part[entry] (stores, then a device-scope RELEASE: the L2's dirty lines are
+// written back — no invalidate), a ticket per key counts the parts that have arrived, and the block that brings the LAST part
+// adds the partials up IN PART ORDER (reads that bypass the L2: agent-scope atomic loads) — deterministic, whichever block
+// comes last — fetches the row and applies the update.  Nobody waits for anybody.
+template <int L, bool EXACT, int DB, bool HAS_VAL, bool MIXED>
+__device__ __forceinline__ void upd_split_role(const UpdArgs& a, uint32_t blk, uint32_t nblk, float& pen, char* smem) {
+  float (*part)[2 + 256] = reinterpret_cast<float (*)[2 + 256]>(smem);
+  const int lane = lane_id();
+  const int grp = lane / L, sub = lane % L;
+  const int kp = EXACT ? 4 * L : a.kp, k = a.k;
+  const bool sub_ok = EXACT ? true : (sub * 4 < kp);
+  const int w = threadIdx.x >> 6;
+  const uint32_t n = *a.seg.split_n;
+  for (uint32_t j = blk; j < n; j += nblk) {
+    const SegEnt e = a.seg.split_ent[j];
+    const uint32_t u = e.x, beg = e.y, end = e.z, p = e.w >> 16, nparts = e.w & 0xFFFFu;
+    if (!key_in(a.rg, u)) continue;  // uniform per block (and per key: none of its parts takes a ticket)
+    const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
+    __syncthreads();  // the previous part's partials have been consumed
+    if (grp == 0) {
+      if (sub == 0) { part[w][0] = s.gw; part[w][1] = s.xxp; }
+      if (sub_ok) {
+        part[w][2 + sub * 4 + 0] = s.gv.x; part[w][2 + sub * 4 + 1] = s.gv.y;
+        part[w][2 + sub * 4 + 2] = s.gv.z; part[w][2 + sub * 4 + 3] = s.gv.w;
+      }
+    }
+    __syncthreads();
+    if (w == 0 && grp == 0) {   // (wave-uniform up to the lane group: the other groups of wave 0 idle through this)
+      float gw = 0.f, xxp = 0.f;
+      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < UPD_NW; ++i) {  // wave order: deterministic
+        gw += part[i][0];
+        xxp += part[i][1];
+        if (sub_ok) {
+          g4.x += part[i][2 + sub * 4 + 0]; g4.y += part[i][2 + sub * 4 + 1];
+          g4.z += part[i][2 + sub * 4 + 2]; g4.w += part[i][2 + sub * 4 + 3];
+        }
+      }
+      const uint32_t first = j - p;   // a key's parts are consecutive entries
+      float* mine = a.split_part + (size_t)j * UPD_SPLIT_STRIDE;
+      if (sub == 0) { mine[0] = gw; mine[1] = xxp; }
+      if (sub_ok) st4(mine + 4 + sub * 4, g4);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this part's sums are in memory before its ticket is
+      uint32_t t = 0;
+      if (sub == 0) t = atomicAdd(a.split_ticket + first, 1u);
+      t = __shfl(t, 0, 64);   // (lane 0 is sub 0 of group 0)
+      if (t == nparts - 1u) {   // the last part of its key to arrive: add the parts up in part order, apply
+        gw = 0.f; xxp = 0.f;
+        g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t q = 0; q < nparts; ++q) {
+          const float* pq = a.split_part + (size_t)(first + q) * UPD_SPLIT_STRIDE;
+          gw += __hip_atomic_load(pq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          xxp += __hip_atomic_load(pq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float* gq = pq + 4 + (sub_ok ? sub * 4 : 0);
+          g4.x += __hip_atomic_load(gq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g4.y += __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g4.z += __hip_atomic_load(gq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g4.w += __hip_atomic_load(gq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t kbeg = a.seg.split_ent[first].y, kend = a.seg.split_ent[first + nparts - 1u].z;
+        const uint32_t rw = ld_rowword(a.uw + u);
+        float4 h0, vv, ac;
+        float fc;
+        upd_load<MIXED>(a, rw, sub, sub_ok, kp, h0, vv, ac, fc);
+        upd_apply<EXACT, MIXED>(a, rw & kRowMask, u, h0, vv, ac, gw, xxp, g4, sub, sub_ok, k, kp, pen, fc, (float)(kend - kbeg),
+                                (rw & kCountLater) != 0u, (rw & kRemoteRow) != 0u);
+        if (sub == 0) a.split_ticket[first] = 0u;   // ready for the next launch
       }
     }
   }
@@ -600,6 +683,7 @@ __device__ __forceinline__ void update_body(const UpdArgs& a, const uint32_t blk
   __syncthreads();
   float pen = 0.f;
   const uint32_t w = threadIdx.x >> 6;
+
   // block -> role.  The list roles (hot, mid, few) are chains of dependent round trips on few bytes, the singles
   // stream most of the launch's HBM traffic: dispatched in that order the former would hold every block slot of
   // the chip for the length of their chains before the first model row moves.  Interleaved 1 : (R - 1) both kinds
@@ -630,8 +714,12 @@ __device__ __forceinline__ void update_body(const UpdArgs& a, const uint32_t blk
     if (DFH_UPD_ROLES & 8)
     upd_singles_role<L, EXACT, DFH_UPD_ROUNDS, HAS_VAL, MIXED>(a, bid * UPD_NW + w, nb_single * UPD_NW, pen);
   } else if (bid < a.nb_hot) {
-    if (DFH_UPD_ROLES & 1)
-    upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
+    if (DFH_UPD_ROLES & 1) {
+      // the parts of the very hot keys first — the longest chains of the launch, taken by the hot role's own blocks (a list that is
+      // empty on most data: one load per block) — then the hot keys
+      if (a.nb_split) upd_split_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
+      upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
+    }
   } else if ((bid -= a.nb_hot) < a.nb_mid) {
     if (DFH_UPD_ROLES & 2)
     upd_mid_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid * UPD_NW + w, a.nb_mid * UPD_NW, pen);

@@ -720,6 +720,49 @@ def test_fused_step_hot_keys(capi, ctx, oracle):
     _run_fused_vs_oracle(capi, ctx, oracle, 16, "hash", [b], 4, kw)
 
 
+@pytest.mark.parametrize("V_dim,binary", [(8, False), (64, True)])
+def test_fused_step_keys_in_every_row(capi, ctx, oracle, V_dim, binary):
+    """a bias-like feature and a missing-value token — keys that occur in EVERY row and in 70 % of the rows of a 6 000-row
+    minibatch, segments of 6 000 and ~4 200 occurrences (beyond 3 072: split): k_update_fused gives every part of 1 024
+    occurrences a block of its own (upd_split_role: partial sums per part, a ticket per key, the last part to arrive adds them up in part order), where
+    the hot role had one block walk the whole segment.  Step by step against the oracle at the model's tolerance, and the
+    result does not depend on which block comes last: two runs are bit-identical."""
+    rng = np.random.default_rng(33)
+    nrows = 6000
+    batches = []
+    for _ in range(2):
+        rows_idx, off = [], [0]
+        for i in range(nrows):
+            ids = [7, 11] if rng.random() < 0.7 else [7]
+            ids += list(rng.integers(100, 40000, size=int(rng.integers(2, 7))))
+            rows_idx.append(np.array(ids, np.uint64))
+            off.append(off[-1] + len(ids))
+        idx = np.concatenate(rows_idx)
+        val = None if binary else (rng.normal(size=len(idx)) * 0.3).astype(np.float32)
+        lab = np.where(rng.random(nrows) < 0.3, 1.0, -1.0).astype(np.float32)
+        batches.append(dict(offset=np.array(off, np.uint64), index=idx, value=val, label=lab))
+    kw = dict(l1=0.01, l2=0.0, lr=0.05, V_lr=0.02, V_l2=0.01, V_threshold=0, V_init_scale=0.1, seed=4)
+    _run_fused_vs_oracle(capi, ctx, oracle, V_dim, "hash", batches, 2, kw, capacity=1 << 17)
+    finals = []
+    for _ in range(2):
+        tb = capi.Table(ctx, 1 << 17, V_dim=V_dim, init_mode=capi.INIT_HASH, **kw)
+        bt = capi.Batch(ctx, nrows, int(batches[0]["offset"][-1]) + 4096)
+        preds = []
+        for ep in range(3):
+            for b in batches:
+                bt.load_host(b["offset"], b["index"], b["value"], b["label"])
+                bt.localize()
+                bt.sgd_step(tb, is_train=True, push_cnt=(ep == 0))
+                preds.append(bt.pred())
+        keys = np.unique(np.concatenate([oracle.localize(b["offset"], b["index"])["feaids"] for b in batches]))
+        finals.append((preds, tb.pull(keys)))
+        bt.close()
+        tb.close()
+    for a, b in zip(finals[0][0], finals[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(finals[0][1][0], finals[1][1][0]) and np.array_equal(finals[0][1][1], finals[1][1][1])
+
+
 SGD_BASIC = [69.314718, 69.314718, 67.151912, 61.414778, 56.244989, 53.218700, 51.248737, 49.846688,
              48.650164, 47.698351, 46.924038, 46.388223, 45.970721, 45.499307, 45.102245, 44.798413,
              44.565211, 44.386417, 44.240657, 44.109764]
