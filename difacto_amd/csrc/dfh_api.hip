@@ -2881,8 +2881,6 @@ int localize_impl(dfh_batch* b, uint64_t max_index, dfh_table* probe) {
     o.sl.hot_ent = b->d_hot_ent;
     o.sl.few = b->d_few;
     o.sl.few_ent = b->d_few_ent;
-    o.sl.split_ent = b->d_split_ent;
-    o.sl.split_n = b->d_U + 2;
     v.split_n = b->d_U + 2;
     b->loc_big = big;
 #ifndef DFH_LOC_GRID_CAP
@@ -3374,17 +3372,19 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
     TimeScope ts(c, DFH_K_LOOKUP);
     // (the lookup's first block also adds up the AUC slots this batch object's previous step left behind)
     const int gl = grid_for_threads(Nb, c);
+    // the pass that sees every unique key's segment lists the parts of the very hot ones for the update's split role
+    const SplitOut so = (is_train && c->upd_kernel && c->upd_split) ? SplitOut{b->d_split_ent, b->d_U + 2, 0u} : SplitOut{nullptr, nullptr, 0u};
     RiderSet rs;  // single-queue step: the stages of later minibatches' Localizer that belong into this launch
     collect_riders(c, 0, true, ((uint32_t)gl + 7u) / 8u, &rs);
     if (rs.n)
       hipLaunchKernelGGL(k_lookup_riders, dim3((((unsigned)gl + 7u) / 8u + rs.ngroups) * 8u), dim3(256), rider_smem(rs), s, t->v, b->d_feaids,
                          b->d_U, 0u, b->d_urow, b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr,
                          push_cnt ? (defer_cnt ? 2 : 1) : 0, refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b),
-                         (uint32_t)gl, rs);
+                         so, (uint32_t)gl, rs);
     else
-    hipLaunchKernelGGL(k_lookup, dim3(gl), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+    hipLaunchKernelGGL(k_lookup_step, dim3(gl), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
-                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b));
+                       refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b), so);
     b->auc_pending_n = 0;
   }
   DFH_HIP(hipGetLastError());

@@ -78,7 +78,7 @@ struct SegLists {
   // ALSO listed part by part — {u, beg_p, end_p, p << 16 | nparts}, the parts of a key consecutive — so that k_update_fused can
   // give every part a block of its own (upd_split_role); it stays in the hot list for the consumers that take whole segments
   const SegEnt* split_ent;
-  const uint32_t* split_n;  // entries in split_ent (device scalar, reset by the Localizer's count pass)
+  const uint32_t* split_n;  // entries in split_ent (device scalar: reset by the Localizer's count pass, filled by k_lookup_step)
 };
 constexpr uint32_t HOT_SPLIT = 1024;       // occurrences per part
 // ... of the segments LONGER than this.  A key of up to ~3 000 occurrences is 12 tiles per wave of its hot-role block: a chain
@@ -86,6 +86,9 @@ constexpr uint32_t HOT_SPLIT = 1024;       // occurrences per part
 // blocks' partial sums, a release fence each — profiles/r06n_*); a key in every one of 10 000 rows is 40 tiles per wave and
 // sets the launch's length (120 against 72 us).
 constexpr uint32_t HOT_SPLIT_MIN = 3072;
+#ifndef DFH_HOT_SPLIT_BUILD
+#define DFH_HOT_SPLIT_BUILD 3   // measurement builds: bit 0 the parts are listed (k_lookup_step), bit 1 k_update_fused has the split role
+#endif
 
 // flag bits of the row word k_lookup / k_uw_remote leave per unique key in uw[]: a table holds fewer
 // than 2^28 rows (dfh_table_create), so the four top bits are free

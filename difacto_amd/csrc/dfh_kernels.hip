@@ -502,10 +502,30 @@ __global__ void __launch_bounds__(256) k_auc_finalize(AucFin f) { auc_finalize_b
 // Push(kFeaCount): fea_cnt += cnt, maybe InitV (sgd_updater.cc:62-73).
 // cnt_from_ptr: counts are the segment lengths of the localized batch.
 // ---------------------------------------------------------------------------
+// The parts of the keys with more than HOT_SPLIT_MIN occurrences in the minibatch (SegLists::split_ent), listed by the pass that
+// visits every unique key before the update and has its segment at hand (col_ptr): one atomic on the list's counter per such key —
+// a handful per minibatch at most.  (Round 6's first form listed them in k_loc_emit: the inlined loop took that kernel from 28 to
+// 36 registers, and an emit wave of 36 no longer fits in the 32 registers five 96-register waves of k_update_fused leave free on
+// a SIMD: the first epoch's steps, where emit runs beside the update, lost 15 % — profiles/r06r_*.)
+struct SplitOut {
+  SegEnt* ent;        // NULL: no list (the update's hot role takes every key whole)
+  uint32_t* n;        // entries so far (zeroed by the Localizer's count pass)
+  uint32_t u_base;    // rank of the first key this launch sees (the sharded store looks up its own keys only)
+};
+__device__ __forceinline__ void lookup_split(const SplitOut& so, uint32_t u, uint32_t beg, uint32_t end) {
+  if (!(DFH_HOT_SPLIT_BUILD & 1) || !so.ent || end - beg <= HOT_SPLIT_MIN) return;
+  const uint32_t nparts = (end - beg + HOT_SPLIT - 1u) / HOT_SPLIT;
+  const uint32_t base = atomicAdd(so.n, nparts);
+  for (uint32_t p = 0; p < nparts; ++p)
+    so.ent[base + p] = make_uint4(u + so.u_base, beg + p * HOT_SPLIT, min(beg + (p + 1u) * HOT_SPLIT, end), (p << 16) | nparts);
+}
+
+template <bool SPLIT = true>
 __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
-                         int rows_known, uint2* __restrict__ uw, AucFin fin, const uint32_t bid, const uint32_t nblk) {
+                         int rows_known, uint2* __restrict__ uw, AucFin fin, const uint32_t bid, const uint32_t nblk,
+                         const SplitOut so = SplitOut{nullptr, nullptr, 0u}) {
   // a step's lookup also closes the AUC its batch object's previous step left pending (dfh_sgd_step; fin.n == 0: none)
   if (fin.n && bid == 0) auc_finalize_block(fin);
   uint32_t n = d_n ? *d_n : n_static;
@@ -523,6 +543,7 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
     else r = active ? find_or_insert(t, key) : 0u;
     if (!active) continue;
     if (urow && !rows_known) urow[u] = r;
+    if (SPLIT && col_ptr) lookup_split(so, u, col_ptr[u], col_ptr[u + 1]);
     float w = 0.f;
     bool hasv = false;
     if (push_cnt) {
@@ -567,11 +588,19 @@ __device__ __forceinline__ void lookup_body(const TableView& t, const uint64_t* 
   }
 }
 
+// (two kernels: the probe that runs on a preparation stream BESIDE the update must stay small in registers — its waves take what
+// five 96-register update waves leave free on a SIMD — so only the step's own pass carries the split-list code)
 __global__ void k_lookup(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
                          uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                          const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
                          int rows_known, uint2* __restrict__ uw, AucFin fin) {
-  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, blockIdx.x, gridDim.x);
+  lookup_body<false>(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, blockIdx.x, gridDim.x);
+}
+__global__ void k_lookup_step(TableView t, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ d_n,
+                              uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
+                              const uint32_t* __restrict__ col_ptr, int push_cnt, uint32_t* __restrict__ need_init,
+                              int rows_known, uint2* __restrict__ uw, AucFin fin, SplitOut so) {
+  lookup_body<true>(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, blockIdx.x, gridDim.x, so);
 }
 
 // sharded store: {u | kRemoteRow, w} for the keys OTHER ranks own, from the rows they sent (row u of
@@ -583,6 +612,7 @@ struct UwRemote {
   uint32_t lo, hi;
   uint2* uw;                 // the whole minibatch's array (the lookup's `uw` starts at the rank's own keys)
   const uint32_t* col_ptr;   // likewise
+  SplitOut so;               // the others' keys can be very hot too (u_base 0: ranks are the minibatch's)
 };
 __device__ __forceinline__ void uw_remote_body(const UwRemote& m) {
   const uint32_t U = *m.d_U;
@@ -590,20 +620,21 @@ __device__ __forceinline__ void uw_remote_body(const UwRemote& m) {
     if (u - m.lo < m.hi - m.lo) continue;
     // (bit 30: the key occurs once in the minibatch — the singles role of the mixed update launch takes it)
     const uint32_t single = (m.col_ptr && m.col_ptr[u + 1] - m.col_ptr[u] == 1u) ? kSingleRow : 0u;
+    if (m.col_ptr) lookup_split(m.so, u, m.col_ptr[u], m.col_ptr[u + 1]);
     const float2 wh = *reinterpret_cast<const float2*>(m.rows + (size_t)u * m.stride);   // [w, has_V (0 / 1 as float), ...]
     m.uw[u] = make_uint2(u | kRemoteRow | single | (wh.y != 0.f ? kHasV : 0u), __float_as_uint(wh.x));
   }
 }
 __global__ void k_uw_remote(const float* __restrict__ rows, size_t stride, const uint32_t* __restrict__ d_U, uint32_t lo,
-                            uint32_t hi, uint2* __restrict__ uw, const uint32_t* __restrict__ col_ptr) {
-  uw_remote_body(UwRemote{rows, stride, d_U, lo, hi, uw, col_ptr});
+                            uint32_t hi, uint2* __restrict__ uw, const uint32_t* __restrict__ col_ptr, SplitOut so) {
+  uw_remote_body(UwRemote{rows, stride, d_U, lo, hi, uw, col_ptr, so});
 }
 // the own keys' lookup and the others' row words in ONE launch (overlapped exchange: the rows of the other owners arrived
 // during the previous step; one launch boundary less on the main stream of the sharded step)
 __global__ void k_lookup_uw_remote(TableView t, const uint64_t* __restrict__ keys, uint32_t n_static, uint32_t* __restrict__ urow,
                                    const float* __restrict__ cnt, const uint32_t* __restrict__ col_ptr, int push_cnt,
-                                   uint2* __restrict__ uw, AucFin fin, UwRemote m) {
-  lookup_body(t, keys, nullptr, n_static, urow, cnt, col_ptr, push_cnt, nullptr, 0, uw, fin, blockIdx.x, gridDim.x);
+                                   uint2* __restrict__ uw, AucFin fin, UwRemote m, SplitOut so) {
+  lookup_body(t, keys, nullptr, n_static, urow, cnt, col_ptr, push_cnt, nullptr, 0, uw, fin, blockIdx.x, gridDim.x, so);
   uw_remote_body(m);
 }
 

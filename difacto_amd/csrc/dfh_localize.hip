@@ -117,7 +117,7 @@ struct LocView {
   uint64_t* last_key;
   uint32_t* nheads;       // [P] runs of equal keys inside the bucket
   uint32_t* lh;           // [P] local index of the bucket's last run head (0: one run only)
-  uint32_t* split_n;      // entries of the split list (SegLists::split_ent): zeroed by the count pass, filled by emit
+  uint32_t* split_n;      // entries of the split list (SegLists::split_ent): zeroed by the count pass, filled by the step's k_lookup
 };
 
 // long-segment lists for k_backward_all, one slot range per list bucket (dfh_internal.h: SegLists)
@@ -128,17 +128,7 @@ struct SegListsOut {
   SegEnt* hot_ent;
   uint2* few;   // keys with 2 .. BWD_SMALL occurrences (k_update_fused)
   SegEnt* few_ent;
-  SegEnt* split_ent;   // the parts of the keys with more than HOT_SPLIT_MIN occurrences (SegLists::split_ent)
-  uint32_t* split_n;
 };
-// a segment of more than HOT_SPLIT_MIN occurrences, in parts of HOT_SPLIT (rare: one atomic on the list's counter per such key)
-__device__ __forceinline__ void loc_emit_split(const SegListsOut& sl, uint32_t u, uint32_t beg, uint32_t end) {
-  if (!sl.split_ent) return;
-  const uint32_t nparts = (end - beg + HOT_SPLIT - 1u) / HOT_SPLIT;
-  const uint32_t base = atomicAdd(sl.split_n, nparts);
-  for (uint32_t p = 0; p < nparts; ++p)
-    sl.split_ent[base + p] = make_uint4(u, beg + p * HOT_SPLIT, min(beg + (p + 1u) * HOT_SPLIT, end), (p << 16) | nparts);
-}
 
 // ReverseBytes(id % max_index), localizer.cc:24; the 64-bit modulo is skipped for the
 // default max_index = 2^64-1 (x % (2^64-1) is x, except the all-ones id which maps to 0)
@@ -331,7 +321,7 @@ __device__ __forceinline__ void loc_count_block(const LocView& v, const uint32_t
     sp[b] = b < P - 1 ? v.spl_pos[b] : ~0u;
   }
   const uint32_t base = bid * LOC_TILE;
-  if (bid == 0 && threadIdx.x == 0 && v.split_n) *v.split_n = 0u;   // (emit, two launches on, appends to the list)
+  if (bid == 0 && threadIdx.x == 0 && v.split_n) *v.split_n = 0u;   // (the step's k_lookup appends to the list)
   uint64_t key[PER];
   if (GATHER) {
     // the rows that cover this tile: their offsets and where they start in their row buffer, in LDS
@@ -812,7 +802,6 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
           if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = e;
           else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = e;
           else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = e;
-          if (len > HOT_SPLIT_MIN) loc_emit_split(sl, uid - 1, prev1 - 1, i);
         }
       }
       index[pos] = uid;  // RemapIndex, localizer.cc:63-77
@@ -839,7 +828,6 @@ __device__ __forceinline__ void loc_emit_bucket(const LocView& v, uint32_t b, ui
         if (len > BWD_MID) sl.hot_ent[hoff + atomicAdd(n_hot, 1u)] = e;
         else if (len > BWD_SMALL) sl.mid_ent[moff + atomicAdd(n_mid, 1u)] = e;
         else if (len > 1) sl.few_ent[foff + atomicAdd(n_few, 1u)] = e;
-        if (len > HOT_SPLIT_MIN) loc_emit_split(sl, uid, lbeg, v.n);
       }
       // the splitters of the next call: the exact P-quantiles of this sorted order
       if (P > 1) {

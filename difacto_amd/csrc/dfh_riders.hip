@@ -117,10 +117,10 @@ __global__ void __launch_bounds__(RID_THREADS, 6) k_lookup_riders(TableView t, c
                                                               uint32_t n_static, uint32_t* __restrict__ urow, const float* __restrict__ cnt,
                                                               const uint32_t* __restrict__ col_ptr, int push_cnt,
                                                               uint32_t* __restrict__ need_init, int rows_known, uint2* __restrict__ uw,
-                                                              AucFin fin, uint32_t nblk_main, RiderSet rs) {
+                                                              AucFin fin, SplitOut so, uint32_t nblk_main, RiderSet rs) {
   struct KA {
     TableView t; const uint64_t* keys; const uint32_t* d_n; uint32_t n_static; uint32_t* urow; const float* cnt; const uint32_t* col_ptr;
-    int push_cnt; uint32_t* need_init; int rows_known; uint2* uw; AucFin fin; uint32_t nblk_main; RiderSet rs;
+    int push_cnt; uint32_t* need_init; int rows_known; uint2* uw; AucFin fin; SplitOut so; uint32_t nblk_main; RiderSet rs;
   };
   uint32_t idx;
   if (rider_map(rs, blockIdx.x, idx)) {
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(RID_THREADS, 6) k_lookup_riders(TableView t, c
     return;
   }
   if (idx >= nblk_main) return;
-  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, idx, nblk_main);
+  lookup_body(t, keys, d_n, n_static, urow, cnt, col_ptr, push_cnt, need_init, rows_known, uw, fin, idx, nblk_main, so);
 }
 
 // ---- F: k_forward + riders (the table's own rows: the fused single-GPU step)

@@ -179,6 +179,12 @@ __global__ void k_loop_wait(const unsigned long long* __restrict__ stamp, unsign
 
 using namespace dfh;
 
+// the list of the very hot keys' parts for the update's split role (SplitOut): filled by the launches of a training step that see
+// the minibatch's keys — the own keys' lookup (ranks offset by own_lo) and the others' row words
+static inline SplitOut shard_split_out(const dfh_ctx* ctx, dfh_batch* b, int is_train, uint32_t u_base) {
+  return (b && is_train && ctx->upd_kernel && ctx->upd_split) ? SplitOut{b->d_split_ent, b->d_U + 2, u_base} : SplitOut{nullptr, nullptr, 0u};
+}
+
 struct dfh_comm {
   dfh_ctx* ctx = nullptr;
   int rank = 0, world = 1;
@@ -1231,10 +1237,11 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     if (int rcr = table_reserve(t, W == 1 ? b->nnz : n_own)) return rcr;
     StageScope ts(s, DFH_SHARD_STAGE_L, st);
     const bool counts = push_cnt != 0;
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
+    hipLaunchKernelGGL(k_lookup_step, dim3(grid_for_threads(W == 1 ? b->nnz : n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + own_lo,
                        W == 1 ? b->d_U : (const uint32_t*)nullptr, W == 1 ? 0u : n_own, b->d_urow + own_lo,
                        (counts && b->has_cnt) ? b->d_feacnt + own_lo : (const float*)nullptr, b->d_col_ptr + own_lo,
-                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo, auc_pending(b));
+                       counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0, (uint32_t*)nullptr, 0, b->d_uw + own_lo, auc_pending(b),
+                       shard_split_out(ctx, b, is_train, own_lo));
     b->auc_pending_n = 0;  // (the lookup's first block added up the AUC slots this batch object's previous step left)
     DFH_HIP(hipGetLastError());
   }
@@ -1287,7 +1294,7 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (any_remote) {
       hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(U, ctx)), dim3(256), 0, st, s->w_rows[0], stride, b->d_U, own_lo, own_hi,
-                         b->d_uw, b->d_col_ptr);
+                         b->d_uw, b->d_col_ptr, shard_split_out(ctx, b, is_train, 0u));
       DFH_HIP(hipGetLastError());
     }
     MixSrc mix{any_remote ? s->w_rows[0] + 4 : nullptr, stride};
@@ -1442,13 +1449,14 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     const int mode = counts ? ((is_train && ctx->upd_kernel) ? 2 : 1) : 0;
     if (uw_folded) {
       DFH_HIP(hipStreamWaitEvent(st, s->ev_rw[cur.slot], 0));  // the rows of the other owners have arrived
-      const UwRemote m{s->w_rows[cur.slot], stride, b->d_U, cur.own_lo, cur.own_hi, b->d_uw, b->d_col_ptr};
+      const UwRemote m{s->w_rows[cur.slot], stride, b->d_U, cur.own_lo, cur.own_hi, b->d_uw, b->d_col_ptr, shard_split_out(ctx, b, is_train, 0u)};
       hipLaunchKernelGGL(k_lookup_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo, n_own,
-                         b->d_urow + cur.own_lo, cntp, b->d_col_ptr + cur.own_lo, mode, b->d_uw + cur.own_lo, auc_pending(b), m);
+                         b->d_urow + cur.own_lo, cntp, b->d_col_ptr + cur.own_lo, mode, b->d_uw + cur.own_lo, auc_pending(b), m,
+                         shard_split_out(ctx, b, is_train, cur.own_lo));
     } else {
-      hipLaunchKernelGGL(k_lookup, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
+      hipLaunchKernelGGL(k_lookup_step, dim3(grid_for_threads(n_own, ctx)), dim3(256), 0, st, t->v, b->d_feaids + cur.own_lo,
                          (const uint32_t*)nullptr, n_own, b->d_urow + cur.own_lo, cntp, b->d_col_ptr + cur.own_lo, mode, (uint32_t*)nullptr,
-                         0, b->d_uw + cur.own_lo, auc_pending(b));
+                         0, b->d_uw + cur.own_lo, auc_pending(b), shard_split_out(ctx, b, is_train, cur.own_lo));
     }
     b->auc_pending_n = 0;
     DFH_HIP(hipGetLastError());
@@ -1482,7 +1490,7 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     const RowSrc tsrc = table_src(t, b->d_urow);
     if (cur.any_remote && !uw_folded) {
       hipLaunchKernelGGL(k_uw_remote, dim3(grid_for_threads(cur.U, ctx)), dim3(256), 0, st, s->w_rows[q], stride, b->d_U, cur.own_lo,
-                         cur.own_hi, b->d_uw, b->d_col_ptr);
+                         cur.own_hi, b->d_uw, b->d_col_ptr, shard_split_out(ctx, b, is_train, 0u));
       DFH_HIP(hipGetLastError());
     }
     MixSrc mix{cur.any_remote ? s->w_rows[q] + 4 : nullptr, stride};

@@ -372,7 +372,7 @@ __device__ __forceinline__ void upd_hot_role(const UpdArgs& a, uint32_t blk, uin
       const uint32_t u = e.x;
       if (!key_in(a.rg, u)) continue;  // uniform per block
       const uint32_t beg = e.y, end = e.z;
-      if (a.nb_split && end - beg > HOT_SPLIT_MIN) continue;  // its parts are in the split list: upd_split_role
+      if ((DFH_HOT_SPLIT_BUILD & 2) && a.nb_split && end - beg > HOT_SPLIT_MIN) continue;  // its parts are in the split list: upd_split_role
       const uint32_t rw = ld_rowword(a.uw + u);
       const uint32_t r = rw & kRowMask;
       const KeySums s = upd_tile_sums<L, DB, HAS_VAL>(a, beg, end, (uint32_t)w, UPD_NW, grp, sub, sub_ok, k, kp);
@@ -717,7 +717,7 @@ __device__ __forceinline__ void update_body(const UpdArgs& a, const uint32_t blk
     if (DFH_UPD_ROLES & 1) {
       // the parts of the very hot keys first — the longest chains of the launch, taken by the hot role's own blocks (a list that is
       // empty on most data: one load per block) — then the hot keys
-      if (a.nb_split) upd_split_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
+      if ((DFH_HOT_SPLIT_BUILD & 2) && a.nb_split) upd_split_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
       upd_hot_role<L, EXACT, DFH_UPD_DEPTH, HAS_VAL, MIXED>(a, bid, a.nb_hot, pen, smem);
     }
   } else if ((bid -= a.nb_hot) < a.nb_mid) {

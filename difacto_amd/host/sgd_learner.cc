@@ -430,6 +430,7 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
     // one device allocation for all of them (dfh_batch_create_many): twelve objects used to be 12 x 61 hipMallocs, ~35 ms of
     // a job's start-up
     DFH_CALL(dfh_batch_create_many(ctx, nrot, batch_rows_, std::max<size_t>(batch_nnz_, 1), batch_));
+    batch_arena_ = true;
     for (int q = 0; q < nrot; ++q) DFH_CALL(dfh_batch_set_option(batch_[q], "compute_auc", 1));  // sgd_learner.cc:153-155
   };
   const bool split_prep = getenv("DIFACTO_SPLIT_PREP") != nullptr;
@@ -590,12 +591,15 @@ void SGDLearner::IterateDataSharded(const sgd::Job& job, sgd::Progress* progress
   };
   constexpr int kSlots = 4;
   static_assert(kSlots <= kFusedBatches, "the sharded loop's objects are the first of the fused loop's");
-  for (int q = kSlots; q < kFusedBatches; ++q) {  // the fused loop's further objects: this loop rotates four
+  // objects a fused job left behind share ONE allocation, which lives as long as any of them: all go (this loop's four
+  // would otherwise pin twelve objects' worth of HBM), this loop creates its own
+  for (int q = batch_arena_ ? 0 : kSlots; q < kFusedBatches; ++q) {  // the fused loop's further objects: this loop rotates four
     if (!batch_[q]) continue;
     drain(batch_[q]);
     dfh_batch_destroy(batch_[q]);
     batch_[q] = nullptr;
   }
+  batch_arena_ = false;
   size_t cap_rows[kSlots] = {0}, cap_nnz[kSlots] = {0};
   for (int q = 0; q < kSlots; ++q) {  // objects left by an earlier job keep their size
     if (batch_[q]) {

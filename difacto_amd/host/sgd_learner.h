@@ -82,6 +82,7 @@ class SGDLearner : public Learner {
   static constexpr int kFusedBatches = 12;
   dfh_batch* batch_[kFusedBatches] = {};
   size_t batch_rows_ = 0, batch_nnz_ = 0;
+  bool batch_arena_ = false;   // batch_[] were carved from ONE device allocation (dfh_batch_create_many): freed when the last one goes
   FILE* pred_file_ = nullptr;       // open while a prediction job runs
   std::vector<float> pred_buf_;
 };
