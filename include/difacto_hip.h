@@ -91,7 +91,16 @@ int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
  *   "upd_kernel", "upd_*_blocks", "upd_interleave", "event_flags": see csrc/dfh_api.hip (measurement switches)
  *   "grow_initial_rows" 16 .. 2^28      first allocation of a growing table (dfh_table_create, capacity_rows = 0; default 2^20)
  *   "auc_in_update"     0 | 1           BinClassMetric::AUC of a training step (batch option "compute_auc") as the first
- *                                       blocks of the update launch (default 1) or as a launch of its own */
+ *                                       blocks of the update launch (default 1) or as a launch of its own
+ *   "single_queue"      0 | 1           1: no preparation stream — dfh_localize only notes the Localizer's four stages, which then
+ *                                       ride as extra blocks of the launches later dfh_sgd_step calls make (the two minibatches the
+ *                                       reference keeps in flight, src/sgd/sgd_learner.cc:196-224, on ONE hardware queue; prepare
+ *                                       two ahead).  Same results bit for bit; pays for small minibatches only (default 0)
+ *   "rider_slot_count / _scatter / _sort / _emit"  0 lookup | 1 forward | 2 update (+ 4: as a launch of its own before it):
+ *                                       which launch of a step carries the stage;  "rider_period_lookup / _forward / _update"
+ *                                       1 .. 4096 and "rider_start_*" 0 .. 100: where the rider blocks sit in the carrier's grid
+ *   "upd_split"         0 | 1           keys with more than 3 072 occurrences in a minibatch go through the update kernel in
+ *                                       parts of 1 024, a block per part (default 1; 0 = one block walks the whole segment) */
 int dfh_ctx_set_option(dfh_ctx* ctx, const char* name, int value);
 
 /* optional per-kernel timing with HIP events recorded on the context's stream
