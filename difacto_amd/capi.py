@@ -27,7 +27,7 @@ SYMBOLS = [
     "dfh_table_warm_start", "dfh_ctx_set_pipeline", "dfh_batch_lookup", "dfh_localize_lookup", "dfh_rowbuf_create", "dfh_rowbuf_destroy", "dfh_rowbuf_load_host", "dfh_batch_gather_rows", "dfh_batch_set_option", "dfh_batch_key_ranges", "dfh_batch_attach_device",
     "dfh_batch_key_ranges_device", "dfh_shard_resolve", "dfh_shard_pull_resolved", "dfh_shard_push_count_resolved",
     "dfh_shard_push_grad_resolved", "dfh_table_check", "dfh_ctx_set_timing_mask", "dfh_table_save", "dfh_table_load", "dfh_shard_resolve_multi", "dfh_shard_push_count_multi",
-    "dfh_shard_push_grad_multi", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
+    "dfh_shard_push_grad_multi", "dfh_shard_count_pull_multi", "dfh_shard_push_grad_listed", "dfh_shard_release", "dfh_ctx_set_option", "dfh_table_set_has_aux", "dfh_table_has_aux",
     "dfh_comm_unique_id", "dfh_comm_create_rccl", "dfh_comm_create_callback", "dfh_comm_destroy", "dfh_comm_rank", "dfh_comm_world",
     "dfh_comm_allreduce_sum", "dfh_shard_create", "dfh_shard_destroy", "dfh_shard_owned_range", "dfh_shard_step", "dfh_shard_prefetch_counts",
     "dfh_shard_pull_host", "dfh_shard_push_host", "dfh_comm_allgather", "dfh_shard_balanced_splits", "dfh_shard_set_exchange", "dfh_shard_set_timing", "dfh_shard_get_timing",
@@ -163,6 +163,8 @@ def lib():
     L.dfh_shard_resolve_multi.argtypes = [vp, vp, vp, i32, i32, vp]
     L.dfh_shard_push_count_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dfh_shard_push_grad_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.dfh_shard_count_pull_multi.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    L.dfh_shard_push_grad_listed.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dfh_shard_release.argtypes = [vp, vp, sz, i32]
     L.dfh_shard_multi_words.restype = sz
     L.dfh_shard_multi_words.argtypes = [sz, i32]
@@ -458,6 +460,16 @@ class Table:
     def shard_push_grad_multi(self, d_rowid, d_keys, seg, d_grads, mask_slot=0):
         a, n = self._seg(seg)
         _ck(lib().dfh_shard_push_grad_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, mask_slot, _dp(d_grads)))
+
+    def shard_count_pull_multi(self, d_rowid, d_keys, seg, d_cnt, d_rows, mask_slot=0):
+        """Push(kFeaCount) of all sources (d_cnt or None) + Pull per distinct key; leaves the key lists of push_grad_listed"""
+        a, n = self._seg(seg)
+        _ck(lib().dfh_shard_count_pull_multi(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, mask_slot,
+                                             _dp(d_cnt) if d_cnt is not None else None, _dp(d_rows)))
+
+    def shard_push_grad_listed(self, d_rowid, d_keys, seg, d_grads, mask_slot=0):
+        a, n = self._seg(seg)
+        _ck(lib().dfh_shard_push_grad_listed(self.h, _dp(d_rowid), _dp(d_keys), _p(a), n, mask_slot, _dp(d_grads)))
 
     def shard_release(self, d_rowid, n, mask_slot=0):
         _ck(lib().dfh_shard_release(self.h, _dp(d_rowid), n, mask_slot))

@@ -50,6 +50,7 @@ struct dfh_ctx {
   // found: 58.7 us; more list blocks cost more in block dispatch than they save in chain length)
   int upd_hot_blocks = 512, upd_mid_blocks = 512, upd_few_blocks = 1024, upd_single_blocks = 4096;
   int upd_interleave = 0;      // n > 1: every n-th block of the launch is a list-role block; 0 / 1: list roles first
+  int owner_per_key = 0;       // sharded store, owner side per distinct key in two launches (1) or per received entry in three (0); env DFH_OWNER_PER_KEY=1 sets the default
   int upd_split = 1;           // keys with more than HOT_SPLIT occurrences part by part, a block per part (0: the hot role walks them whole; A/B)
   int auc_in_update = 1;       // a training step's AUC as the first blocks of k_update_fused (1) or a launch of its own (0)
   int shard_mixed_update = 1;  // sharded step: one k_update_fused<MIXED> launch for own + others' keys (1) or round 4's two launches (0)
@@ -937,6 +938,7 @@ int dfh_ctx_create(int device, void* stream, dfh_ctx** out) {
   dfh_ctx* c = new (std::nothrow) dfh_ctx();
   DFH_ARG(c != nullptr, "out of host memory");
   c->device = device;
+  if (const char* e = getenv("DFH_OWNER_PER_KEY")) c->owner_per_key = atoi(e) != 0;  // (measurement: bench.py --emulate-world)
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -1048,6 +1050,9 @@ int dfh_ctx_set_option(dfh_ctx* c, const char* name, int value) {
   } else if (n == "shard_mixed_update") {
     DFH_ARG(value == 0 || value == 1, "shard_mixed_update must be 0 or 1");
     c->shard_mixed_update = value;
+  } else if (n == "owner_per_key") {
+    DFH_ARG(value == 0 || value == 1, "owner_per_key must be 0 (count push, Pull, gradient push per received entry) or 1 (per distinct key)");
+    c->owner_per_key = value;
   } else if (n == "upd_split") {
     DFH_ARG(value == 0 || value == 1, "upd_split must be 0 (one block per hot key, whatever its length) or 1 (a block per part of 1 024 occurrences)");
     c->upd_split = value;
@@ -1465,6 +1470,65 @@ int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint6
     const size_t blocks = std::min<size_t>((n * L + 255) / 256, (size_t)t->ctx->num_cu * 16);   // (8 / 32 per CU: 61.0 / 58.6 against 57.4 us)
     hipLaunchKernelGGL((k_push_grad_multi<L>), dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g,
                        d_grads, stride);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+// Push(kFeaCount) of all sources (d_cnt, or NULL: none this step) and Pull, per distinct key, in one launch; leaves the key
+// lists dfh_shard_push_grad_listed runs over
+int dfh_shard_count_pull_multi(dfh_table* t, uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc, int mask_slot,
+                               const float* d_cnt, float* d_rows) {
+  DFH_ARG(t, "NULL table");
+  if (d_cnt && !hash_init_only(t)) {
+    set_error("multi-source store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  SegOff g;
+  int rc = make_segoff(seg, nsrc, mask_slot, &g);
+  if (rc) return rc;
+  const size_t n = g.off[nsrc];
+  DFH_ARG(n == 0 || (d_rowid && d_keys && d_rows), "dfh_shard_count_pull_multi: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PULL);
+  const size_t stride = dfh_row_stride(t->v.k);
+  const size_t nchunk = (n + MULTI_CH - 1) / MULTI_CH;
+  rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    const dim3 grid((unsigned)std::min<size_t>(nchunk, (size_t)t->ctx->num_cu * 16));
+    if (d_cnt)
+      hipLaunchKernelGGL((k_count_pull_multi<L, true>), grid, dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g, d_cnt, d_rows, stride);
+    else
+      hipLaunchKernelGGL((k_count_pull_multi<L, false>), grid, dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g, d_cnt, d_rows, stride);
+  });
+  if (rc) return rc;
+  DFH_HIP(hipGetLastError());
+  return DFH_OK;
+}
+
+// Push(kGradient) of all sources over the key lists dfh_shard_count_pull_multi left in d_rowid (same seg, same slot)
+int dfh_shard_push_grad_listed(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                               int mask_slot, const float* d_grads) {
+  DFH_ARG(t, "NULL table");
+  if (int rca = require_aux(t, "dfh_shard_push_grad_listed")) return rca;
+  if (!hash_init_only(t)) {
+    set_error("multi-source store calls need V_init = hash (order independent)");
+    return DFH_ERR_STATE;
+  }
+  SegOff g;
+  int rc = make_segoff(seg, nsrc, mask_slot, &g);
+  if (rc) return rc;
+  const size_t n = g.off[nsrc];
+  DFH_ARG(n == 0 || (d_rowid && d_keys && d_grads), "dfh_shard_push_grad_listed: NULL argument");
+  if (n == 0) return DFH_OK;
+  TimeScope ts(t->ctx, DFH_K_PUSH);
+  const size_t stride = dfh_row_stride(t->v.k);
+  const size_t nchunk = (n + MULTI_CH - 1) / MULTI_CH;
+  rc = dispatch_L(std::max(t->v.kp, 4), [&](auto Lc) {
+    constexpr int L = decltype(Lc)::value;
+    const dim3 grid((unsigned)std::min<size_t>(nchunk, (size_t)t->ctx->num_cu * 16));
+    hipLaunchKernelGGL((k_push_grad_chunks<L>), grid, dim3(256), 0, t->ctx->stream, t->v, d_rowid, d_keys, g, d_grads, stride);
   });
   if (rc) return rc;
   DFH_HIP(hipGetLastError());

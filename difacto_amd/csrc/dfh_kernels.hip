@@ -1694,7 +1694,23 @@ constexpr uint32_t ROW_WORKER = 0x80000000u;
 constexpr int MULTI_FAST = 8;                  // entries per key ordered in registers (one node: 7 peers)
 __host__ __device__ __forceinline__ uint32_t multi_xs(int nsrc) { return (uint32_t)((nsrc - 1 + 3) / 4 * 4 > 0 ? (nsrc - 1 + 3) / 4 * 4 : 4); }
 __host__ __device__ __forceinline__ size_t multi_extra_base(size_t n) { return (n + 3) & ~(size_t)3; }
-__host__ __device__ __forceinline__ size_t multi_words(size_t n, int nsrc) { return multi_extra_base(n) + n * multi_xs(nsrc); }
+// Behind the row words and the extras, the key lists k_count_pull_multi leaves for k_push_grad_chunks: the entries are cut
+// into chunks of MULTI_CH; a chunk's keys of ONE source (its workers without extras) stand in slist[c * MULTI_CH ...) as
+// {entry, row}, its keys of several sources in mrec[(c * MULTI_CH + j) * (XS + 4) ...) as {entry | m << 27, row, -, -,
+// the other entries in ascending (= source) order}, chdr[c] = {keys of one source, keys of several}.
+#ifndef DFH_MULTI_CH
+#define DFH_MULTI_CH 32   // (16 / 32 / 64 / 128: push 48.7 / 45.1 / 53.2 / 66.6 us, count + pull 36 / 36 / 40 / 45 us at N = 8 size)
+#endif
+constexpr uint32_t MULTI_CH = DFH_MULTI_CH;
+__host__ __device__ __forceinline__ size_t multi_slist_base(size_t n, int nsrc) { return multi_extra_base(n) + n * multi_xs(nsrc); }
+__host__ __device__ __forceinline__ size_t multi_ch_entries(size_t n) { return (n + MULTI_CH - 1) / MULTI_CH * MULTI_CH; }  // whole chunks: the readers request a chunk's first entries with its counts
+__host__ __device__ __forceinline__ size_t multi_mrec_base(size_t n, int nsrc) { return multi_slist_base(n, nsrc) + 2 * multi_ch_entries(n); }
+__host__ __device__ __forceinline__ size_t multi_chdr_base(size_t n, int nsrc) {
+  return multi_mrec_base(n, nsrc) + multi_ch_entries(n) * (multi_xs(nsrc) + 4);
+}
+__host__ __device__ __forceinline__ size_t multi_words(size_t n, int nsrc) {
+  return multi_chdr_base(n, nsrc) + 2 * ((n + MULTI_CH - 1) / MULTI_CH + 1);
+}
 
 __global__ void k_resolve_multi(TableView t, const uint64_t* __restrict__ keys, SegOff g, uint32_t* __restrict__ rowid) {
   const uint32_t n = g.off[g.nsrc];
@@ -1902,6 +1918,298 @@ __global__ void __launch_bounds__(256) k_push_grad_multi(TableView t, const uint
         st4_nt(va + d, v);
         st4_nt(va + t.kp + d, acc);
       } else {
+        st4(va + d, v);
+        st4(va + t.kp + d, acc);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Owner side per DISTINCT key (round 6).  k_count_pull_multi is Push(kFeaCount) of all sources and Pull in ONE launch:
+// a key's worker adds the sources' counts, takes the InitV decision once (sgd_updater.cc:62-73), reads the row ONCE and
+// writes [w, has_V, 0, 0 | V] to the output row of every entry of the key (its own and its extras') — the duplicate keys of
+// k_pull_resolved re-read their row (81.7 MB counted for 58.8 MB at N = 8 size), and the count push was a launch of its own.
+// On the way it leaves the step's keys as lists per chunk of MULTI_CH entries (layout above), so that k_push_grad_chunks
+// runs over keys, not entries: in k_push_grad_multi 36 % of the lane groups idle on entries that are not workers and a
+// wave takes the several-sources path (a third round trip) when ONE of its four keys has extras — 59 % of the waves for
+// 20 % of the keys.  Here a wave's keys are all of one kind, the keys of several sources have their other entries in
+// source order with the first read, and their gradient rows are requested with the row: two round trips for both kinds.
+// ---------------------------------------------------------------------------
+template <int L, bool HAS_CNT>
+__global__ void __launch_bounds__(256) k_count_pull_multi(TableView t, uint32_t* __restrict__ rowid, const uint64_t* __restrict__ keys,
+                                                          SegOff g, const float* __restrict__ cnt, float* __restrict__ rows,
+                                                          size_t stride) {
+  constexpr uint32_t G = 256 / L;
+  __shared__ uint32_t sh_n[2];
+  const uint32_t sub = threadIdx.x % L, grp = threadIdx.x / L;
+  const uint32_t n = g.off[g.nsrc];
+  const uint32_t XS = multi_xs(g.nsrc), RS = XS + 4;
+  const uint32_t* __restrict__ extra = rowid + multi_extra_base(n);
+  uint2* __restrict__ slist = reinterpret_cast<uint2*>(rowid + multi_slist_base(n, g.nsrc));
+  uint32_t* __restrict__ mrec = rowid + multi_mrec_base(n, g.nsrc);
+  uint2* __restrict__ chdr = reinterpret_cast<uint2*>(rowid + multi_chdr_base(n, g.nsrc));
+  const uint32_t nchunk = (n + MULTI_CH - 1) / MULTI_CH;
+  const int d = (int)sub * 4;
+  const bool d_ok = d < t.kp;
+  for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    if (threadIdx.x == 0) sh_n[0] = sh_n[1] = 0;
+    __syncthreads();
+    for (uint32_t i = grp; i < MULTI_CH; i += G) {
+      const uint32_t e = c * MULTI_CH + i;
+      if (e >= n) continue;
+      const uint32_t rw = rowid[e];
+      if (!(rw & ROW_WORKER)) continue;  // another entry of this key works for it
+      const uint32_t r = rw & ROW_ID_MASK;
+      RowHdr* hp = t.hdr + r;
+      const float* va = t.va + (size_t)r * (2 * t.kp);
+      // one round trip: the header (both halves), this lane's V slice, the extras
+      const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+      const float fea_cnt = hp->fea_cnt;
+      const uint32_t word = hp->pad[g.slot];
+      float4 v = ld4(d_ok ? va + d : reinterpret_cast<const float*>(hp));
+      const uint32_t* xp = extra + (size_t)e * XS;
+      const uint4 x0 = *reinterpret_cast<const uint4*>(xp);
+      const uint4 x1 = *reinterpret_cast<const uint4*>(xp + (XS >= 8 ? 4 : 0));
+      const uint32_t m = min(word & 31u, XS);  // entries of this key besides the worker's own
+      bool hv = __float_as_uint(h0.y) != 0u;
+      // the other entries in ascending order (sources are concatenated in ascending order): a network on 8 registers; more
+      // than 8 (a job beyond one node) are ordered by selection out of memory, below
+      uint32_t ent[MULTI_FAST] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      const bool fast = m <= (uint32_t)MULTI_FAST;
+      if (m > 0 && fast) {
+#pragma unroll
+        for (int j = 0; j < MULTI_FAST; ++j)
+          if ((uint32_t)j >= m || (j >= 4 && XS < 8)) ent[j] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int pass = 0; pass < MULTI_FAST; ++pass) {
+#pragma unroll
+          for (int j = pass & 1; j + 1 < MULTI_FAST; j += 2) {
+            const uint32_t lo = min(ent[j], ent[j + 1]), hi = max(ent[j], ent[j + 1]);
+            ent[j] = lo;
+            ent[j + 1] = hi;
+          }
+        }
+      }
+      if (HAS_CNT) {
+        float fc = fea_cnt + cnt[e];  // small integers: the sum is exact in any order
+        if (fast) {
+#pragma unroll
+          for (int j = 0; j < MULTI_FAST; ++j)
+            if ((uint32_t)j < m) fc += cnt[ent[j]];
+        } else {
+          for (uint32_t j = 0; j < m; ++j) fc += cnt[xp[j]];
+        }
+        if (t.k > 0 && !hv && h0.x != 0 && fc > (float)t.p.V_threshold) {
+          // every lane of the group writes its own 16 B of V and of the accumulators, and answers with what it wrote
+          if (d_ok) {
+            init_v_hash_slice(t, r, keys[e], d);
+            v.x = d + 0 < t.k ? hash_init_value(keys[e], d + 0, t.p.seed, t.p.V_init_scale) : 0.0f;
+            v.y = d + 1 < t.k ? hash_init_value(keys[e], d + 1, t.p.seed, t.p.V_init_scale) : 0.0f;
+            v.z = d + 2 < t.k ? hash_init_value(keys[e], d + 2, t.p.seed, t.p.V_init_scale) : 0.0f;
+            v.w = d + 3 < t.k ? hash_init_value(keys[e], d + 3, t.p.seed, t.p.V_init_scale) : 0.0f;
+          }
+          hv = true;
+          if (sub == 0) hp->has_V = 1;
+        }
+        if (sub == 0) hp->fea_cnt = fc;
+      }
+      if (!hv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 head = make_float4(h0.x, hv ? 1.0f : 0.0f, 0.f, 0.f);
+      auto put = [&](uint32_t idx) {
+        float* out = rows + (size_t)idx * stride;
+        if (sub == 0) st4(out, head);
+        if (d_ok) st4(out + 4 + d, v);
+      };
+      put(e);
+      if (fast) {
+#pragma unroll
+        for (int j = 0; j < MULTI_FAST; ++j)
+          if ((uint32_t)j < m) put(ent[j]);
+      } else {
+        for (uint32_t j = 0; j < m; ++j) put(xp[j]);
+      }
+      if (sub == 0) {
+        if (m == 0) {
+          slist[(size_t)c * MULTI_CH + atomicAdd(&sh_n[0], 1u)] = make_uint2(e, r);
+        } else {
+          uint32_t* rec = mrec + ((size_t)c * MULTI_CH + atomicAdd(&sh_n[1], 1u)) * RS;
+          *reinterpret_cast<uint4*>(rec) = make_uint4(e | (m << 27), r, 0u, 0u);
+          if (fast) {
+            *reinterpret_cast<uint4*>(rec + 4) = make_uint4(ent[0], ent[1], ent[2], ent[3]);
+            if (XS >= 8) *reinterpret_cast<uint4*>(rec + 8) = make_uint4(ent[4], ent[5], ent[6], ent[7]);
+          } else {
+            uint32_t cur = 0;
+            for (uint32_t done = 0; done < m; ++done) {  // selection: the next entry in ascending order
+              uint32_t best = 0xFFFFFFFFu;
+              for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t x = xp[j];
+                if ((done == 0 || x > cur) && x < best) best = x;
+              }
+              rec[4 + done] = best;
+              cur = best;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) chdr[c] = make_uint2(sh_n[0], sh_n[1]);
+    __syncthreads();
+  }
+}
+
+// Push(kGradient) of all sources over the key lists of k_count_pull_multi: L lanes per KEY, a block per chunk; FTRL on w
+// with lazy InitV, AdaGrad on V iff the rows were pulled with V, the sources' gradient rows applied in source order on
+// registers, the row stored once, its step word cleared (what k_push_grad_multi does per entry).
+template <int L>
+__global__ void __launch_bounds__(256) k_push_grad_chunks(TableView t, const uint32_t* __restrict__ rowid,
+                                                          const uint64_t* __restrict__ keys, SegOff g,
+                                                          const float* __restrict__ grads, size_t stride) {
+  constexpr uint32_t G = 256 / L;
+  const uint32_t sub = threadIdx.x % L, grp = threadIdx.x / L;
+  const uint32_t n = g.off[g.nsrc];
+  const uint32_t XS = multi_xs(g.nsrc), RS = XS + 4;
+  const uint2* __restrict__ slist = reinterpret_cast<const uint2*>(rowid + multi_slist_base(n, g.nsrc));
+  const uint32_t* __restrict__ mrec = rowid + multi_mrec_base(n, g.nsrc);
+  const uint2* __restrict__ chdr = reinterpret_cast<const uint2*>(rowid + multi_chdr_base(n, g.nsrc));
+  const uint32_t nchunk = (n + MULTI_CH - 1) / MULTI_CH;
+  const int d = (int)sub * 4;
+  const bool d_ok = d < t.kp;  // this lane's V slice (4 * L >= kp by dispatch: one float4 per lane covers the row)
+  const int goff = d_ok ? 4 + d : 0;
+  for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    const uint2 ch = chdr[c];
+    const size_t base = (size_t)c * MULTI_CH;
+    uint2 en = slist[base + min(grp, MULTI_CH - 1)];  // requested with the chunk's counts
+    uint4 r0 = *reinterpret_cast<const uint4*>(mrec + (base + min(grp, MULTI_CH - 1)) * RS);
+    // ---- keys of one source: row word -> {header, row, gradient} -> store
+    for (uint32_t i = grp; i < ch.x; i += G) {
+      if (i != grp) en = slist[base + i];
+      const uint32_t e = en.x, r = en.y;
+      RowHdr* hp = t.hdr + r;
+      float* va = t.va + (size_t)r * (2 * t.kp);
+      // lanes beyond the row (and V_dim = 0) read valid addresses they do not use: the loads stay unconditional
+      const float* vp = d_ok ? va + d : reinterpret_cast<const float*>(hp);
+      const float* ap = d_ok ? va + t.kp + d : reinterpret_cast<const float*>(hp);
+      const float4 h0 = ld4(reinterpret_cast<const float*>(hp));  // {w, has_V, sqrt_g, z}
+      const float fea_cnt = hp->fea_cnt;
+      const float* g_own = grads + (size_t)e * stride;
+      const float4 go0 = ld4(g_own);
+      const float4 gv = ld4(g_own + goff);
+      float4 v = ld4(vp), acc = ld4(ap);
+      float w = h0.x, sqrt_g = h0.z, z = h0.w;
+      uint32_t has_v = __float_as_uint(h0.y);
+      const bool had_v = go0.y != 0.0f;
+      if (had_v && !has_v) {  // CHECK(e.V != nullptr), sgd_updater.cc:92
+        if (sub == 0) atomicOr(t.err, 4u);
+        if (sub == 0) hp->pad[g.slot] = 0;
+        continue;
+      }
+      const float w_old = w;
+      w = ftrl_update_w(go0.x, w_old, sqrt_g, z, t.p);
+      // lazy InitV when w leaves zero (sgd_updater.cc:122-126); the pulled rows had no V, so no gradient touches the fresh values
+      if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
+        if (d_ok) init_v_hash_slice(t, r, keys[e], d);
+        has_v = 1;
+      }
+      if (sub == 0) {
+        st4(reinterpret_cast<float*>(hp), make_float4(w, __uint_as_float(has_v), sqrt_g, z));
+        hp->pad[g.slot] = 0;
+      }
+      if (had_v && d_ok) {
+        adagrad_update_v(gv.x, v.x, acc.x, t.p);
+        adagrad_update_v(gv.y, v.y, acc.y, t.p);
+        adagrad_update_v(gv.z, v.z, acc.z, t.p);
+        adagrad_update_v(gv.w, v.w, acc.w, t.p);
+        if (d + 0 >= t.k) { v.x = 0.f; acc.x = 0.f; }
+        if (d + 1 >= t.k) { v.y = 0.f; acc.y = 0.f; }
+        if (d + 2 >= t.k) { v.z = 0.f; acc.z = 0.f; }
+        if (d + 3 >= t.k) { v.w = 0.f; acc.w = 0.f; }
+        st4(va + d, v);
+        st4(va + t.kp + d, acc);
+      }
+    }
+    // ---- keys of several sources: record -> {header, row, the first four gradient rows} -> [the others] -> store
+    for (uint32_t i = grp; i < ch.y; i += G) {
+      const uint32_t* rec = mrec + (base + i) * RS;
+      if (i != grp) r0 = *reinterpret_cast<const uint4*>(rec);
+      const uint4 x0 = *reinterpret_cast<const uint4*>(rec + 4);
+      const uint32_t e = r0.x & 0x07FFFFFFu, m = r0.x >> 27, r = r0.y;
+      RowHdr* hp = t.hdr + r;
+      float* va = t.va + (size_t)r * (2 * t.kp);
+      const float* vp = d_ok ? va + d : reinterpret_cast<const float*>(hp);
+      const float* ap = d_ok ? va + t.kp + d : reinterpret_cast<const float*>(hp);
+      const float4 h0 = ld4(reinterpret_cast<const float*>(hp));
+      const float fea_cnt = hp->fea_cnt;
+      const float* g_own = grads + (size_t)e * stride;
+      const float4 go0 = ld4(g_own);
+      const float4 go_v = ld4(g_own + goff);
+      float4 v = ld4(vp), acc = ld4(ap);
+      float w = h0.x, sqrt_g = h0.z, z = h0.w;
+      uint32_t has_v = __float_as_uint(h0.y);
+      const bool had_v = go0.y != 0.0f;  // every source pulled the same model version: one answer
+      if (had_v && !has_v) {
+        if (sub == 0) atomicOr(t.err, 4u);
+        if (sub == 0) hp->pad[g.slot] = 0;
+        continue;
+      }
+      if (!(had_v && d_ok)) v = acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      auto apply = [&](float gw, const float4& gv) {
+        const float w_old = w;
+        w = ftrl_update_w(gw, w_old, sqrt_g, z, t.p);
+        if (w_old == 0 && w != 0 && t.k > 0 && has_v == 0 && fea_cnt > (float)t.p.V_threshold) {
+          if (d_ok) init_v_hash_slice(t, r, keys[e], d);
+          has_v = 1;
+        }
+        if (had_v && d_ok) {
+          adagrad_update_v(gv.x, v.x, acc.x, t.p);
+          adagrad_update_v(gv.y, v.y, acc.y, t.p);
+          adagrad_update_v(gv.z, v.z, acc.z, t.p);
+          adagrad_update_v(gv.w, v.w, acc.w, t.p);
+        }
+      };
+      // the first four of the other entries' gradient rows travel with the row (unconditional loads on clamped entries)
+      const uint32_t xs[4] = {x0.x, x0.y, x0.z, x0.w};
+      float gws[4];
+      float4 gvs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* gp = grads + (size_t)((uint32_t)j < m ? xs[j] : e) * stride;
+        gws[j] = ld4(gp).x;
+        gvs[j] = ld4(gp + goff);
+      }
+      bool own_done = false;  // the worker's own entry takes its place in the ascending order
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if ((uint32_t)j < m) {
+          if (!own_done && e < xs[j]) {
+            apply(go0.x, go_v);
+            own_done = true;
+          }
+          apply(gws[j], gvs[j]);
+        }
+      }
+      for (uint32_t j = 4; j < m; ++j) {  // rare: a key five or more sources carry
+        const uint32_t x = rec[4 + j];
+        const float* gp = grads + (size_t)x * stride;
+        const float gw = ld4(gp).x;
+        const float4 gv = ld4(gp + goff);
+        if (!own_done && e < x) {
+          apply(go0.x, go_v);
+          own_done = true;
+        }
+        apply(gw, gv);
+      }
+      if (!own_done) apply(go0.x, go_v);
+      if (sub == 0) {
+        st4(reinterpret_cast<float*>(hp), make_float4(w, __uint_as_float(has_v), sqrt_g, z));
+        hp->pad[g.slot] = 0;
+      }
+      if (had_v && d_ok) {
+        if (d + 0 >= t.k) { v.x = 0.f; acc.x = 0.f; }
+        if (d + 1 >= t.k) { v.y = 0.f; acc.y = 0.f; }
+        if (d + 2 >= t.k) { v.z = 0.f; acc.z = 0.f; }
+        if (d + 3 >= t.k) { v.w = 0.f; acc.w = 0.f; }
         st4(va + d, v);
         st4(va + t.kp + d, acc);
       }

@@ -253,6 +253,7 @@ struct dfh_shard {
     uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu;
     bool any_own = false, any_remote = false;
     int slot = 0;
+    bool listed = false;              // R left the key lists of the per-key owner side: P runs over them
   } fl[2];
   int cur = 0;                        // fl[cur]: the minibatch the next step trains; fl[cur ^ 1]: the one after
   // ---- per-stage timing (dfh_shard_set_timing): counts, L, K, R, RW, F, G, P
@@ -948,6 +949,12 @@ int flight_bufs(dfh_shard* s, const dfh_shard::Flight& f, size_t stride) {
   return DFH_OK;
 }
 
+// ctx option "owner_per_key" (DFH_OWNER_PER_KEY=1 sets its default; measurement): the owner side per DISTINCT key in two launches (dfh_shard_count_pull_multi,
+// dfh_shard_push_grad_listed) instead of per received entry in three.  Built in round 6 on VERDICT r5 #2, bit-identical
+// (tests/test_gpu_parity.py "listed"), and NOT faster: 101 against 98 us for the owner side of an N = 8 step
+// (profiles/r06o_owner_side_per_key.txt) — the default stays per entry.
+bool owner_per_entry(const dfh_table* t) { return !t->ctx->owner_per_key; }
+
 void flight_bytes(const dfh_shard::Flight& f, int W, size_t unit, std::vector<size_t>& sb, std::vector<size_t>& rb, std::vector<size_t>& so) {
   sb.resize(W);
   rb.resize(W);
@@ -1004,11 +1011,16 @@ int flight_R_RW(dfh_shard* s, dfh_shard::Flight& f, int push_cnt) {
     if (f.nrecv) {
       rc = dfh_shard_resolve_multi(t, s->r_keys[q], f.seg.data(), W, q, s->r_rowid[q]);
       if (rc) return rc;
-      if (push_cnt) {
-        rc = dfh_shard_push_count_multi(t, s->r_rowid[q], s->r_keys[q], f.seg.data(), W, q, s->r_cnt[q]);
-        if (rc) return rc;
+      f.listed = !owner_per_entry(t);
+      if (!f.listed) {
+        if (push_cnt) {
+          rc = dfh_shard_push_count_multi(t, s->r_rowid[q], s->r_keys[q], f.seg.data(), W, q, s->r_cnt[q]);
+          if (rc) return rc;
+        }
+        rc = dfh_shard_pull_resolved(t, s->r_rowid[q], f.nrecv, s->r_rows[q]);
+      } else {
+        rc = dfh_shard_count_pull_multi(t, s->r_rowid[q], s->r_keys[q], f.seg.data(), W, q, push_cnt ? s->r_cnt[q] : nullptr, s->r_rows[q]);
       }
-      rc = dfh_shard_pull_resolved(t, s->r_rowid[q], f.nrecv, s->r_rows[q]);
       if (rc) return rc;
     }
     DFH_HIP(hipEventRecord(s->ev_r[q], st));
@@ -1266,15 +1278,20 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     }
   }
   // ---- R: owners resolve once, count-push, pull (every source reads the same model version)
+  const bool per_entry = owner_per_entry(t);
   if (nrecv) {
     StageScope ts(s, DFH_SHARD_STAGE_R, st);
     rc = dfh_shard_resolve_multi(t, s->r_keys[0], seg.data(), W, 0, s->r_rowid[0]);
     if (rc) return rc;
-    if (push_cnt) {
-      rc = dfh_shard_push_count_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_cnt[0]);
-      if (rc) return rc;
+    if (per_entry) {
+      if (push_cnt) {
+        rc = dfh_shard_push_count_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_cnt[0]);
+        if (rc) return rc;
+      }
+      rc = dfh_shard_pull_resolved(t, s->r_rowid[0], nrecv, s->r_rows[0]);
+    } else {
+      rc = dfh_shard_count_pull_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, push_cnt ? s->r_cnt[0] : nullptr, s->r_rows[0]);
     }
-    rc = dfh_shard_pull_resolved(t, s->r_rowid[0], nrecv, s->r_rows[0]);
     if (rc) return rc;
   }
   // ---- RW: rows back to the workers, each owner's slice to its place among the minibatch's keys
@@ -1370,7 +1387,8 @@ int dfh_shard_step(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, int* 
     }
     if (nrecv) {
       StageScope ts(s, DFH_SHARD_STAGE_P, st);
-      rc = dfh_shard_push_grad_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_rows[0]);
+      rc = per_entry ? dfh_shard_push_grad_multi(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_rows[0])
+                             : dfh_shard_push_grad_listed(t, s->r_rowid[0], s->r_keys[0], seg.data(), W, 0, s->r_rows[0]);
       if (rc) return rc;
     }
   } else if (nrecv) {
@@ -1577,7 +1595,8 @@ int shard_step_overlap(dfh_shard* s, dfh_batch* b, int is_train, int push_cnt, i
     StageScope ts(s, DFH_SHARD_STAGE_P, st);
     DFH_HIP(hipStreamWaitEvent(st, s->ev_g, 0));
     if (cur.nrecv) {
-      rc = dfh_shard_push_grad_multi(t, s->r_rowid[q], s->r_keys[q], cur.seg.data(), W, q, s->r_rows[q]);
+      rc = !cur.listed ? dfh_shard_push_grad_multi(t, s->r_rowid[q], s->r_keys[q], cur.seg.data(), W, q, s->r_rows[q])
+                             : dfh_shard_push_grad_listed(t, s->r_rowid[q], s->r_keys[q], cur.seg.data(), W, q, s->r_rows[q]);
       if (rc) return rc;
     }
   } else if (cur.nrecv) {

@@ -100,7 +100,10 @@ int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
  *                                       which launch of a step carries the stage;  "rider_period_lookup / _forward / _update"
  *                                       1 .. 4096 and "rider_start_*" 0 .. 100: where the rider blocks sit in the carrier's grid
  *   "upd_split"         0 | 1           keys with more than 3 072 occurrences in a minibatch go through the update kernel in
- *                                       parts of 1 024, a block per part (default 1; 0 = one block walks the whole segment) */
+ *                                       parts of 1 024, a block per part (default 1; 0 = one block walks the whole segment)
+ *   "owner_per_key"     0 | 1           dfh_shard_step's owner side per distinct key (dfh_shard_count_pull_multi +
+ *                                       dfh_shard_push_grad_listed) instead of per received entry; same results, not faster
+ *                                       (default 0; measurement switch) */
 int dfh_ctx_set_option(dfh_ctx* ctx, const char* name, int value);
 
 /* optional per-kernel timing with HIP events recorded on the context's stream
@@ -348,6 +351,15 @@ int dfh_shard_push_count_multi(dfh_table* t, const uint32_t* d_rowid, const uint
                                int mask_slot, const float* d_cnt);
 int dfh_shard_push_grad_multi(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
                               int mask_slot, const float* d_grads);
+/* The owner side per DISTINCT key (what dfh_shard_step uses): dfh_shard_count_pull_multi is Push(kFeaCount) of all sources
+ * (d_cnt; NULL = no counts this step) and Pull in one launch — a key's row is read once and written to the output row of
+ * every entry that carries the key (d_rows: n rows of dfh_row_stride floats, entry order) — and leaves, behind the extras in
+ * d_rowid, the step's keys as lists; dfh_shard_push_grad_listed is Push(kGradient) of all sources over those lists (same
+ * seg / mask_slot; d_grads in entry order; ends the step like push_grad_multi).  Results equal the per-entry calls above. */
+int dfh_shard_count_pull_multi(dfh_table* t, uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc, int mask_slot,
+                               const float* d_cnt, float* d_rows);
+int dfh_shard_push_grad_listed(dfh_table* t, const uint32_t* d_rowid, const uint64_t* d_keys, const size_t* seg, int nsrc,
+                               int mask_slot, const float* d_grads);
 int dfh_shard_release(dfh_table* t, const uint32_t* d_rowid, size_t n, int mask_slot);
 /* fetch and report the table's sticky device-side error word (capacity exceeded, gradient
  * with V for a row without V); synchronises */

@@ -849,14 +849,17 @@ def test_sharded_blocks_match_fused(capi, ctx, oracle, V_dim):
 
 
 @pytest.mark.parametrize("V_dim", [0, 6, 64])
-@pytest.mark.parametrize("form,G", [("resolved", 4), ("multi", 4), ("multi", 8), ("multi", 11)])
+@pytest.mark.parametrize("form,G", [("resolved", 4), ("multi", 4), ("multi", 8), ("multi", 11), ("listed", 2), ("listed", 4),
+                                    ("listed", 8), ("listed", 11)])
 def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
     """keys arriving from several source ranks in one step (the same key under more than one
     source).  Two forms of the owner side must equal the per-source dfh_shard_* calls
     (parity-tested above) applied in source order:
       resolved  resolve once + pull all + per-source pushes on row ids
       multi     one launch per operation for all sources (leader entry per key applies every
-                source's value in order) - what difacto_amd.sharded runs"""
+                source's value in order)
+      listed    per DISTINCT key: count push + Pull in one launch (a key's row read once, written to every entry's
+                output row), gradient push over the key lists that launch leaves - what dfh_shard_step runs"""
     import torch
     rng = np.random.default_rng(77 + V_dim)
     kw = dict(l1=0.02, l2=0.01, lr=0.3, V_lr=0.05, V_l2=0.02, V_threshold=2, V_init_scale=0.2, seed=9)
@@ -870,6 +873,8 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
     for step in range(7):
         srcs = [np.sort(rng.choice(universe, size=int(rng.integers(0 if step == 3 else 200, 900)), replace=False))
                 for _ in range(G)]
+        if step in (1, 4):  # a few keys EVERY source carries: the longest lists of extras (beyond the register path at G = 11)
+            srcs = [np.union1d(x, universe[step * 7:step * 7 + 5]) for x in srcs]
         if step == 3:
             srcs[1] = srcs[1][:0]  # a source with nothing for this owner
         if step == 5:
@@ -883,9 +888,9 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         rows_a = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         rows_b = torch.zeros((n, stride), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()  # the fixture's context runs on its own (non-blocking) stream
-        if form == "multi":
+        if form in ("multi", "listed"):
             ta.shard_resolve_multi(keys, seg, rowid)
-            if step < 3:
+            if step < 3 and form == "multi":
                 ta.shard_push_count_multi(rowid, keys, seg, cnt)
         else:
             ta.shard_resolve(keys, n, rowid)
@@ -895,7 +900,10 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
                 if form == "resolved":
                     ta.shard_push_count_resolved(rowid[a:b], keys[a:b], b - a, cnt[a:b])
                 tb.shard_push_count(keys[a:b], b - a, cnt[a:b])
-        ta.shard_pull_resolved(rowid, n, rows_a)
+        if form == "listed":
+            ta.shard_count_pull_multi(rowid, keys, seg, cnt if step < 3 else None, rows_a)
+        else:
+            ta.shard_pull_resolved(rowid, n, rows_a)
         for s in range(G):
             a, b = int(seg[s]), int(seg[s + 1])
             if b > a:
@@ -904,7 +912,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         torch.cuda.synchronize()
         assert torch.equal(rows_a, rows_b)
         if not train:
-            if form == "multi":
+            if form in ("multi", "listed"):
                 ta.shard_release(rowid, n)
             continue
         # gradient rows: [gw, has_V as pulled, 0, 0 | gV]
@@ -916,6 +924,8 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         torch.cuda.synchronize()
         if form == "multi":
             ta.shard_push_grad_multi(rowid, keys, seg, grads)
+        elif form == "listed":
+            ta.shard_push_grad_listed(rowid, keys, seg, grads)
         for s in range(G):
             a, b = int(seg[s]), int(seg[s + 1])
             if b > a:
@@ -930,7 +940,7 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
     assert (la > 1).any() or V_dim == 0
     assert_close(va, vb, rtol=1e-6, what="weights")
     assert ta.size() == tb.size()
-    if form == "multi":  # every source mask was cleared: a fresh multi step must see clean rows
+    if form in ("multi", "listed"):  # every source mask was cleared: a fresh multi step must see clean rows
         keys = torch.from_numpy(universe[:100].view(np.int64).copy()).to(dev)
         rowid = torch.empty(capi.multi_words(100, 2), dtype=torch.int32, device=dev)
         rows = torch.zeros((100, stride), dtype=torch.float32, device=dev)
@@ -938,13 +948,17 @@ def test_owner_side_forms_match_per_source_calls(capi, ctx, V_dim, form, G):
         zeros[:, 1] = 0
         torch.cuda.synchronize()
         ta.shard_resolve_multi(keys, np.array([0, 0, 100]), rowid)   # source 0 empty, source 1 carries all
-        ta.shard_pull_resolved(rowid, 100, rows)
+        if form == "listed":
+            ta.shard_count_pull_multi(rowid, keys, np.array([0, 0, 100]), None, rows)
+        else:
+            ta.shard_pull_resolved(rowid, 100, rows)
         ctx.sync()
         g = np.zeros((100, stride), np.float32)
         g[:, 1] = rows[:, 1].cpu().numpy()
         grads = torch.from_numpy(g).to(dev)
         torch.cuda.synchronize()
-        ta.shard_push_grad_multi(rowid, keys, np.array([0, 0, 100]), grads)   # applied iff the masks were clean
+        (ta.shard_push_grad_listed if form == "listed" else ta.shard_push_grad_multi)(
+            rowid, keys, np.array([0, 0, 100]), grads)   # applied iff the masks were clean
         ta.check()
         tb.shard_push_grad(keys, 100, grads)
         v2a, _ = ta.pull(universe[:100])

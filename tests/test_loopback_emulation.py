@@ -36,8 +36,10 @@ def dense_rows(vals, lens, k, stride):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,r,mode", [(3, 1, "sync"), (4, 0, "sync"), (3, 2, "overlap"), (8, 5, "overlap")])
-def test_loopback_rank_computes_what_the_real_rank_computes(oracle, W, r, mode):
+@pytest.mark.parametrize("W,r,mode,per_key", [(3, 1, "sync", 0), (4, 0, "sync", 0), (3, 2, "overlap", 0), (8, 5, "overlap", 0),
+                                              (4, 0, "sync", 1), (8, 5, "overlap", 1)])
+def test_loopback_rank_computes_what_the_real_rank_computes(oracle, W, r, mode, per_key):
+    # per_key: ctx option "owner_per_key" — the owner side per distinct key (dfh_shard_count_pull_multi / _push_grad_listed)
     import test_shard_native as T
     from conftest import random_batch
     from difacto_amd import capi, sharded
@@ -62,6 +64,7 @@ def test_loopback_rank_computes_what_the_real_rank_computes(oracle, W, r, mode):
     stride = capi.row_stride(V_DIM)
 
     ctx = capi.Context(0)
+    ctx.set_option("owner_per_key", per_key)
     comm = capi.Comm.loopback(ctx, r, W)
     assert "loop-back" in comm.info()
     tb = capi.Table(ctx, 1 << 16, V_dim=V_DIM, init_mode=capi.INIT_HASH, **HYPER)

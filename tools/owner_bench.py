@@ -2,7 +2,8 @@
 """Owner side of the sharded store alone, at the size rank 0 of an 8-rank C4 job sees (7 source lists of ~18 k keys each
 from other workers' minibatches, data-balanced key ranges, a pre-filled shard): resolve_multi, push_count_multi,
 pull_resolved, push_grad_multi in a loop.  Run under `rocprofv3 --kernel-trace --stats` for per-kernel times
-(tools/gpu_r05e.sh); prints HIP-event times of the groups itself.   usage: owner_bench.py [iters] [vdim] [world]"""
+; prints HIP-event times of the groups itself.   usage: owner_bench.py [iters] [vdim] [world] [entry|listed]
+(listed, round 6: resolve_multi, count_pull_multi, push_grad_listed — the owner side per distinct key, what dfh_shard_step runs)"""
 import os
 import sys
 import time
@@ -17,6 +18,7 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    listed = (sys.argv[4] if len(sys.argv) > 4 else "listed") == "listed"
     from difacto_amd import capi, sharded, synth
     B, S, ids, r = 10000, synth.NUM_SLOTS, 33_000_000, 0
 
@@ -68,14 +70,18 @@ def main():
     for it in range(iters):
         s = sets[it % nd]
         tb.shard_resolve_multi(s["keys"].ptr, s["seg"], rowid.ptr, 0)
-        tb.shard_push_count_multi(rowid.ptr, s["keys"].ptr, s["seg"], s["cnt"].ptr, 0)
-        tb.shard_pull_resolved(rowid.ptr, s["n"], rows.ptr)
-        tb.shard_push_grad_multi(rowid.ptr, s["keys"].ptr, s["seg"], grads.ptr, 0)
+        if listed:
+            tb.shard_count_pull_multi(rowid.ptr, s["keys"].ptr, s["seg"], s["cnt"].ptr, rows.ptr, 0)
+            tb.shard_push_grad_listed(rowid.ptr, s["keys"].ptr, s["seg"], grads.ptr, 0)
+        else:
+            tb.shard_push_count_multi(rowid.ptr, s["keys"].ptr, s["seg"], s["cnt"].ptr, 0)
+            tb.shard_pull_resolved(rowid.ptr, s["n"], rows.ptr)
+            tb.shard_push_grad_multi(rowid.ptr, s["keys"].ptr, s["seg"], grads.ptr, 0)
     ctx.sync()
     tb.check()
     tm = ctx.get_timing(reset=True)
-    print("owner_bench: W=%d k=%d  entries/step %.0f  unique %.0f  (HIP events, incl. launch) %s  wall %.1f us/iter"
-          % (W, k, np.mean([s["n"] for s in sets]), np.mean([s["uniq"] for s in sets]),
+    print("owner_bench (%s): W=%d k=%d  entries/step %.0f  unique %.0f  (HIP events, incl. launch) %s  wall %.1f us/iter"
+          % ("per distinct key" if listed else "per entry", W, k, np.mean([s["n"] for s in sets]), np.mean([s["uniq"] for s in sets]),
              {n: round(v[0] / max(v[1], 1) * 1e3, 1) for n, v in tm.items() if v[1]}, (time.time() - t0) / iters * 1e6))
 
 
