@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--bias-slots", type=int, default=0,
                     help="diagnostic (NOT the metric): the first n slots carry ONE id in every row (a bias-like feature, the token of a "
                          "missing value): keys with B occurrences per minibatch, the update kernel's longest segments")
+    ap.add_argument("--head-share", type=float, default=1.0,
+                    help="with --bias-slots: the share of a slot's rows that carry its one id (1.0: every row; 0.25 over 13 slots is "
+                         "the head of an integer feature of real click logs: thirteen keys of ~2 500 occurrences per minibatch)")
     ap.add_argument("--no-auc", action="store_true",
                     help="A/B: leave BinClassMetric::AUC out of the step (the reference computes it for every minibatch, "
                          "sgd_learner.cc:153-155; the default step does too)")
@@ -421,8 +424,13 @@ def main():
 
         def draw():
             hb = bgen.batch(B)
-            for g in range(min(args.bias_slots, S)):   # (--bias-slots: one id in every row of the slot)
-                hb["index"].reshape(B, S)[:, g] = bgen.ids_of(g, np.zeros(1, np.int64))[0]
+            for g in range(min(args.bias_slots, S)):   # (--bias-slots: one id in every row of the slot, or in --head-share of them)
+                col = hb["index"].reshape(B, S)[:, g]
+                head = bgen.ids_of(g, np.zeros(1, np.int64))[0]
+                if args.head_share >= 1.0:
+                    col[:] = head
+                else:
+                    col[bgen.rng.random(B) < args.head_share] = head
             return hb
         fut_batches = pool.submit(lambda: [draw() for _ in range(nd)])
     else:

@@ -80,12 +80,21 @@ struct SegLists {
   const SegEnt* split_ent;
   const uint32_t* split_n;  // entries in split_ent (device scalar: reset by the Localizer's count pass, filled by k_lookup_step)
 };
-constexpr uint32_t HOT_SPLIT = 1024;       // occurrences per part
-// ... of the segments LONGER than this.  A key of up to ~3 000 occurrences is 12 tiles per wave of its hot-role block: a chain
-// that ends well inside the launch (C3's largest keys, ~1 300 occurrences, split in two cost the default step 2 %: two more
-// blocks' partial sums, a release fence each — profiles/r06n_*); a key in every one of 10 000 rows is 40 tiles per wave and
-// sets the launch's length (120 against 72 us).
-constexpr uint32_t HOT_SPLIT_MIN = 3072;
+#ifndef DFH_HOT_SPLIT
+#define DFH_HOT_SPLIT 1024
+#endif
+#ifndef DFH_HOT_SPLIT_MIN
+#define DFH_HOT_SPLIT_MIN 4096
+#endif
+constexpr uint32_t HOT_SPLIT = DFH_HOT_SPLIT;       // occurrences per part
+// ... of the segments LONGER than this.  A key of up to ~4 000 occurrences is 16 tiles per wave of its hot-role block: a chain
+// that ends inside the launch; a key in every one of 10 000 rows is 40 tiles per wave and sets the launch's length (120 against
+// 72 us).  The crossover, measured on minibatches whose first n slots carry their most popular id in a share f of the rows
+// (bench.py --bias-slots n --head-share f; profiles/r06hs_hot_split_thresholds.txt, one box per table): thirteen keys of
+// 2 500-3 800 occurrences 81.9 M examples/sec split (thresholds 1 536 / 2 048 / 3 072 alike; parts of 512: 80.2) against 84.9-85.5
+// whole; thirteen of 4 000-5 300: 83.5 split against 81.1 whole; 26 of ~5 000: 85.7 against 81.9.  (C3's own largest keys,
+// ~1 300 occurrences, split in two cost the default step 2 % in the role's first form, profiles/r06p_*.)
+constexpr uint32_t HOT_SPLIT_MIN = DFH_HOT_SPLIT_MIN;
 #ifndef DFH_HOT_SPLIT_BUILD
 #define DFH_HOT_SPLIT_BUILD 3   // measurement builds: bit 0 the parts are listed (k_lookup_step), bit 1 k_update_fused has the split role
 #endif

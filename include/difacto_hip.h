@@ -99,7 +99,7 @@ int dfh_ctx_set_pipeline(dfh_ctx* ctx, int enable);
  *   "rider_slot_count / _scatter / _sort / _emit"  0 lookup | 1 forward | 2 update (+ 4: as a launch of its own before it):
  *                                       which launch of a step carries the stage;  "rider_period_lookup / _forward / _update"
  *                                       1 .. 4096 and "rider_start_*" 0 .. 100: where the rider blocks sit in the carrier's grid
- *   "upd_split"         0 | 1           keys with more than 3 072 occurrences in a minibatch go through the update kernel in
+ *   "upd_split"         0 | 1           keys with more than 4 096 occurrences in a minibatch go through the update kernel in
  *                                       parts of 1 024, a block per part (default 1; 0 = one block walks the whole segment)
  *   "owner_per_key"     0 | 1           dfh_shard_step's owner side per distinct key (dfh_shard_count_pull_multi +
  *                                       dfh_shard_push_grad_listed) instead of per received entry; same results, not faster
