@@ -515,6 +515,8 @@ def main():
     # TIMING_EVERY-th step carries a start/stop HIP event pair (hipExtLaunchKernelGGL: the kernel's own
     # begin/end stamps, no marker packets).  Every step would cost the job 3 %, every 4th costs 1 %.
     mask = 0 if args.no_timing else ((1 << capi.K_FORWARD) | (1 << capi.K_BACKWARD))
+    if mask and os.environ.get("DFH_GAP_TRACE"):   # measurement: the lookup dispatch timed too (csrc: dfh_ctx_get_timing prints the gaps)
+        mask |= 1 << capi.K_LOOKUP
     ctx.get_timing(reset=True)
     reps, enq = [], []
     t_all = 0.0

@@ -78,7 +78,7 @@ struct dfh_ctx {
 
   // optional per-kernel HIP-event timing (dfh_ctx_set_timing)
   uint32_t timing = 0;  // bit i: time kernel id i
-  struct Span { int id; hipEvent_t a, b; };
+  struct Span { int id; hipEvent_t a, b; int ride = 0; };  // ride: the events travel on the dispatch itself (main stream)
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
   double t_ms[DFH_K_COUNT] = {0};
@@ -103,7 +103,7 @@ struct TimeScope {
     return e;
   }
   TimeScope(dfh_ctx* ctx, int kid, hipStream_t s = nullptr) : c(ctx), id(kid), st(s ? s : ctx->stream) {
-    if (!((c->timing >> kid) & 1u)) return;
+    if (kid >= DFH_K_COUNT || !((c->timing >> kid) & 1u)) return;
     a = get(c);
     b = get(c);
     if (a && b) (void)hipEventRecord(a, st);
@@ -1120,6 +1120,26 @@ int dfh_ctx_get_timing(dfh_ctx* c, int reset, double* total_ms, uint64_t* calls)
   {
     int rc = sync_all(c);
     if (rc) return rc;
+  }
+  if (getenv("DFH_GAP_TRACE") && c->spans.size() > 1) {
+    double g[DFH_K_COUNT][DFH_K_COUNT] = {};
+    uint64_t n[DFH_K_COUNT][DFH_K_COUNT] = {};
+    const dfh_ctx::Span* prev = nullptr;  // the main stream's launches only: lookup (its own events), forward, update
+    for (const auto& sp : c->spans) {
+      const bool main_launch = sp.ride || sp.id == DFH_K_FORWARD || sp.id == DFH_K_BACKWARD;
+      if (!main_launch) continue;
+      float ms = 0;
+      if (prev && hipEventElapsedTime(&ms, prev->b, sp.a) == hipSuccess) {
+        g[prev->id][sp.id] += ms;
+        n[prev->id][sp.id] += 1;
+      }
+      prev = &sp;
+    }
+    for (int x = 0; x < DFH_K_COUNT; ++x)
+      for (int y = 0; y < DFH_K_COUNT; ++y)
+        if (n[x][y])
+          fprintf(stderr, "gap trace: end of %s -> start of %s: %.2f us on average (%llu pairs)\n", dfh_kernel_name(x), dfh_kernel_name(y),
+                  g[x][y] / n[x][y] * 1e3, (unsigned long long)n[x][y]);
   }
   for (auto& sp : c->spans) {
     float ms = 0;
@@ -3433,7 +3453,15 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
   // along (k_lookup then only reads them)
   const bool defer_cnt = push_cnt && is_train && c->upd_kernel != 0;
   {
-    TimeScope ts(c, DFH_K_LOOKUP);
+    // DFH_GAP_TRACE=1 (measurement): the step's lookup dispatch carries its own start / stop events, like the forward and the
+    // update, and dfh_ctx_get_timing prints the time between the end of one timed launch and the start of the next
+    static const bool gap_trace = getenv("DFH_GAP_TRACE") != nullptr;
+    hipEvent_t la = nullptr, lb = nullptr;
+    if (gap_trace && ((c->timing >> DFH_K_LOOKUP) & 1u)) {
+      la = TimeScope::get(c);
+      lb = TimeScope::get(c);
+    }
+    TimeScope ts(c, (la && lb) ? DFH_K_COUNT : DFH_K_LOOKUP);
     // (the lookup's first block also adds up the AUC slots this batch object's previous step left behind)
     const int gl = grid_for_threads(Nb, c);
     // the pass that sees every unique key's segment lists the parts of the very hot ones for the update's split role
@@ -3445,7 +3473,12 @@ int dfh_sgd_step(dfh_table* t, dfh_batch* b, int is_train, int push_cnt) {
                          b->d_U, 0u, b->d_urow, b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr,
                          push_cnt ? (defer_cnt ? 2 : 1) : 0, refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b),
                          so, (uint32_t)gl, rs);
-    else
+    else if (la && lb) {
+      hipExtLaunchKernelGGL(k_lookup_step, dim3(gl), dim3(256), 0, s, la, lb, 0, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
+                            b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
+                            refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b), so);
+      c->spans.push_back({DFH_K_LOOKUP, la, lb, 1});
+    } else
     hipLaunchKernelGGL(k_lookup_step, dim3(gl), dim3(256), 0, s, t->v, b->d_feaids, b->d_U, 0u, b->d_urow,
                        b->has_cnt ? b->d_feacnt : (const float*)nullptr, b->d_col_ptr, push_cnt ? (defer_cnt ? 2 : 1) : 0,
                        refrand ? b->d_need : (uint32_t*)nullptr, pre ? 1 : 0, uw, auc_pending(b), so);
