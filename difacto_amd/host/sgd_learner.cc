@@ -384,6 +384,17 @@ void SGDLearner::IterateDataFused(const sgd::Job& job, sgd::Progress* progress) 
   const char* sqe = getenv("DIFACTO_SINGLE_QUEUE");
   const bool single_queue = sqe != nullptr && atoi(sqe) != 0;
   DFH_CALL(dfh_ctx_set_option(ctx, "single_queue", single_queue ? 1 : 0));
+  // The preparation streams' priority (DIFACTO_PREP_PRIORITY=-1|0|1; decided by the first job of a process: the streams are
+  // created once).  With the device feed the preparation chain (row gather + Localizer + probe) is as long as the step, and at
+  // the lowest priority — bench.py's setting, whose chain is shorter — it is the chain that sets the pace: default priority,
+  // same box, by this loop's clock, .rec 62.9 / 63.2 -> 66.9 / 64.9 M rows/s, criteo text unchanged (58.5 M: the parsers'
+  // pace), three streams no better (66.6), highest priority worse (60.8) — profiles/r06e2e_prep_priority.txt.
+  static bool prio_set = false;
+  if (!prio_set) {
+    const char* pp = getenv("DIFACTO_PREP_PRIORITY");
+    if (pp || feed_wanted) DFH_CALL(dfh_ctx_set_option(ctx, "prep_priority", pp ? atoi(pp) : 0));
+    prio_set = true;
+  }
   DFH_CALL(dfh_ctx_set_pipeline(ctx, ps ? std::max(1, std::min(atoi(ps), 4)) : (feed_wanted ? 2 : 1)));  // (ignored on the single queue)
   const int ahead = single_queue ? 2 : 1;
   // minibatches are cut (permutation + row selection) two ahead on the reader's own thread, the reference's reader /
