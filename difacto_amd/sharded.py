@@ -177,10 +177,21 @@ def bench_main_native(args, rank, world, local_rank, hyper, cpu_baseline_fn=None
                                "(dfh_comm_wire_probe, %d timed repetitions after 2 untimed); GB/s per link and direction = "
                                "bytes_per_peer / time; max over ranks of the time" % 10)
         for nb in sizes:
-            us = comm.wire_probe(nb, reps=10)
-            t_ = torch.tensor([us], dtype=torch.float64)
+            # a probe that fails on one rank (out of memory for the 2 x peers x bytes buffers, a transport error) must not
+            # leave the others waiting in the reduction below: every rank takes part, the failure travels as a flag, the
+            # remaining sizes are skipped and the measurement itself goes on
+            try:
+                us, bad = comm.wire_probe(nb, reps=10), 0.0
+            except Exception as ex:  # noqa: BLE001
+                us, bad = 0.0, 1.0
+                wire_probe.setdefault("errors", []).append("rank %d, %d bytes per peer: %r" % (rank, nb, ex))
+            t_ = torch.tensor([us, bad], dtype=torch.float64)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            us = float(t_.item())
+            us = float(t_[0].item())
+            if float(t_[1].item()) > 0:
+                wire_probe["per_size"].append(dict(bytes_per_peer=nb, us_per_grouped_exchange=None, gbps_per_link_and_direction=None,
+                                                   error="the probe failed on at least one rank"))
+                break
             wire_probe["per_size"].append(dict(bytes_per_peer=nb, us_per_grouped_exchange=us,
                                                gbps_per_link_and_direction=(nb / us / 1e3) if us > 0 else None))
     gen = synth.CriteoSynth(total_ids=args.ids, seed=42)
