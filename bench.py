@@ -153,7 +153,7 @@ def parse_args():
     return args
 
 
-TIMING_EVERY = int(os.environ.get("DFH_TIMING_EVERY", "4"))  # forward/backward are timed on every n-th step of the timed region
+TIMING_EVERY = int(os.environ.get("DFH_TIMING_EVERY", "8"))  # forward/backward are timed on every n-th step of the timed region
 
 
 def pmc_traffic(kernels, preset):
@@ -513,7 +513,8 @@ def main():
         b.progress(reset=True)
     # live timing of the two big kernels inside the timed region: the k_forward / k_backward_all dispatch of every
     # TIMING_EVERY-th step carries a start/stop HIP event pair (hipExtLaunchKernelGGL: the kernel's own
-    # begin/end stamps, no marker packets).  Every step would cost the job 3 %, every 4th costs 1 %.
+    # begin/end stamps, no marker packets).  Every step would cost the job 3-7 %, every 4th 1 %, every 8th (the default) ~0.5 %:
+    # a dispatch that carries events is followed by ~5 us of idle queue instead of ~1 (profiles/r06gap_step_gaps.txt).
     mask = 0 if args.no_timing else ((1 << capi.K_FORWARD) | (1 << capi.K_BACKWARD))
     if mask and os.environ.get("DFH_GAP_TRACE"):   # measurement: the lookup dispatch timed too (csrc: dfh_ctx_get_timing prints the gaps)
         mask |= 1 << capi.K_LOOKUP
